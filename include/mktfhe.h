@@ -1,0 +1,172 @@
+/*
+ * mktfhe.h -- C ABI of the MI355X-native multi-key TFHE gate-bootstrapping engine.
+ *
+ * Drop-in boundary for the hot path of SNUCP/MKTFHE (reference: Julia, /root/reference/src).
+ * The reference has no FFI; its boundary is the Julia dispatch surface
+ *     bootstrapping!(ctxt::LWE, scheme)          src/tfhe/bootstrapping.jl:4
+ *     NAND/AND/OR/XOR/XNOR/NOR(c1, c2, scheme)   src/tfhe/gate.jl:1-53,  NOT!(c) gate.jl:55
+ *     blindrotate!(atilde, acc, scheme)          bootstrapping.jl:32,:114,:234,:369
+ *     keyswitch!(res, acc, scheme)               bootstrapping.jl:81,:170,:333,:564,:664
+ * A Julia `ccall` shim flattens its pointer-graph objects into the flat
+ * layouts documented here and calls these entry points.  Plain pointers and sizes only.
+ *
+ * Every function returns MKT_OK (0) or a negative mkt_status; none throws.
+ * The engine REQUIRES a gfx950 GPU: there is no CPU fallback on any compute entry point.
+ *
+ * Layouts (0-based, row-major, innermost last)
+ *   LWE ciphertext      : uint32 [k*n + 1] = [a_0 .. a_{k*n-1}, b]   (lwe.jl:1-9; MK mask is the
+ *                         concatenation of k per-party blocks of n words, scheme.jl:379-386)
+ *   ring polynomial     : N ring words; ring word = uint32 if W == 32, uint64 if W == 64
+ *   RLWE accumulator    : [1 + kacc][N] ring words = (b, a_0 .. a_{kacc-1})   (lwe.jl:61-76)
+ *   TransPoly           : M = N/2 complex doubles (re, im interleaved) in the order the reference's
+ *                         transform leaves them (bit-reversed; fft.jl:105-155)
+ *   BRK, RGSW schemes   : per party [n][(kr+1)*l_gsw rows][kr+1 polys] polynomials; rows ordered
+ *                         basketb.stack[0..l), basketa[0].stack[0..l), ...  (gsw.jl:219-227);
+ *                         polys ordered (b, a_0 ..) (lwe.jl:165-179); kr = k (SK) or 1 (KMS)
+ *   BRK, CCS            : per party [n][3*l_uni]: d[0..l), then (f.stack[j].b, f.stack[j].a) j-major
+ *                         (unienc.jl:92-99)
+ *   KSK                 : per party [kr][N][Drows][f][n+1] uint32 LWE rows ([a.., b]); entry d
+ *                         encrypts (d+1)*z_j*2^(32-(t+1)logD); Drows = D-1, or D/2 for the block
+ *                         schemes (keygen.jl:17-23,:37,:141)
+ */
+#ifndef MKTFHE_H
+#define MKTFHE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKT_ABI_VERSION 1
+
+typedef enum {
+    MKT_OK = 0,
+    MKT_ERR_ARG = -1,          /* bad argument / size mismatch (reference: @assert, polynomial.jl:10,19-20) */
+    MKT_ERR_UNSUPPORTED = -2,  /* parameter combination not implemented */
+    MKT_ERR_NO_DEVICE = -3,    /* no gfx950 device / HIP runtime failure at context creation */
+    MKT_ERR_HIP = -4,          /* HIP runtime error, see mkt_last_error */
+    MKT_ERR_STATE = -5,        /* keys not loaded */
+    MKT_ERR_NOMEM = -6
+} mkt_status;
+
+/* scheme kinds: scheme.jl:107 (CGGI), :168 (LMSS), :209 (CCS), :256 (KMS), :301 (KMS_block) */
+enum { MKT_CGGI = 0, MKT_LMSS = 1, MKT_CCS = 2, MKT_KMS = 3, MKT_KMS_BLOCK = 4 };
+/* gates: gate.jl:1-53 */
+enum { MKT_NAND = 0, MKT_AND = 1, MKT_OR = 2, MKT_XOR = 3, MKT_XNOR = 4, MKT_NOR = 5 };
+/* arithmetic modes of the negacyclic transform */
+enum {
+    MKT_ARITH_F64REF = 0, /* the reference's Float64 twisted FFT, operation for operation (fft.jl) */
+    MKT_ARITH_EXACT = 1   /* exact integer NTT -- reserved, returns MKT_ERR_UNSUPPORTED */
+};
+/* where batch pointers live */
+enum { MKT_MEM_DEVICE = 0, MKT_MEM_HOST = 1 };
+/* key data formats */
+enum {
+    MKT_FMT_INT_COEFF = 0, /* coefficient-form ring words; the engine transforms on device
+                              (replaces keygen.jl:14,:67,:99-108 `fft(..., ffter)`) */
+    MKT_FMT_F64_FFT = 1    /* the reference's Trans* values (TransPoly layout above) */
+};
+
+/* parameter block: scheme.jl:6-101 / params.jl.  LWE word is 32 bit in every shipped set. */
+typedef struct {
+    int32_t scheme;          /* MKT_CGGI .. MKT_KMS_BLOCK */
+    int32_t n;               /* LWE dimension per party (block schemes: blk_d * blk_len) */
+    int32_t N;               /* ring dimension (power of two, 256..4096) */
+    int32_t k;               /* SK: RLWE length; MK: number of parties */
+    int32_t W;               /* ring word bits: 32 or 64 */
+    int32_t l_gsw, logB_gsw; /* RGSW gadget (CGGI/LMSS/KMS) */
+    int32_t l_lev, logB_lev; /* LEV gadget (KMS) */
+    int32_t l_uni, logB_uni; /* UniEnc gadget (CCS/KMS) */
+    int32_t f, logD;         /* key-switch gadget */
+    int32_t blk_len, blk_d;  /* block length and count (LMSS/KMS_block) */
+} mkt_params;
+
+typedef struct mkt_ctx mkt_ctx;
+
+/* ---- context: replaces the scheme object (scheme.jl:107-116 ...), FFTransformer (fft.jl:18-45)
+ *      and getmonomial (scheme.jl:121-146), all built on device `device`. ---- */
+int mkt_abi_version(void);
+int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx **out);
+int mkt_ctx_destroy(mkt_ctx *ctx);
+const char *mkt_last_error(const mkt_ctx *ctx); /* ctx may be NULL: last creation error */
+/* HIP stream (hipStream_t) all subsequent batch calls are enqueued on; NULL = default stream */
+int mkt_set_stream(mkt_ctx *ctx, void *hip_stream);
+int mkt_synchronize(mkt_ctx *ctx);
+
+/* twiddle tables (fft.jl:31-41): which = 0 Psi, 1 Psiinv, 2 roots, 3 rootsinv; M complex each.
+ * mkt_set_twiddles lets a caller install the reference's own ffter tables verbatim. */
+int mkt_get_twiddles(mkt_ctx *ctx, int which, double *out_host);
+int mkt_set_twiddles(mkt_ctx *ctx, const double *psi, const double *psiinv,
+                     const double *roots, const double *rootsinv);
+
+/* ---- evaluation keys (host pointers, copied; keygen.jl:3-155) ---- */
+int mkt_load_brk(mkt_ctx *ctx, int party, const void *data, int fmt);
+int mkt_load_ksk(mkt_ctx *ctx, int party, const uint32_t *data);
+int mkt_load_rlk(mkt_ctx *ctx, int party, const void *d, const void *f, int fmt); /* KMS: keygen.jl:103 */
+int mkt_load_pubkey(mkt_ctx *ctx, int party, const void *b, int fmt);             /* CCS/KMS: keygen.jl:67,:100 */
+int mkt_load_crs(mkt_ctx *ctx, const void *a, int fmt);                           /* scheme.jl:409-410 */
+
+/* ---- hot path, batched: B independent ciphertexts per call (the reference does one per call) ---- */
+/* gate.jl:1-53: out = bootstrapping!(linear(op, x, y)); x, y, out: [B][k*n+1] */
+int mkt_gate_batch(mkt_ctx *ctx, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem);
+/* gate.jl:55-58 NOT!: in-place negation, no bootstrap */
+int mkt_not_batch(mkt_ctx *ctx, uint32_t *x, size_t B, int mem);
+/* bootstrapping.jl:4-27 bootstrapping!: in place on [B][k*n+1] */
+int mkt_bootstrap_batch(mkt_ctx *ctx, uint32_t *lwe, size_t B, int mem);
+/* bootstrapping.jl:8-9: atilde [B][k*n], btilde [B] */
+int mkt_modswitch_batch(mkt_ctx *ctx, const uint32_t *lwe, uint32_t *atilde, uint32_t *btilde, size_t B, int mem);
+/* blindrotate!(atilde, acc, scheme): acc [B][1+k][N] ring words, updated in place */
+int mkt_blindrotate_batch(mkt_ctx *ctx, const uint32_t *atilde, void *acc, size_t B, int mem);
+/* keyswitch!(res, acc, scheme): acc [B][1+k][N] -> out [B][k*n+1] */
+int mkt_keyswitch_batch(mkt_ctx *ctx, const void *acc, uint32_t *out, size_t B, int mem);
+/* KMS phase_1 (bootstrapping.jl:389-443 / :599-659) of every party: atilde [B][k*n] ->
+ * levkey [B][Rtot][2][M] complex, Rtot = 1 + (k-1)*l_lev, party-major rows */
+int mkt_kms_phase1_batch(mkt_ctx *ctx, const uint32_t *atilde, double *levkey, size_t B, int mem);
+
+/* ---- unit-level entry points (parity tests, transform roofline) ---- */
+/* fft.jl:57-63 fftto!: p [B][N] ring words -> t [B][M] complex */
+int mkt_transform_fwd_batch(mkt_ctx *ctx, const void *p, double *t, size_t B, int mem);
+/* fft.jl:74-81 ifftto!: t [B][M] complex -> p [B][N] ring words (t is left unmodified) */
+int mkt_transform_inv_batch(mkt_ctx *ctx, const double *t, void *p, size_t B, int mem);
+/* gsw.jl:86-96 decompto!: p [B][N] -> digits [B][l][N] ring words (wrapped signed digits) */
+int mkt_decompose_batch(mkt_ctx *ctx, const void *p, void *digits, int l, int logB, size_t B, int mem);
+/* scheme.jl:121-146: copy monomial table entry e (1..2N) to host, M complex */
+int mkt_get_monomial(mkt_ctx *ctx, int e, double *out_host);
+
+/* average device time (ms) of the most recent batch call's kernels, measured with hipEvents on the
+ * context's stream; `which` selects the kernel class (0 = whole call, 1 = blind rotation,
+ * 2 = key switch, 3 = transform).  Returns <0 if timing was not enabled. */
+int mkt_enable_timing(mkt_ctx *ctx, int on);
+int mkt_last_kernel_ms(mkt_ctx *ctx, int which, double *ms);
+
+/* ---- client side (host only, no GPU): seeded counterparts of the reference's key generation and
+ *      encryption, exact integer arithmetic.  setup/party_keygen scheme.jl:151,:190,:227,:273,:324;
+ *      keygen.jl; lwe_encrypt scheme.jl:352-386; lwe_decrypt scheme.jl:388-407; CRS scheme.jl:409 ---- */
+typedef struct mkt_client_party mkt_client_party;
+/* crs: [l_uni][N] ring words (MK schemes), filled from `seed` */
+int mkt_client_crs(const mkt_params *params, uint64_t seed, void *crs_out);
+/* one party's secret + evaluation keys; crs may be NULL for SK schemes; sigma_lwe/sigma_ring are the
+ * absolute noise standard deviations alpha/beta of params.jl */
+int mkt_client_party_keygen(const mkt_params *params, uint64_t seed, int party, const void *crs,
+                            double sigma_lwe, double sigma_ring, mkt_client_party **out);
+int mkt_client_party_destroy(mkt_client_party *p);
+/* sizes in bytes / pointers to the flat key material (layouts above), valid until destroy */
+const uint32_t *mkt_client_lwekey(const mkt_client_party *p);             /* [n] 0/1 */
+const void *mkt_client_brk(const mkt_client_party *p, size_t *bytes);     /* INT_COEFF */
+const uint32_t *mkt_client_ksk(const mkt_client_party *p, size_t *bytes);
+const void *mkt_client_rlk_d(const mkt_client_party *p, size_t *bytes);
+const void *mkt_client_rlk_f(const mkt_client_party *p, size_t *bytes);
+const void *mkt_client_pubkey(const mkt_client_party *p, size_t *bytes);
+/* lwe_encrypt (SK: party = 0) / lwe_ith_encrypt (MK): out [k*n+1] */
+int mkt_client_lwe_encrypt(const mkt_params *params, const mkt_client_party *p, int party, int bit,
+                           double sigma_lwe, uint64_t seed, uint32_t *out);
+/* lwe_decrypt: keys = nparties pointers; returns 0/1, <0 on error */
+int mkt_client_lwe_decrypt(const mkt_params *params, const mkt_client_party *const *keys, int nparties,
+                           const uint32_t *lwe);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,93 @@
+"""ctypes loader of the engine's C-ABI library (include/mktfhe.h).
+
+The library is built in-tree (mktfhe_amd/lib/libmktfhe_hip.so) by `make -C mktfhe_amd/csrc`
+(see __graft_entry__.build).  There is no Python or CPU fallback for any compute entry point:
+a missing library or a missing gfx950 device raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmktfhe_hip.so")
+
+
+class MktParams(C.Structure):
+    """mkt_params (include/mktfhe.h) -- scheme.jl:6-101 flattened."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "scheme", "n", "N", "k", "W", "l_gsw", "logB_gsw", "l_lev", "logB_lev",
+        "l_uni", "logB_uni", "f", "logD", "blk_len", "blk_d")]
+
+
+class MktError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mktfhe error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/mktfhe.h declares: name -> (restype, argtypes)
+_vp, _i, _sz, _u64, _dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.c_double
+_pp = C.POINTER(MktParams)
+SYMBOLS = {
+    "mkt_abi_version": (_i, []),
+    "mkt_ctx_create": (_i, [_pp, _i, _i, C.POINTER(_vp)]),
+    "mkt_ctx_destroy": (_i, [_vp]),
+    "mkt_last_error": (C.c_char_p, [_vp]),
+    "mkt_set_stream": (_i, [_vp, _vp]),
+    "mkt_synchronize": (_i, [_vp]),
+    "mkt_get_twiddles": (_i, [_vp, _i, _vp]),
+    "mkt_set_twiddles": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mkt_load_brk": (_i, [_vp, _i, _vp, _i]),
+    "mkt_load_ksk": (_i, [_vp, _i, _vp]),
+    "mkt_load_rlk": (_i, [_vp, _i, _vp, _vp, _i]),
+    "mkt_load_pubkey": (_i, [_vp, _i, _vp, _i]),
+    "mkt_load_crs": (_i, [_vp, _vp, _i]),
+    "mkt_gate_batch": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "mkt_not_batch": (_i, [_vp, _vp, _sz, _i]),
+    "mkt_bootstrap_batch": (_i, [_vp, _vp, _sz, _i]),
+    "mkt_modswitch_batch": (_i, [_vp, _vp, _vp, _vp, _sz, _i]),
+    "mkt_blindrotate_batch": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "mkt_keyswitch_batch": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "mkt_kms_phase1_batch": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "mkt_transform_fwd_batch": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "mkt_transform_inv_batch": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "mkt_decompose_batch": (_i, [_vp, _vp, _vp, _i, _i, _sz, _i]),
+    "mkt_get_monomial": (_i, [_vp, _i, _vp]),
+    "mkt_enable_timing": (_i, [_vp, _i]),
+    "mkt_last_kernel_ms": (_i, [_vp, _i, C.POINTER(_dbl)]),
+    "mkt_client_crs": (_i, [_pp, _u64, _vp]),
+    "mkt_client_party_keygen": (_i, [_pp, _u64, _i, _vp, _dbl, _dbl, C.POINTER(_vp)]),
+    "mkt_client_party_destroy": (_i, [_vp]),
+    "mkt_client_lwekey": (_vp, [_vp]),
+    "mkt_client_brk": (_vp, [_vp, C.POINTER(_sz)]),
+    "mkt_client_ksk": (_vp, [_vp, C.POINTER(_sz)]),
+    "mkt_client_rlk_d": (_vp, [_vp, C.POINTER(_sz)]),
+    "mkt_client_rlk_f": (_vp, [_vp, C.POINTER(_sz)]),
+    "mkt_client_pubkey": (_vp, [_vp, C.POINTER(_sz)]),
+    "mkt_client_lwe_encrypt": (_i, [_pp, _vp, _i, _i, _dbl, _u64, _vp]),
+    "mkt_client_lwe_decrypt": (_i, [_pp, C.POINTER(_vp), _i, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library; raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C mktfhe_amd/csrc). mktfhe_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(code, ctx=None):
+    if code < 0:
+        msg = lib().mkt_last_error(ctx)
+        raise MktError(code, msg.decode() if msg else "")
+    return code

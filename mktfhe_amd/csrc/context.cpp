@@ -1,0 +1,569 @@
+// C ABI of the engine (include/mktfhe.h): per-device context, key upload + on-device pre-transform,
+// batched hot-path entry points.  Host code; kernels live in kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_api.h"
+#include "fft_device.h"
+#include "host_internal.h"
+
+using mktd::cplx;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct TimedSpan { int cls; hipEvent_t a, b; };
+}  // namespace
+
+struct mkt_ctx {
+    mkt_params p;
+    mkt::Shape sh;
+    int device = 0;
+    int logM = 0, logN = 0, M = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    mkt::Twiddles tw;
+    // device tables
+    cplx *d_tw = nullptr;        // psi | psiinv | roots | rootsinv, M each
+    cplx *d_monomial = nullptr;  // [2N][M]
+    // keys
+    cplx *d_brk = nullptr;  size_t brk_party_cplx = 0;  std::vector<char> brk_loaded;
+    uint32_t *d_ksk = nullptr; size_t ksk_party_words = 0; std::vector<char> ksk_loaded;
+    cplx *d_rlk_d = nullptr, *d_rlk_f = nullptr, *d_pub = nullptr, *d_crs = nullptr;
+    std::vector<char> rlk_loaded, pub_loaded; bool crs_loaded = false;
+    // rotation slots (KMS phase 1: party-major rows)
+    int rtot = 1;
+    int *d_slot_party = nullptr, *d_slot_row = nullptr;
+    // workspace
+    size_t ws_gates = 0;
+    uint32_t *ws_lin = nullptr;
+    void *ws_acc = nullptr;
+    cplx *ws_lev = nullptr, *ws_scratch = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+
+    mktd::TwPtrs twp() const { return mktd::TwPtrs{d_tw, d_tw + M, d_tw + 2 * (size_t)M, d_tw + 3 * (size_t)M}; }
+};
+
+namespace {
+
+int fail(mkt_ctx *c, int code, const std::string &msg) { if (c) c->err = msg; else g_create_error = msg; return code; }
+int hipfail(mkt_ctx *c, hipError_t e, const char *what) {
+    return fail(c, MKT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(c, call) do { hipError_t _e = (call); if (_e != hipSuccess) return hipfail((c), _e, #call); } while (0)
+
+struct DevGuard {   // make the context's device current for the duration of a call
+    int prev = -1; bool ok = true;
+    explicit DevGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+struct Timer {
+    mkt_ctx *c; int cls; hipEvent_t a = nullptr, b = nullptr;
+    Timer(mkt_ctx *c_, int cls_) : c(c_), cls(cls_) {
+        if (c->timing && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, c->stream);
+        else a = b = nullptr;
+    }
+    ~Timer() { if (a && b) { (void)hipEventRecord(b, c->stream); c->spans.push_back(TimedSpan{cls, a, b}); } }
+};
+
+void clear_spans(mkt_ctx *c) {
+    for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    c->spans.clear();
+}
+
+size_t poly_bytes(const mkt_ctx *c) { return (size_t)c->p.N * c->sh.word; }
+
+// transform `npolys` coefficient-form polynomials (host) into TransPolys at `dst` (device)
+int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt) {
+    if (fmt == MKT_FMT_F64_FFT) {
+        HIPCHK(c, hipMemcpyAsync(dst, host, npolys * (size_t)c->M * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return MKT_OK;
+    }
+    if (fmt != MKT_FMT_INT_COEFF) return fail(c, MKT_ERR_ARG, "unknown key format");
+    void *tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, npolys * poly_bytes(c)));
+    hipError_t e = hipMemcpyAsync(tmp, host, npolys * poly_bytes(c), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return hipfail(c, e, "key pre-transform");
+    return MKT_OK;
+}
+
+int build_monomial(mkt_ctx *c) {   // scheme.jl:121-146
+    const int N = c->p.N;
+    const size_t wb = c->sh.word;
+    std::vector<unsigned char> host((size_t)2 * N * N * wb, 0);
+    auto set = [&](int e, int i, uint64_t v) {
+        unsigned char *p = host.data() + ((size_t)(e - 1) * N + i) * wb;
+        if (wb == 8) std::memcpy(p, &v, 8); else { uint32_t w = (uint32_t)v; std::memcpy(p, &w, 4); }
+    };
+    const uint64_t m1 = ~0ull;
+    for (int e = 1; e < N; e++) { set(e, 0, m1); set(e, e, 1); }            // -1 + X^e
+    set(N, 0, m1 - 1);                                                       // -2
+    for (int e = N + 1; e < 2 * N; e++) { set(e, 0, m1); set(e, e - N, m1); } // -1 - X^(e-N)
+    int r = upload_polys(c, host.data(), (size_t)2 * N, c->d_monomial, MKT_FMT_INT_COEFF);
+    if (r) return r;
+    HIPCHK(c, hipMemsetAsync(c->d_monomial + (size_t)(2 * N - 1) * c->M, 0, (size_t)c->M * sizeof(cplx), c->stream));  // entry 2N = 0
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MKT_OK;
+}
+
+int upload_twiddles(mkt_ctx *c) {
+    const size_t tb = (size_t)c->M * sizeof(cplx);
+    HIPCHK(c, hipMemcpy(c->d_tw, c->tw.psi.data(), tb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_tw + c->M, c->tw.psiinv.data(), tb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_tw + 2 * (size_t)c->M, c->tw.roots.data(), tb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_tw + 3 * (size_t)c->M, c->tw.rootsinv.data(), tb, hipMemcpyHostToDevice));
+    return MKT_OK;
+}
+
+int ensure_workspace(mkt_ctx *c, size_t gates) {
+    if (gates <= c->ws_gates) return MKT_OK;
+    if (c->ws_lin) (void)hipFree(c->ws_lin);
+    if (c->ws_acc) (void)hipFree(c->ws_acc);
+    if (c->ws_lev) (void)hipFree(c->ws_lev);
+    if (c->ws_scratch) (void)hipFree(c->ws_scratch);
+    c->ws_lin = nullptr; c->ws_acc = nullptr; c->ws_lev = nullptr; c->ws_scratch = nullptr; c->ws_gates = 0;
+    const mkt_params &p = c->p;
+    HIPCHK(c, hipMalloc((void **)&c->ws_lin, gates * (size_t)c->sh.lwe_len * 4));
+    HIPCHK(c, hipMalloc(&c->ws_acc, gates * (size_t)(1 + c->sh.kacc) * poly_bytes(c)));
+    if (mkt::is_kms(p.scheme)) {
+        HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * (size_t)c->rtot * 2 * c->M * sizeof(cplx)));
+        HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)2 * (p.k + 1) * c->M * sizeof(cplx)));
+    }
+    c->ws_gates = gates;
+    return MKT_OK;
+}
+
+constexpr size_t CHUNK_GATES = 8192;   // bounds the workspace (KMS N=2048, k=2: ~1.9 GiB)
+
+int check_ready(mkt_ctx *c, bool need_brk, bool need_ksk) {
+    for (int i = 0; i < c->sh.nparty; i++) {
+        if (need_brk && !c->brk_loaded[i]) return fail(c, MKT_ERR_STATE, "bootstrapping key not loaded");
+        if (need_ksk && !c->ksk_loaded[i]) return fail(c, MKT_ERR_STATE, "key-switching key not loaded");
+        if (need_brk && mkt::is_kms(c->p.scheme) && (!c->rlk_loaded[i] || !c->pub_loaded[i])) return fail(c, MKT_ERR_STATE, "rlk / public key not loaded");
+    }
+    if (need_brk && mkt::is_mk(c->p.scheme) && !c->crs_loaded) return fail(c, MKT_ERR_STATE, "crs not loaded");
+    return MKT_OK;
+}
+
+int unsupported_scheme(mkt_ctx *c) {
+    if (c->p.scheme == MKT_CCS) return fail(c, MKT_ERR_UNSUPPORTED, "CCS blind rotation is not implemented yet");
+    if (!mkt::is_kms(c->p.scheme) && c->p.k != 1) return fail(c, MKT_ERR_UNSUPPORTED, "single-key schemes are implemented for RLWE length k = 1");
+    return MKT_OK;
+}
+
+mktd::RotArgs rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
+    const mkt_params &p = c->p;
+    mktd::RotArgs a{};
+    a.tw = c->twp(); a.brk = c->d_brk; a.brk_party_stride = c->brk_party_cplx; a.monomial = c->d_monomial;
+    a.lwe = lwe; a.lwe_stride = stride; a.pre_switched = pre; a.n = p.n; a.logN = c->logN;
+    a.l = p.l_gsw; a.logB = p.logB_gsw;
+    a.blk_len = mkt::is_block(p.scheme) ? p.blk_len : 1;
+    a.blk_accum = mkt::is_block(p.scheme) ? 1 : 0;
+    a.rows_per_gate = c->rtot; a.slot_party = c->d_slot_party; a.slot_row = c->d_slot_row;
+    a.logB_lev = p.logB_lev;
+    return a;
+}
+
+// blind rotation of `B` accumulators resident at `acc` ([B][1+k][N]); atilde source described by (lwe, stride, pre)
+int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const uint32_t *lin_for_tv, void *acc, cplx *lev, cplx *scratch, size_t B) {
+    const mkt_params &p = c->p;
+    if (!mkt::is_kms(p.scheme)) {
+        mktd::RotArgs a = rot_args(c, lwe, stride, pre);
+        a.init_mode = 0; a.out_mode = 0; a.acc_io = acc;
+        Timer tm(c, 1);
+        HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, p.W, a, B, c->stream));
+        return MKT_OK;
+    }
+    {
+        mktd::RotArgs a = rot_args(c, lwe, stride, pre);
+        a.init_mode = 1; a.out_mode = 1; a.tout = lev;
+        Timer tm(c, 1);
+        HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, p.W, a, B * (size_t)c->rtot, c->stream));
+    }
+    mktd::Phase2Args q{};
+    q.tw = c->twp(); q.lin = lin_for_tv; q.lwe_stride = c->sh.lwe_len; q.logN = c->logN;
+    q.k = p.k; q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni;
+    q.levkey = lev; q.rtot = c->rtot; q.rlk_d = c->d_rlk_d; q.rlk_f = c->d_rlk_f; q.pub_b = c->d_pub; q.crs = c->d_crs;
+    q.acc = acc; q.scratch = scratch;
+    Timer tm(c, 4);
+    HIPCHK(c, mktd::launch_kms_phase2(c->logM, p.W, q, B, c->stream));
+    return MKT_OK;
+}
+
+int do_keyswitch(mkt_ctx *c, const void *acc, uint32_t *out, size_t B) {
+    const mkt_params &p = c->p;
+    mktd::KsArgs a{};
+    a.acc = acc; a.out = out; a.ksk = c->d_ksk; a.ksk_party_stride = c->ksk_party_words;
+    a.N = p.N; a.n = p.n; a.f = p.f; a.logD = p.logD; a.drows = c->sh.ksk_drows; a.kacc = c->sh.kacc;
+    a.mk = mkt::is_mk(p.scheme) ? 1 : 0; a.balanced = mkt::is_block(p.scheme) ? 1 : 0; a.lmss = p.scheme == MKT_LMSS ? 1 : 0;
+    Timer tm(c, 2);
+    HIPCHK(c, mktd::launch_keyswitch(p.W, a, B, c->stream));
+    return MKT_OK;
+}
+
+// bootstrapping!(lin) -> out for a device-resident chunk
+int bootstrap_chunk(mkt_ctx *c, const uint32_t *lin, uint32_t *out, size_t B) {
+    const mkt_params &p = c->p;
+    int r;
+    if (!mkt::is_kms(p.scheme)) {
+        HIPCHK(c, mktd::launch_testvector(p.W, lin, c->sh.lwe_len, c->logN, c->sh.kacc, c->ws_acc, B, c->stream));
+        if ((r = do_blindrotate(c, lin, c->sh.lwe_len, 0, nullptr, c->ws_acc, nullptr, nullptr, B))) return r;
+    } else {
+        if ((r = do_blindrotate(c, lin, c->sh.lwe_len, 0, lin, c->ws_acc, c->ws_lev, c->ws_scratch, B))) return r;
+    }
+    return do_keyswitch(c, c->ws_acc, out, B);
+}
+
+// staging helper for MKT_MEM_HOST callers
+struct Staged {
+    mkt_ctx *c; void *dev = nullptr; void *host_out = nullptr; size_t bytes = 0; bool owned = false;
+    int in(const void *ptr, size_t nbytes, int mem, bool copy_in) {
+        bytes = nbytes;
+        if (mem == MKT_MEM_DEVICE) { dev = const_cast<void *>(ptr); return MKT_OK; }
+        hipError_t e = hipMalloc(&dev, nbytes ? nbytes : 1);
+        if (e != hipSuccess) return hipfail(c, e, "hipMalloc(staging)");
+        owned = true;
+        if (copy_in && nbytes) { e = hipMemcpyAsync(dev, ptr, nbytes, hipMemcpyHostToDevice, c->stream); if (e != hipSuccess) return hipfail(c, e, "H2D"); }
+        return MKT_OK;
+    }
+    int out(void *ptr) {
+        if (!owned || !bytes) return MKT_OK;
+        hipError_t e = hipMemcpyAsync(ptr, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hipfail(c, e, "D2H");
+        return MKT_OK;
+    }
+    ~Staged() { if (owned && dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(dev); } }
+};
+
+bool mem_ok(int mem) { return mem == MKT_MEM_DEVICE || mem == MKT_MEM_HOST; }
+
+}  // namespace
+
+extern "C" {
+
+int mkt_abi_version(void) { return MKT_ABI_VERSION; }
+
+const char *mkt_last_error(const mkt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx **out) {
+    if (!params || !out) return fail(nullptr, MKT_ERR_ARG, "null argument");
+    *out = nullptr;
+    std::string why;
+    if (mkt::validate_params(*params, why)) return fail(nullptr, MKT_ERR_ARG, why);
+    if (arith_mode == MKT_ARITH_EXACT) return fail(nullptr, MKT_ERR_UNSUPPORTED, "EXACT (integer NTT) mode is reserved; use MKT_ARITH_F64REF");
+    if (arith_mode != MKT_ARITH_F64REF) return fail(nullptr, MKT_ERR_ARG, "unknown arithmetic mode");
+    const int logN = __builtin_ctz((unsigned)params->N);
+    if (!mktd::transform_supported(logN - 1)) return fail(nullptr, MKT_ERR_UNSUPPORTED, "ring dimension not instantiated (N must be 32..4096)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, MKT_ERR_NO_DEVICE, "no HIP device available: the engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, MKT_ERR_ARG, "device index out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, MKT_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, MKT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", the engine is built for gfx950 only");
+
+    auto *c = new mkt_ctx();
+    c->p = *params; c->sh = mkt::shape_of(*params); c->device = device;
+    c->logN = logN; c->logM = logN - 1; c->M = params->N / 2;
+    DevGuard dg(device);
+    auto bail = [&](int code) { std::string m = c->err; mkt_ctx_destroy(c); g_create_error = m; return code; };
+    if (!dg.ok) { c->err = "hipSetDevice failed"; return bail(MKT_ERR_HIP); }
+    const mkt_params &p = c->p;
+    const int np = c->sh.nparty, N = p.N, M = c->M;
+    c->brk_loaded.assign(np, 0); c->ksk_loaded.assign(np, 0); c->rlk_loaded.assign(np, 0); c->pub_loaded.assign(np, 0);
+    mkt::make_twiddles(N, c->tw);
+#define CK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(_e); return bail(_e == hipErrorOutOfMemory ? MKT_ERR_NOMEM : MKT_ERR_HIP); } } while (0)
+    CK(hipMalloc((void **)&c->d_tw, (size_t)4 * M * sizeof(cplx)));
+    CK(hipMalloc((void **)&c->d_monomial, (size_t)2 * N * M * sizeof(cplx)));
+    c->brk_party_cplx = (size_t)p.n * c->sh.brk_polys * M;
+    CK(hipMalloc((void **)&c->d_brk, (size_t)np * c->brk_party_cplx * sizeof(cplx)));
+    c->ksk_party_words = (size_t)c->sh.ksk_kr * N * c->sh.ksk_drows * p.f * (p.n + 1);
+    CK(hipMalloc((void **)&c->d_ksk, (size_t)np * c->ksk_party_words * sizeof(uint32_t)));
+    if (mkt::is_mk(p.scheme)) {
+        CK(hipMalloc((void **)&c->d_pub, (size_t)np * p.l_uni * M * sizeof(cplx)));
+        CK(hipMalloc((void **)&c->d_crs, (size_t)p.l_uni * M * sizeof(cplx)));
+    }
+    if (mkt::is_kms(p.scheme)) {
+        CK(hipMalloc((void **)&c->d_rlk_d, (size_t)np * p.l_uni * M * sizeof(cplx)));
+        CK(hipMalloc((void **)&c->d_rlk_f, (size_t)np * p.l_uni * 2 * M * sizeof(cplx)));
+    }
+    // rotation slots: KMS phase 1 runs 1 row for party 0 and l_lev rows for the others (bootstrapping.jl:400)
+    std::vector<int> sp, sr;
+    if (mkt::is_kms(p.scheme)) {
+        for (int i = 0; i < p.k; i++) { int rows = i == 0 ? 1 : p.l_lev; for (int r = 0; r < rows; r++) { sp.push_back(i); sr.push_back(r); } }
+    } else { sp.push_back(0); sr.push_back(0); }
+    c->rtot = (int)sp.size();
+    CK(hipMalloc((void **)&c->d_slot_party, sp.size() * sizeof(int)));
+    CK(hipMalloc((void **)&c->d_slot_row, sr.size() * sizeof(int)));
+    CK(hipMemcpy(c->d_slot_party, sp.data(), sp.size() * sizeof(int), hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_slot_row, sr.data(), sr.size() * sizeof(int), hipMemcpyHostToDevice));
+#undef CK
+    int r = upload_twiddles(c);
+    if (!r) r = build_monomial(c);
+    if (r) return bail(r);
+    *out = c;
+    return MKT_OK;
+}
+
+int mkt_ctx_destroy(mkt_ctx *c) {
+    if (!c) return MKT_OK;
+    DevGuard dg(c->device);
+    (void)hipDeviceSynchronize();
+    clear_spans(c);
+    void *ptrs[] = {c->d_tw, c->d_monomial, c->d_brk, c->d_ksk, c->d_rlk_d, c->d_rlk_f, c->d_pub, c->d_crs,
+                    c->d_slot_party, c->d_slot_row, c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete c;
+    return MKT_OK;
+}
+
+int mkt_set_stream(mkt_ctx *c, void *hip_stream) { if (!c) return MKT_ERR_ARG; c->stream = (hipStream_t)hip_stream; return MKT_OK; }
+
+int mkt_synchronize(mkt_ctx *c) {
+    if (!c) return MKT_ERR_ARG;
+    DevGuard dg(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MKT_OK;
+}
+
+int mkt_get_twiddles(mkt_ctx *c, int which, double *out_host) {
+    if (!c || !out_host || which < 0 || which > 3) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out_host, c->d_tw + (size_t)which * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
+    return MKT_OK;
+}
+
+int mkt_set_twiddles(mkt_ctx *c, const double *psi, const double *psiinv, const double *roots, const double *rootsinv) {
+    if (!c || !psi || !psiinv || !roots || !rootsinv) return fail(c, MKT_ERR_ARG, "null table");
+    DevGuard dg(c->device);
+    const size_t nd = (size_t)2 * c->M;
+    c->tw.psi.assign(psi, psi + nd); c->tw.psiinv.assign(psiinv, psiinv + nd);
+    c->tw.roots.assign(roots, roots + nd); c->tw.rootsinv.assign(rootsinv, rootsinv + nd);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int r = upload_twiddles(c);
+    if (r) return r;
+    return build_monomial(c);   // the monomial table depends on the tables (scheme.jl:121-146)
+}
+
+int mkt_get_monomial(mkt_ctx *c, int e, double *out_host) {
+    if (!c || !out_host || e < 1 || e > 2 * c->p.N) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out_host, c->d_monomial + (size_t)(e - 1) * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
+    return MKT_OK;
+}
+
+int mkt_load_brk(mkt_ctx *c, int party, const void *data, int fmt) {
+    if (!c || !data || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    int r = upload_polys(c, data, (size_t)c->p.n * c->sh.brk_polys, c->d_brk + (size_t)party * c->brk_party_cplx, fmt);
+    if (!r) c->brk_loaded[party] = 1;
+    return r;
+}
+
+int mkt_load_ksk(mkt_ctx *c, int party, const uint32_t *data) {
+    if (!c || !data || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    HIPCHK(c, hipMemcpy(c->d_ksk + (size_t)party * c->ksk_party_words, data, c->ksk_party_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->ksk_loaded[party] = 1;
+    return MKT_OK;
+}
+
+int mkt_load_rlk(mkt_ctx *c, int party, const void *d, const void *f, int fmt) {
+    if (!c || !d || !f || party < 0 || party >= c->sh.nparty || !mkt::is_kms(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    const size_t l = (size_t)c->p.l_uni;
+    int r = upload_polys(c, d, l, c->d_rlk_d + (size_t)party * l * c->M, fmt);
+    if (!r) r = upload_polys(c, f, 2 * l, c->d_rlk_f + (size_t)party * 2 * l * c->M, fmt);
+    if (!r) c->rlk_loaded[party] = 1;
+    return r;
+}
+
+int mkt_load_pubkey(mkt_ctx *c, int party, const void *b, int fmt) {
+    if (!c || !b || party < 0 || party >= c->sh.nparty || !mkt::is_mk(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    int r = upload_polys(c, b, (size_t)c->p.l_uni, c->d_pub + (size_t)party * c->p.l_uni * c->M, fmt);
+    if (!r) c->pub_loaded[party] = 1;
+    return r;
+}
+
+int mkt_load_crs(mkt_ctx *c, const void *a, int fmt) {
+    if (!c || !a || !mkt::is_mk(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    int r = upload_polys(c, a, (size_t)c->p.l_uni, c->d_crs, fmt);
+    if (!r) c->crs_loaded = true;
+    return r;
+}
+
+// ---- batched hot path ----
+
+int mkt_gate_batch(mkt_ctx *c, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem) {
+    if (!c || !x || !y || !out || !mem_ok(mem) || op < MKT_NAND || op > MKT_NOR) return fail(c, MKT_ERR_ARG, "bad argument");
+    int r;
+    if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
+    DevGuard dg(c->device);
+    Timer whole(c, 0);
+    const size_t len = (size_t)c->sh.lwe_len;
+    Staged sx{c}, sy{c}, so{c};
+    if ((r = sx.in(x, B * len * 4, mem, true)) || (r = sy.in(y, B * len * 4, mem, true)) || (r = so.in(out, B * len * 4, mem, false))) return r;
+    for (size_t off = 0; off < B; off += CHUNK_GATES) {
+        const size_t nb = std::min(CHUNK_GATES, B - off);
+        if ((r = ensure_workspace(c, nb))) return r;
+        HIPCHK(c, mktd::launch_gate_linear(op, (const uint32_t *)sx.dev + off * len, (const uint32_t *)sy.dev + off * len, c->ws_lin, (int)len, nb, c->stream));
+        if ((r = bootstrap_chunk(c, c->ws_lin, (uint32_t *)so.dev + off * len, nb))) return r;
+    }
+    return so.out(out);
+}
+
+int mkt_not_batch(mkt_ctx *c, uint32_t *x, size_t B, int mem) {
+    if (!c || !x || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    Staged sx{c};
+    int r;
+    const size_t words = B * (size_t)c->sh.lwe_len;
+    if ((r = sx.in(x, words * 4, mem, true))) return r;
+    HIPCHK(c, mktd::launch_negate((uint32_t *)sx.dev, words, c->stream));
+    return sx.out(x);
+}
+
+int mkt_bootstrap_batch(mkt_ctx *c, uint32_t *lwe, size_t B, int mem) {
+    if (!c || !lwe || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    int r;
+    if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
+    DevGuard dg(c->device);
+    Timer whole(c, 0);
+    const size_t len = (size_t)c->sh.lwe_len;
+    Staged sx{c};
+    if ((r = sx.in(lwe, B * len * 4, mem, true))) return r;
+    for (size_t off = 0; off < B; off += CHUNK_GATES) {
+        const size_t nb = std::min(CHUNK_GATES, B - off);
+        if ((r = ensure_workspace(c, nb))) return r;
+        uint32_t *chunk = (uint32_t *)sx.dev + off * len;
+        // the rotation reads the masks, phase 2 / the test vector read b, all before key switching overwrites them
+        if ((r = bootstrap_chunk(c, chunk, chunk, nb))) return r;
+    }
+    return sx.out(lwe);
+}
+
+int mkt_modswitch_batch(mkt_ctx *c, const uint32_t *lwe, uint32_t *atilde, uint32_t *btilde, size_t B, int mem) {
+    if (!c || !lwe || !atilde || !btilde || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    const size_t len = (size_t)c->sh.lwe_len;
+    Staged sl{c}, sa{c}, sb{c};
+    int r;
+    if ((r = sl.in(lwe, B * len * 4, mem, true)) || (r = sa.in(atilde, B * (len - 1) * 4, mem, false)) || (r = sb.in(btilde, B * 4, mem, false))) return r;
+    HIPCHK(c, mktd::launch_modswitch((const uint32_t *)sl.dev, (uint32_t *)sa.dev, (uint32_t *)sb.dev, (int)len, c->logN, B, c->stream));
+    if ((r = sa.out(atilde))) return r;
+    return sb.out(btilde);
+}
+
+int mkt_blindrotate_batch(mkt_ctx *c, const uint32_t *atilde, void *acc, size_t B, int mem) {
+    if (!c || !atilde || !acc || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    int r;
+    if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, false))) return r;
+    DevGuard dg(c->device);
+    Timer whole(c, 0);
+    const size_t alen = (size_t)c->sh.lwe_len - 1, accb = (size_t)(1 + c->sh.kacc) * poly_bytes(c);
+    Staged sa{c}, sc{c};
+    if ((r = sa.in(atilde, B * alen * 4, mem, true)) || (r = sc.in(acc, B * accb, mem, true))) return r;
+    for (size_t off = 0; off < B; off += CHUNK_GATES) {
+        const size_t nb = std::min(CHUNK_GATES, B - off);
+        if ((r = ensure_workspace(c, nb))) return r;
+        if ((r = do_blindrotate(c, (const uint32_t *)sa.dev + off * alen, (int)alen, 1, nullptr, (char *)sc.dev + off * accb, c->ws_lev, c->ws_scratch, nb))) return r;
+    }
+    return sc.out(acc);
+}
+
+int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, size_t B, int mem) {
+    if (!c || !atilde || !levkey || !mem_ok(mem) || !mkt::is_kms(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    int r;
+    if ((r = check_ready(c, true, false))) return r;
+    DevGuard dg(c->device);
+    const size_t alen = (size_t)c->sh.lwe_len - 1, lb = (size_t)c->rtot * 2 * c->M * sizeof(cplx);
+    Staged sa{c}, sl{c};
+    if ((r = sa.in(atilde, B * alen * 4, mem, true)) || (r = sl.in(levkey, B * lb, mem, false))) return r;
+    mktd::RotArgs a = rot_args(c, (const uint32_t *)sa.dev, (int)alen, 1);
+    a.init_mode = 1; a.out_mode = 1; a.tout = (cplx *)sl.dev;
+    { Timer tm(c, 1); HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, c->p.W, a, B * (size_t)c->rtot, c->stream)); }
+    return sl.out(levkey);
+}
+
+int mkt_keyswitch_batch(mkt_ctx *c, const void *acc, uint32_t *out, size_t B, int mem) {
+    if (!c || !acc || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    int r;
+    if ((r = check_ready(c, false, true))) return r;
+    DevGuard dg(c->device);
+    const size_t accb = (size_t)(1 + c->sh.kacc) * poly_bytes(c), len = (size_t)c->sh.lwe_len;
+    Staged sc{c}, so{c};
+    if ((r = sc.in(acc, B * accb, mem, true)) || (r = so.in(out, B * len * 4, mem, false))) return r;
+    if ((r = do_keyswitch(c, sc.dev, (uint32_t *)so.dev, B))) return r;
+    return so.out(out);
+}
+
+int mkt_transform_fwd_batch(mkt_ctx *c, const void *p, double *t, size_t B, int mem) {
+    if (!c || !p || !t || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    Staged sp{c}, st{c};
+    int r;
+    if ((r = sp.in(p, B * poly_bytes(c), mem, true)) || (r = st.in(t, B * (size_t)c->M * sizeof(cplx), mem, false))) return r;
+    { Timer tm(c, 3); HIPCHK(c, mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), sp.dev, (cplx *)st.dev, B, c->stream)); }
+    return st.out(t);
+}
+
+int mkt_transform_inv_batch(mkt_ctx *c, const double *t, void *p, size_t B, int mem) {
+    if (!c || !p || !t || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    Staged st{c}, sp{c};
+    int r;
+    if ((r = st.in(t, B * (size_t)c->M * sizeof(cplx), mem, true)) || (r = sp.in(p, B * poly_bytes(c), mem, false))) return r;
+    { Timer tm(c, 3); HIPCHK(c, mktd::launch_transform_inv(c->logM, c->p.W, c->twp(), (const cplx *)st.dev, sp.dev, B, c->stream)); }
+    return sp.out(p);
+}
+
+int mkt_decompose_batch(mkt_ctx *c, const void *p, void *digits, int l, int logB, size_t B, int mem) {
+    if (!c || !p || !digits || !mem_ok(mem) || l < 1 || logB < 1 || l * logB > c->p.W) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    Staged sp{c}, sd{c};
+    int r;
+    if ((r = sp.in(p, B * poly_bytes(c), mem, true)) || (r = sd.in(digits, B * (size_t)l * poly_bytes(c), mem, false))) return r;
+    HIPCHK(c, mktd::launch_decompose(c->p.W, sp.dev, sd.dev, c->p.N, l, logB, B, c->stream));
+    return sd.out(digits);
+}
+
+int mkt_enable_timing(mkt_ctx *c, int on) {
+    if (!c) return MKT_ERR_ARG;
+    DevGuard dg(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    clear_spans(c);
+    c->timing = on != 0;
+    return MKT_OK;
+}
+
+// sum of the recorded spans of class `which` since timing was enabled (ms); *ms / count = average launch
+int mkt_last_kernel_ms(mkt_ctx *c, int which, double *ms) {
+    if (!c || !ms) return MKT_ERR_ARG;
+    if (!c->timing) return fail(c, MKT_ERR_STATE, "timing not enabled");
+    DevGuard dg(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double tot = 0.0; int cnt = 0;
+    for (auto &s : c->spans) if (s.cls == which) { float f = 0; if (hipEventElapsedTime(&f, s.a, s.b) == hipSuccess) { tot += f; cnt++; } }
+    *ms = tot;
+    return cnt;
+}
+
+}  // extern "C"

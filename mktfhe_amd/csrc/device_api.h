@@ -1,0 +1,78 @@
+// Host-callable launchers of the HIP kernels (kernels.hip).  Internal to the library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mktd {
+
+struct cplx;
+
+struct TwPtrs { const cplx *psi, *psiinv, *roots, *rootsinv; };
+
+// Blind rotation with an RLWE accumulator of length 1 (b, a): CGGI/LMSS with k = 1 and every row of
+// KMS / KMS_block phase 1.  One workgroup per rotation.
+struct RotArgs {
+    TwPtrs tw;
+    const cplx *brk;          // party 0 base; [n][2l rows][2 polys][M]
+    size_t brk_party_stride;  // in cplx
+    const cplx *monomial;     // [2N][M], entry e-1
+    const uint32_t *lwe;      // [B][lwe_stride]: LWE words (mod-switched on the fly) or atilde
+    int lwe_stride;
+    int pre_switched;         // 1: `lwe` already holds atilde values
+    int n, logN;
+    int l, logB;              // RGSW gadget
+    int blk_len;              // 1, or the block length of LMSS / KMS_block
+    int blk_accum;            // block schemes: tacc2 += monomial*tacc form (bootstrapping.jl:157,:648)
+    int rows_per_gate;        // rotations per ciphertext
+    const int *slot_party;    // [rows_per_gate]
+    const int *slot_row;      // [rows_per_gate]
+    int init_mode;            // 0: load acc from acc_io; 1: trivial RLEV row b = 2^(W-(row+1)*logB_lev)
+    int logB_lev;
+    int out_mode;             // 0: write acc to acc_io; 1: write fft(acc) to tout
+    void *acc_io;             // [rot][2][N] ring words
+    cplx *tout;               // [rot][2][M]
+};
+
+// KMS phase 2 (bootstrapping.jl:448-558), one workgroup per ciphertext.
+struct Phase2Args {
+    TwPtrs tw;
+    const uint32_t *lin;      // [B][lwe_stride] linear-combined LWE (b last) for the test vector, or NULL
+    int lwe_stride;
+    int logN;
+    int k, l_lev, logB_lev, l_uni, logB_uni;
+    const cplx *levkey;       // [B][Rtot][2][M]
+    int rtot;
+    const cplx *rlk_d;        // [k][l_uni][M]
+    const cplx *rlk_f;        // [k][l_uni][2][M]
+    const cplx *pub_b;        // [k][l_uni][M]
+    const cplx *crs;          // [l_uni][M]
+    void *acc;                // [B][1+k][N] ring words (in: test vector unless lin != NULL; out: result)
+    cplx *scratch;            // [B][2*(k+1)][M]
+};
+
+struct KsArgs {
+    const void *acc;          // [B][1+kacc][N] ring words
+    uint32_t *out;            // [B][lwe_len]
+    const uint32_t *ksk;      // party 0 base
+    size_t ksk_party_stride;  // words
+    int N, n, f, logD, drows;
+    int kacc;                 // ring components
+    int mk;                   // 1: component i -> party i's KSK and mask block i; 0: single block, ksk comp i
+    int balanced;             // block schemes: copy the first words, balanced digits
+    int lmss;                 // LMSS flavour of the copy rule (global coefficient index across components)
+};
+
+hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, hipStream_t s);
+hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void *p, size_t B, hipStream_t s);
+hipError_t launch_decompose(int W, const void *p, void *digits, int N, int l, int logB, size_t B, hipStream_t s);
+hipError_t launch_gate_linear(int op, const uint32_t *x, const uint32_t *y, uint32_t *out, int len, size_t B, hipStream_t s);
+hipError_t launch_negate(uint32_t *x, size_t words, hipStream_t s);
+hipError_t launch_modswitch(const uint32_t *lwe, uint32_t *atilde, uint32_t *btilde, int len, int logN, size_t B, hipStream_t s);
+hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int logN, int kacc, void *acc, size_t B, hipStream_t s);
+hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s);
+hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hipStream_t s);
+hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s);
+bool transform_supported(int logM);
+
+}  // namespace mktd

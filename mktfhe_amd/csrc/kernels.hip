@@ -1,0 +1,674 @@
+// HIP kernels of the gate-bootstrapping hot path for gfx950 (CDNA4, wave64).
+// Hand-written for MI355X only; no portability layers.  All floating point is IEEE double with
+// contraction off (one rounding per reference operation); see fft_device.h for the mapping.
+#include "device_api.h"
+#include "fft_device.h"
+
+#pragma clang fp contract(off)
+
+namespace mktd {
+
+constexpr int LOGR = 2;  // points per thread = 4
+
+extern __shared__ __attribute__((aligned(16))) unsigned char mkt_smem[];
+
+// ------------------------------------------------------------------------------------------------
+// batched transforms (fft.jl:57-63 / :74-81): HBM -> HBM, one polynomial per workgroup pass
+// ------------------------------------------------------------------------------------------------
+template <int LOGM, typename WORD>
+__global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(TwPtrs tw, const WORD *__restrict__ p,
+                                                                            cplx *__restrict__ out, size_t B) {
+    using P = Plan<LOGM, LOGR>;
+    constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
+    cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
+    const int t = threadIdx.x;
+    cplx rt[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) rt[e] = tw.roots[e * NT + t];
+    for (size_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const WORD *pp = p + b * N;
+        cplx z[R];
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            const int idx = e * NT + t;
+            cplx v;
+            v.re = word_to_f64<WORD>(pp[idx]);
+            v.im = word_to_f64<WORD>((WORD)((WORD)0 - pp[idx + M]));   // subtraction in the integer type (fft.jl:60)
+            z[e] = cmul(v, rt[e]);
+        }
+        fft_forward<LOGM, LOGR>(z, tw.psi, lds, t);
+        cplx *o = out + b * M + (size_t)t * R;
+#pragma unroll
+        for (int e = 0; e < R; e++) o[e] = z[e];
+    }
+}
+
+template <int LOGM, typename WORD>
+__global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_inv_kernel(TwPtrs tw, const cplx *__restrict__ in,
+                                                                            WORD *__restrict__ p, size_t B) {
+    using P = Plan<LOGM, LOGR>;
+    constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
+    cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
+    const int t = threadIdx.x;
+    cplx ri[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) ri[e] = tw.rootsinv[e * NT + t];
+    for (size_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const cplx *i = in + b * M + (size_t)t * R;
+        cplx z[R];
+#pragma unroll
+        for (int e = 0; e < R; e++) z[e] = i[e];
+        fft_inverse<LOGM, LOGR>(z, tw.psiinv, lds, t);
+        WORD *pp = p + b * N;
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            const int idx = e * NT + t;
+            const cplx v = cmul(z[e], ri[e]);
+            pp[idx] = native<WORD>(v.re);
+            pp[idx + M] = native<WORD>(-v.im);
+        }
+    }
+}
+
+// gsw.jl:86-96 decompto!(avec, a, params) on a batch
+template <typename WORD>
+__global__ void decompose_kernel(const WORD *__restrict__ p, WORD *__restrict__ dig, int N, int l, int logB, size_t total) {
+    const Gadget<WORD> gd(l, logB);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / N, c = i % N;
+        const WORD tp = gd.prep(p[i]);
+        for (int j = 0; j < l; j++) dig[(b * l + j) * N + c] = (WORD)(typename WordTraits<WORD>::S)gd.digit(tp, j);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gate.jl:1-58, bootstrapping.jl:8-23: linear part, mod-switch, test vector
+// ------------------------------------------------------------------------------------------------
+__global__ void gate_linear_kernel(int op, const uint32_t *__restrict__ x, const uint32_t *__restrict__ y,
+                                   uint32_t *__restrict__ out, int len, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const bool isb = (int)(i % len) == len - 1;
+        const uint32_t a = x[i], b = y[i];
+        uint32_t r;
+        switch (op) {
+        case 0:  r = (isb ? (1u << 29) : 0u) - a - b; break;              // NAND gate.jl:1-8
+        case 1:  r = (isb ? (7u << 29) : 0u) + a + b; break;              // AND  :10-17
+        case 2:  r = (isb ? (1u << 29) : 0u) + a + b; break;              // OR   :19-26
+        case 3:  r = (isb ? (1u << 30) : 0u) + 2u * (a + b); break;       // XOR  :28-35
+        case 4:  r = (isb ? (3u << 30) : 0u) - 2u * (a + b); break;       // XNOR :37-44
+        default: r = (isb ? (7u << 29) : 0u) - a - b; break;              // NOR  :46-53
+        }
+        out[i] = r;
+    }
+}
+
+__global__ void negate_kernel(uint32_t *x, size_t total) {   // gate.jl:55-58
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) x[i] = 0u - x[i];
+}
+
+__global__ void modswitch_kernel(const uint32_t *__restrict__ lwe, uint32_t *__restrict__ at, uint32_t *__restrict__ bt,
+                                 int len, int logN, size_t total) {
+    const int bit = 32 - logN - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / len; const int c = (int)(i % len);
+        const uint32_t v = divbits<uint32_t>(lwe[i], bit);
+        if (c == len - 1) bt[g] = v; else at[g * (len - 1) + c] = v;
+    }
+}
+
+// bootstrapping.jl:11-23: acc = (testvector(btilde), 0 ...)
+template <typename WORD>
+__global__ void testvector_kernel(const uint32_t *__restrict__ lin, int lwe_stride, int logN, int kacc, WORD *__restrict__ acc) {
+    constexpr int W = WordTraits<WORD>::W;
+    const int N = 1 << logN;
+    const size_t g = blockIdx.x;
+    uint32_t tb = divbits<uint32_t>(lin[g * lwe_stride + lwe_stride - 1], 32 - logN - 1);
+    const WORD e = (WORD)1 << (W - 3), me = (WORD)((WORD)0 - e);
+    WORD lo_v = e, hi_v = me;
+    if (tb > (uint32_t)N) { tb -= (uint32_t)N; lo_v = me; hi_v = e; }
+    WORD *a = acc + g * (size_t)(1 + kacc) * N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) a[i] = ((uint32_t)i < tb) ? lo_v : hi_v;
+    for (int i = threadIdx.x; i < kacc * N; i += blockDim.x) a[N + i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// digit -> transform helper: z[e] = (d(c_idx) - i*d(c_{idx+M})) * roots[idx]   (fft.jl:57-63)
+// ------------------------------------------------------------------------------------------------
+template <typename WORD, int R>
+__device__ __forceinline__ void digit_points(cplx (&z)[R], const WORD (&tp)[R][2], const Gadget<WORD> &gd, int j, const cplx (&rt)[R]) {
+#pragma unroll
+    for (int e = 0; e < R; e++) {
+        const int d0 = gd.digit(tp[e][0], j), d1 = gd.digit(tp[e][1], j);
+        cplx v; v.re = (double)d0; v.im = (double)(-d1);
+        z[e] = cmul(v, rt[e]);
+    }
+}
+
+// inverse transform of a transform-domain accumulator followed by native() (fft.jl:74-81)
+template <int LOGM, typename WORD>
+__device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)[1 << LOGR][2], const TwPtrs &tw, cplx *lds, int t) {
+    using P = Plan<LOGM, LOGR>;
+    fft_inverse<LOGM, LOGR>(z, tw.psiinv, lds, t);
+#pragma unroll
+    for (int e = 0; e < P::R; e++) {
+        const cplx v = cmul(z[e], tw.rootsinv[e * P::NT + t]);
+        w[e][0] = native<WORD>(v.re);
+        w[e][1] = native<WORD>(-v.im);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Blind rotation, RLWE length 1.  bootstrapping.jl:32-76 (CGGI), :114-165 (LMSS), :389-443 and
+// :599-659 (KMS / KMS_block phase 1).  One workgroup per rotation; the accumulator (2 polynomials)
+// and the transform-domain accumulator stay in registers for all n CMux steps; LDS only stages the
+// in-transform exchanges.  LB = block length (1 for the plain schemes).
+// ------------------------------------------------------------------------------------------------
+template <int LOGM, typename WORD, int LB>
+__global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_k1_kernel(const RotArgs a) {
+    using P = Plan<LOGM, LOGR>;
+    constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
+    cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
+    const int t = threadIdx.x;
+    const size_t rot = blockIdx.x;
+    const size_t gate = rot / (size_t)a.rows_per_gate;
+    const int slot = (int)(rot % (size_t)a.rows_per_gate);
+    const int party = a.slot_party[slot], row = a.slot_row[slot];
+    const uint32_t *at_src = a.lwe + gate * (size_t)a.lwe_stride + (size_t)party * a.n;
+    const cplx *brk = a.brk + (size_t)party * a.brk_party_stride;
+    const Gadget<WORD> gd(a.l, a.logB);
+    const int l = a.l;
+
+    WORD acc[2][R][2];
+    if (a.init_mode == 0) {
+        const WORD *src = reinterpret_cast<const WORD *>(a.acc_io) + rot * 2 * N;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < R; e++) { acc[c][e][0] = src[c * N + e * NT + t]; acc[c][e][1] = src[c * N + M + e * NT + t]; }
+    } else {   // bootstrapping.jl:403-406: b = gvec_lev[row] at X^0, a = 0
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < R; e++) { acc[c][e][0] = 0; acc[c][e][1] = 0; }
+        if (t == 0) acc[0][0][0] = (WORD)1 << (W - (row + 1) * a.logB_lev);
+    }
+    cplx rt[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) rt[e] = a.tw.roots[e * NT + t];
+
+    const int nblk = a.n / LB;
+    const int msbit = 32 - a.logN - 1;
+    for (int blk = 0; blk < nblk; blk++) {
+        uint32_t ats[LB];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < LB; q++) {
+            const uint32_t v = at_src[blk * LB + q];
+            ats[q] = a.pre_switched ? v : divbits<uint32_t>(v, msbit);   // bootstrapping.jl:8
+            any |= ats[q] != 0;
+        }
+        if (!any) continue;                                              // :48 / :145 / :413 / :638
+
+        cplx tacc[LB][2][R];
+#pragma unroll
+        for (int q = 0; q < LB; q++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int e = 0; e < R; e++) { tacc[q][c][e].re = 0.0; tacc[q][c][e].im = 0.0; }
+
+#pragma unroll
+        for (int c = 0; c < 2; c++) {                                    // digits of b first, then of a (:63-68)
+            WORD tp[R][2];
+#pragma unroll
+            for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(acc[c][e][0]); tp[e][1] = gd.prep(acc[c][e][1]); }
+            for (int j = 0; j < l; j++) {
+                cplx z[R];
+                digit_points<WORD, R>(z, tp, gd, j, rt);                 // :50-51 decompto!
+                fft_forward<LOGM, LOGR>(z, a.tw.psi, lds, t);            // :54-59 fftto!
+#pragma unroll
+                for (int q = 0; q < LB; q++) {
+                    if (ats[q] == 0) continue;
+                    const cplx *krow = brk + (((size_t)(blk * LB + q) * 2 * l + (size_t)(c * l + j)) * 2) * M + (size_t)t * R;
+#pragma unroll
+                    for (int e = 0; e < R; e++) {                        // :63-68 muladdto!(tacc, digit, row)
+                        tacc[q][0][e] = cadd(tacc[q][0][e], cmul(z[e], krow[e]));
+                        tacc[q][1][e] = cadd(tacc[q][1][e], cmul(z[e], krow[M + e]));
+                    }
+                }
+            }
+        }
+
+        cplx t2[2][R];
+        if (LB == 1 && !a.blk_accum) {                               // :71 mul!(monomial[atilde], tacc)
+            const cplx *mono = a.monomial + (size_t)(ats[0] - 1) * M + (size_t)t * R;
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int e = 0; e < R; e++) t2[c][e] = cmul(mono[e], tacc[0][c][e]);
+        } else {                                                         // :157 / :648 tacc2 += monomial * tacc
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int e = 0; e < R; e++) { t2[c][e].re = 0.0; t2[c][e].im = 0.0; }
+#pragma unroll
+            for (int q = 0; q < LB; q++) {
+                if (ats[q] == 0) continue;
+                const cplx *mono = a.monomial + (size_t)(ats[q] - 1) * M + (size_t)t * R;
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int e = 0; e < R; e++) t2[c][e] = cadd(t2[c][e], cmul(mono[e], tacc[q][c][e]));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {                                    // :72-73 ifftto!, add!
+            WORD w[R][2];
+            inverse_to_words<LOGM, WORD>(t2[c], w, a.tw, lds, t);
+#pragma unroll
+            for (int e = 0; e < R; e++) { acc[c][e][0] = (WORD)(acc[c][e][0] + w[e][0]); acc[c][e][1] = (WORD)(acc[c][e][1] + w[e][1]); }
+        }
+    }
+
+    if (a.out_mode == 0) {
+        WORD *dst = reinterpret_cast<WORD *>(a.acc_io) + rot * 2 * N;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < R; e++) { dst[c * N + e * NT + t] = acc[c][e][0]; dst[c * N + M + e * NT + t] = acc[c][e][1]; }
+    } else {                                                             // :441 / :657 fftto!(tacc, acc)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            cplx z[R];
+#pragma unroll
+            for (int e = 0; e < R; e++) {
+                cplx v; v.re = word_to_f64<WORD>(acc[c][e][0]); v.im = word_to_f64<WORD>((WORD)((WORD)0 - acc[c][e][1]));
+                z[e] = cmul(v, rt[e]);
+            }
+            fft_forward<LOGM, LOGR>(z, a.tw.psi, lds, t);
+            cplx *o = a.tout + (rot * 2 + c) * M + (size_t)t * R;
+#pragma unroll
+            for (int e = 0; e < R; e++) o[e] = z[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// KMS phase 2 (bootstrapping.jl:448-558): k sequential merges, one workgroup per ciphertext.
+// < 1 % of the bootstrap's transforms; polynomials stream through a per-ciphertext scratch area,
+// every thread only ever touches its own points / coefficients, so no inter-thread ordering is needed
+// outside the transforms.
+// ------------------------------------------------------------------------------------------------
+template <int LOGM, typename WORD>
+__global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(const Phase2Args a) {
+    using P = Plan<LOGM, LOGR>;
+    constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
+    cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
+    const int t = threadIdx.x;
+    const size_t g = blockIdx.x;
+    const int k = a.k;
+    WORD *acc = reinterpret_cast<WORD *>(a.acc) + g * (size_t)(k + 1) * N;
+    cplx *tx = a.scratch + g * (size_t)2 * (k + 1) * M;
+    cplx *ty2 = tx + (size_t)(k + 1) * M;
+    const Gadget<WORD> glev(a.l_lev, a.logB_lev), guni(a.l_uni, a.logB_uni);
+    const size_t pt = (size_t)t * R;
+
+    cplx rt[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) rt[e] = a.tw.roots[e * NT + t];
+
+    if (a.lin) {                                                          // bootstrapping.jl:11-23
+        uint32_t tb = divbits<uint32_t>(a.lin[g * a.lwe_stride + a.lwe_stride - 1], 32 - a.logN - 1);
+        const WORD ev = (WORD)1 << (W - 3), me = (WORD)((WORD)0 - ev);
+        WORD lo_v = ev, hi_v = me;
+        if (tb > (uint32_t)N) { tb -= (uint32_t)N; lo_v = me; hi_v = ev; }
+#pragma unroll
+        for (int e = 0; e < R; e++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = h * M + e * NT + t;
+                acc[i] = ((uint32_t)i < tb) ? lo_v : hi_v;
+                for (int q = 1; q <= k; q++) acc[(size_t)q * N + i] = 0;
+            }
+    }
+
+    for (int idx = 0; idx < k; idx++) {
+        const int iter = idx == 0 ? 1 : a.l_lev;                          // :481
+        const int rowbase = idx == 0 ? 0 : 1 + (idx - 1) * a.l_lev;
+        const cplx *lev = a.levkey + (g * (size_t)a.rtot + rowbase) * 2 * M;   // stack[r].b, stack[r].a
+        const cplx *rd = a.rlk_d + (size_t)idx * a.l_uni * M;
+        const cplx *rf = a.rlk_f + (size_t)idx * a.l_uni * 2 * M;
+        cplx tv[R];
+#pragma unroll
+        for (int e = 0; e < R; e++) { tv[e].re = 0.0; tv[e].im = 0.0; }
+
+        for (int q = 0; q <= idx; q++) {                                  // input polys: b, a_0 .. a_{idx-1}
+            WORD tp[R][2];
+#pragma unroll
+            for (int e = 0; e < R; e++) {
+                tp[e][0] = glev.prep(acc[(size_t)q * N + e * NT + t]);    // :470-471
+                tp[e][1] = glev.prep(acc[(size_t)q * N + M + e * NT + t]);
+            }
+            cplx txq[R], tyq[R];
+#pragma unroll
+            for (int e = 0; e < R; e++) { txq[e].re = txq[e].im = 0.0; tyq[e].re = tyq[e].im = 0.0; }
+            for (int j = 0; j < iter; j++) {                              // :485-499 LEV multiplication
+                cplx z[R];
+                digit_points<WORD, R>(z, tp, glev, j, rt);
+                fft_forward<LOGM, LOGR>(z, a.tw.psi, lds, t);
+                const cplx *kb = lev + (size_t)(2 * j) * M + pt, *ka = kb + M;
+#pragma unroll
+                for (int e = 0; e < R; e++) { txq[e] = cadd(txq[e], cmul(z[e], kb[e])); tyq[e] = cadd(tyq[e], cmul(z[e], ka[e])); }
+            }
+#pragma unroll
+            for (int e = 0; e < R; e++) tx[(size_t)q * M + pt + e] = txq[e];
+            WORD yw[R][2];
+            inverse_to_words<LOGM, WORD>(tyq, yw, a.tw, lds, t);          // :501-504
+#pragma unroll
+            for (int e = 0; e < R; e++) { tp[e][0] = guni.prep(yw[e][0]); tp[e][1] = guni.prep(yw[e][1]); }   // :508-509
+            cplx tyu[R];
+#pragma unroll
+            for (int e = 0; e < R; e++) { tyu[e].re = tyu[e].im = 0.0; }
+            const cplx *vk = q == 0 ? a.crs : a.pub_b + (size_t)(q - 1) * a.l_uni * M;
+            for (int j = 0; j < a.l_uni; j++) {                           // :521-535 u and v
+                cplx z[R];
+                digit_points<WORD, R>(z, tp, guni, j, rt);
+                fft_forward<LOGM, LOGR>(z, a.tw.psi, lds, t);
+                const cplx *kd = rd + (size_t)j * M + pt, *kv = vk + (size_t)j * M + pt;
+#pragma unroll
+                for (int e = 0; e < R; e++) {
+                    tyu[e] = cadd(tyu[e], cmul(z[e], kd[e]));
+                    const cplx pr = cmul(z[e], kv[e]);
+                    tv[e] = q == 0 ? csub(tv[e], pr) : cadd(tv[e], pr);   // mulsubto! with crs, muladdto! with b_i
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < R; e++) ty2[(size_t)q * M + pt + e] = tyu[e];
+        }
+
+        WORD vw[R][2];
+        inverse_to_words<LOGM, WORD>(tv, vw, a.tw, lds, t);               // :538
+        WORD tp[R][2];
+#pragma unroll
+        for (int e = 0; e < R; e++) { tp[e][0] = guni.prep(vw[e][0]); tp[e][1] = guni.prep(vw[e][1]); }      // :541
+        cplx tyb[R], tya[R];
+#pragma unroll
+        for (int e = 0; e < R; e++) { tyb[e] = ty2[pt + e]; tya[e].re = tya[e].im = 0.0; }
+        for (int i = 0; i < a.l_uni; i++) {                               // :547-550 w
+            cplx z[R];
+            digit_points<WORD, R>(z, tp, guni, i, rt);
+            fft_forward<LOGM, LOGR>(z, a.tw.psi, lds, t);
+            const cplx *fb = rf + (size_t)(2 * i) * M + pt, *fa = fb + M;
+#pragma unroll
+            for (int e = 0; e < R; e++) { tyb[e] = cadd(tyb[e], cmul(z[e], fb[e])); tya[e] = cadd(tya[e], cmul(z[e], fa[e])); }
+        }
+        // :553 add!(tx, ty); :556 ifftto!(acc, tx)
+        for (int q = 0; q <= idx + 1; q++) {
+            cplx s[R];
+#pragma unroll
+            for (int e = 0; e < R; e++) {
+                cplx xv, yv;
+                if (q <= idx) xv = tx[(size_t)q * M + pt + e]; else { xv.re = 0.0; xv.im = 0.0; }
+                if (q == 0) yv = tyb[e]; else if (q == idx + 1) yv = tya[e]; else yv = ty2[(size_t)q * M + pt + e];
+                s[e] = cadd(xv, yv);
+            }
+            WORD w[R][2];
+            inverse_to_words<LOGM, WORD>(s, w, a.tw, lds, t);
+#pragma unroll
+            for (int e = 0; e < R; e++) { acc[(size_t)q * N + e * NT + t] = w[e][0]; acc[(size_t)q * N + M + e * NT + t] = w[e][1]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sample extract + LWE key switch.  bootstrapping.jl:81-109 (CGGI), :170-229 (LMSS), :333-364 (CCS),
+// :564-594 (KMS), :664-695 (KMS_block).  Gather-accumulate of pre-multiplied LWE rows; u32 wrap adds
+// are order independent, so the per-party partial sums (and the atomics on b) are deterministic.
+// grid = (B, parties or 1); 256 threads, thread t owns output words t, t+256, ...
+// ------------------------------------------------------------------------------------------------
+template <typename WORD>
+__device__ __forceinline__ uint32_t extract_word(const WORD *a, int j, int N) {   // :91,:99 ; KMS :575,:583
+    constexpr int sh = WordTraits<WORD>::W - 32;
+    if (j == 0) return (uint32_t)(a[0] >> sh);
+    return 0u - (uint32_t)(a[N - j] >> sh);
+}
+
+template <typename WORD>
+__global__ void ks_init_kernel(const WORD *__restrict__ acc, uint32_t *__restrict__ out, int kacc, int N, int lwe_len, size_t B) {
+    constexpr int sh = WordTraits<WORD>::W - 32;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < B; g += (size_t)gridDim.x * blockDim.x)
+        out[g * lwe_len + lwe_len - 1] = (uint32_t)(acc[g * (size_t)(1 + kacc) * N] >> sh);   // :86 / :569
+}
+
+constexpr int KS_THREADS = 256, KS_MAXU = 4;
+
+template <typename WORD>
+__global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(const KsArgs a) {
+    const int t = threadIdx.x;
+    const size_t g = blockIdx.x;
+    const int N = a.N, n = a.n, n1 = n + 1, f = a.f, logD = a.logD;
+    const WORD *accg = reinterpret_cast<const WORD *>(a.acc) + g * (size_t)(1 + a.kacc) * N;
+    const int nblocks_out = a.mk ? a.kacc : 1;
+    const int lwe_len = nblocks_out * n + 1;
+    uint32_t *outg = a.out + g * (size_t)lwe_len;
+    const int c_begin = a.mk ? (int)blockIdx.y : 0, c_end = a.mk ? c_begin + 1 : a.kacc;
+    const uint32_t Dm = (1u << logD) - 1;
+    const Gadget<uint32_t> gb(f, logD);
+    const size_t comp_words = (size_t)N * a.drows * f * n1;
+    uint32_t sum[KS_MAXU];
+#pragma unroll
+    for (int u = 0; u < KS_MAXU; u++) sum[u] = 0;
+
+    for (int c = c_begin; c < c_end; c++) {
+        const WORD *ac = accg + (size_t)(1 + c) * N;
+        const uint32_t *ksk = a.mk ? a.ksk + (size_t)c * a.ksk_party_stride : a.ksk + (size_t)c * comp_words;
+        int jstart = 0;
+        if (a.balanced) {   // block schemes: the first words are copied (added at the end), not switched
+            if (a.lmss) { const long cur = (long)c * N; jstart = cur >= n ? 0 : (cur + N <= n ? N : (int)(n - cur)); }
+            else jstart = n;
+        }
+        for (int j = jstart; j < N; j++) {
+            const uint32_t w = extract_word<WORD>(ac, j, N);
+            const uint32_t *rowj = ksk + (size_t)j * a.drows * f * n1;
+            if (!a.balanced) {
+                const uint32_t tt = divbits<uint32_t>(w, 32 - f * logD);     // gsw.jl:34-40
+                for (int td = 0; td < f; td++) {
+                    const uint32_t d = (tt >> (logD * (f - 1 - td))) & Dm;
+                    if (d == 0) continue;
+                    const uint32_t *row = rowj + ((size_t)(d - 1) * f + td) * n1;
+#pragma unroll
+                    for (int u = 0; u < KS_MAXU; u++) { const int q = t + u * KS_THREADS; if (q < n1) sum[u] += row[q]; }
+                }
+            } else {
+                const uint32_t tp = gb.prep(w);                              // gsw.jl:42-52
+                for (int td = 0; td < f; td++) {
+                    const int d = gb.digit(tp, td);
+                    if (d == 0) continue;
+                    const int ad = d > 0 ? d : -d;
+                    const uint32_t *row = rowj + ((size_t)(ad - 1) * f + td) * n1;
+                    if (d > 0) {
+#pragma unroll
+                        for (int u = 0; u < KS_MAXU; u++) { const int q = t + u * KS_THREADS; if (q < n1) sum[u] += row[q]; }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < KS_MAXU; u++) { const int q = t + u * KS_THREADS; if (q < n1) sum[u] -= row[q]; }
+                    }
+                }
+            }
+        }
+    }
+    // write the mask block (+ copied words for the block schemes) and fold b
+    const int blk = a.mk ? c_begin : 0;
+#pragma unroll
+    for (int u = 0; u < KS_MAXU; u++) {
+        const int q = t + u * KS_THREADS;
+        if (q < n) {
+            uint32_t v = sum[u];
+            if (a.balanced) {
+                if (a.lmss) { const int c = q / N, j = q % N; v += extract_word<WORD>(accg + (size_t)(1 + c) * N, j, N); }
+                else v += extract_word<WORD>(accg + (size_t)(1 + blk) * N, q, N);
+            }
+            outg[(size_t)blk * n + q] = v;
+        } else if (q == n) {
+            atomicAdd(&outg[lwe_len - 1], sum[u]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int blocks_for(size_t total, int threads) {
+    size_t b = (total + threads - 1) / threads;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <typename K>
+static hipError_t set_lds(K kern, size_t bytes) {
+    if (bytes > 48 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipSuccess;
+}
+
+bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
+
+#define MKT_DISPATCH_LOGM(logM, ...)                 \
+    switch (logM) {                                  \
+    case 4:  { constexpr int LM = 4;  __VA_ARGS__; } break; \
+    case 5:  { constexpr int LM = 5;  __VA_ARGS__; } break; \
+    case 6:  { constexpr int LM = 6;  __VA_ARGS__; } break; \
+    case 7:  { constexpr int LM = 7;  __VA_ARGS__; } break; \
+    case 8:  { constexpr int LM = 8;  __VA_ARGS__; } break; \
+    case 9:  { constexpr int LM = 9;  __VA_ARGS__; } break; \
+    case 10: { constexpr int LM = 10; __VA_ARGS__; } break; \
+    case 11: { constexpr int LM = 11; __VA_ARGS__; } break; \
+    default: return hipErrorInvalidValue;            \
+    }
+
+hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, hipStream_t s) {
+    if (B == 0) return hipSuccess;
+    const int grid = (int)(B < 4096 ? B : 4096);
+    MKT_DISPATCH_LOGM(logM, {
+        using P = Plan<LM, LOGR>;
+        if (W == 64) {
+            hipError_t e = set_lds(transform_fwd_kernel<LM, uint64_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, (const uint64_t *)p, t, B);
+        } else {
+            hipError_t e = set_lds(transform_fwd_kernel<LM, uint32_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, (const uint32_t *)p, t, B);
+        }
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void *p, size_t B, hipStream_t s) {
+    if (B == 0) return hipSuccess;
+    const int grid = (int)(B < 4096 ? B : 4096);
+    MKT_DISPATCH_LOGM(logM, {
+        using P = Plan<LM, LOGR>;
+        if (W == 64) {
+            hipError_t e = set_lds(transform_inv_kernel<LM, uint64_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((transform_inv_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, t, (uint64_t *)p, B);
+        } else {
+            hipError_t e = set_lds(transform_inv_kernel<LM, uint32_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((transform_inv_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, t, (uint32_t *)p, B);
+        }
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_decompose(int W, const void *p, void *digits, int N, int l, int logB, size_t B, hipStream_t s) {
+    const size_t total = B * (size_t)N;
+    if (!total) return hipSuccess;
+    if (W == 64) hipLaunchKernelGGL(decompose_kernel<uint64_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const uint64_t *)p, (uint64_t *)digits, N, l, logB, total);
+    else hipLaunchKernelGGL(decompose_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const uint32_t *)p, (uint32_t *)digits, N, l, logB, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_gate_linear(int op, const uint32_t *x, const uint32_t *y, uint32_t *out, int len, size_t B, hipStream_t s) {
+    const size_t total = B * (size_t)len;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(gate_linear_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, op, x, y, out, len, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_negate(uint32_t *x, size_t words, hipStream_t s) {
+    if (!words) return hipSuccess;
+    hipLaunchKernelGGL(negate_kernel, dim3(blocks_for(words, 256)), dim3(256), 0, s, x, words);
+    return hipGetLastError();
+}
+
+hipError_t launch_modswitch(const uint32_t *lwe, uint32_t *atilde, uint32_t *btilde, int len, int logN, size_t B, hipStream_t s) {
+    const size_t total = B * (size_t)len;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(modswitch_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, lwe, atilde, btilde, len, logN, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int logN, int kacc, void *acc, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    if (W == 64) hipLaunchKernelGGL(testvector_kernel<uint64_t>, dim3((unsigned)B), dim3(256), 0, s, lin, lwe_stride, logN, kacc, (uint64_t *)acc);
+    else hipLaunchKernelGGL(testvector_kernel<uint32_t>, dim3((unsigned)B), dim3(256), 0, s, lin, lwe_stride, logN, kacc, (uint32_t *)acc);
+    return hipGetLastError();
+}
+
+template <int LM, typename WORD>
+static hipError_t launch_rot_lb(const RotArgs &a, size_t nrot, hipStream_t s) {
+    using P = Plan<LM, LOGR>;
+#define MKT_ROT(LBV)                                                                                          \
+    {                                                                                                         \
+        hipError_t e = set_lds(blindrotate_k1_kernel<LM, WORD, LBV>, P::LDS_BYTES); if (e != hipSuccess) return e; \
+        hipLaunchKernelGGL((blindrotate_k1_kernel<LM, WORD, LBV>), dim3((unsigned)nrot), dim3(P::NT), P::LDS_BYTES, s, a); \
+    }
+    switch (a.blk_len) {
+    case 1: MKT_ROT(1) break;
+    case 2: MKT_ROT(2) break;
+    case 3: MKT_ROT(3) break;
+    case 4: MKT_ROT(4) break;
+    default: return hipErrorInvalidValue;
+    }
+#undef MKT_ROT
+    return hipGetLastError();
+}
+
+hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s) {
+    if (!nrot) return hipSuccess;
+    MKT_DISPATCH_LOGM(logM, {
+        if (W == 64) return launch_rot_lb<LM, uint64_t>(a, nrot, s);
+        return launch_rot_lb<LM, uint32_t>(a, nrot, s);
+    });
+    return hipSuccess;
+}
+
+hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    MKT_DISPATCH_LOGM(logM, {
+        using P = Plan<LM, LOGR>;
+        if (W == 64) {
+            hipError_t e = set_lds(kms_phase2_kernel<LM, uint64_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((kms_phase2_kernel<LM, uint64_t>), dim3((unsigned)B), dim3(P::NT), P::LDS_BYTES, s, a);
+        } else {
+            hipError_t e = set_lds(kms_phase2_kernel<LM, uint32_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((kms_phase2_kernel<LM, uint32_t>), dim3((unsigned)B), dim3(P::NT), P::LDS_BYTES, s, a);
+        }
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    if (a.n + 1 > KS_THREADS * KS_MAXU) return hipErrorInvalidValue;
+    const int lwe_len = (a.mk ? a.kacc : 1) * a.n + 1;
+    const dim3 grid((unsigned)B, a.mk ? a.kacc : 1);
+    if (W == 64) {
+        hipLaunchKernelGGL(ks_init_kernel<uint64_t>, dim3(blocks_for(B, 256)), dim3(256), 0, s, (const uint64_t *)a.acc, a.out, a.kacc, a.N, lwe_len, B);
+        hipLaunchKernelGGL(keyswitch_kernel<uint64_t>, grid, dim3(KS_THREADS), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(ks_init_kernel<uint32_t>, dim3(blocks_for(B, 256)), dim3(256), 0, s, (const uint32_t *)a.acc, a.out, a.kacc, a.N, lwe_len, B);
+        hipLaunchKernelGGL(keyswitch_kernel<uint32_t>, grid, dim3(KS_THREADS), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mktd

@@ -1,0 +1,87 @@
+"""The reference's shipped parameter sets, mirrored as data (src/tfhe/params.jl:1-125; field
+meaning src/tfhe/scheme.jl:6-101).  alpha / beta are absolute noise standard deviations."""
+from dataclasses import dataclass, replace
+
+from ._lib import MktParams
+
+CGGI, LMSS, CCS, KMS, KMS_BLOCK = range(5)
+NAND_OP, AND_OP, OR_OP, XOR_OP, XNOR_OP, NOR_OP = range(6)
+
+
+@dataclass(frozen=True)
+class Params:
+    name: str
+    scheme: int
+    n: int
+    N: int
+    k: int
+    W: int
+    alpha: float
+    beta: float
+    l_gsw: int = 0
+    logB_gsw: int = 0
+    l_lev: int = 0
+    logB_lev: int = 0
+    l_uni: int = 0
+    logB_uni: int = 0
+    f: int = 8
+    logD: int = 2
+    blk_len: int = 0
+    blk_d: int = 0
+
+    @property
+    def multikey(self):
+        return self.scheme in (CCS, KMS, KMS_BLOCK)
+
+    @property
+    def nparty(self):
+        return self.k if self.multikey else 1
+
+    @property
+    def lwe_len(self):
+        return self.nparty * self.n + 1
+
+    @property
+    def ring_dtype(self):
+        import numpy as np
+        return np.uint64 if self.W == 64 else np.uint32
+
+    def c(self):
+        return MktParams(self.scheme, self.n, self.N, self.k, self.W, self.l_gsw, self.logB_gsw, self.l_lev,
+                         self.logB_lev, self.l_uni, self.logB_uni, self.f, self.logD, self.blk_len, self.blk_d)
+
+    def scaled(self, **kw):
+        """a reduced copy for fast tests (e.g. n=16, N=256)"""
+        return replace(self, **kw)
+
+
+# params.jl:1-6, :8-13
+CGGIparam = Params("CGGIparam", CGGI, 630, 1024, 1, 32, 2.0**17, 2.0**7, l_gsw=3, logB_gsw=9)
+Blockparam = Params("Blockparam", LMSS, 229 * 3, 1024, 1, 32, 2.0**17, 2.0**7, l_gsw=3, logB_gsw=9, blk_len=3, blk_d=229)
+
+
+def _ccs(k, l, logB):   # params.jl:15-45
+    return Params(f"CCS{k}party", CCS, 560, 1024, k, 32, 2.0**17, 2.0**4, l_uni=l, logB_uni=logB)
+
+
+CCS2party, CCS4party, CCS8party, CCS16party = _ccs(2, 3, 8), _ccs(4, 4, 8), _ccs(8, 5, 6), _ccs(16, 12, 2)
+
+
+def _kms(k, g, lv, u, block=False):   # params.jl:47-125
+    kw = dict(l_gsw=g[0], logB_gsw=g[1], l_lev=lv[0], logB_lev=lv[1], l_uni=u[0], logB_uni=u[1])
+    if block:
+        return Params(f"KMS{k}partyblock", KMS_BLOCK, 203 * 3, 2048, k, 64, 2.0**17, 85.4084, blk_len=3, blk_d=203, **kw)
+    return Params(f"KMS{k}party", KMS, 560, 2048, k, 64, 2.0**17, 85.4084, **kw)
+
+
+_KMS_G = {2: ((3, 12), (2, 7), (3, 10)), 4: ((5, 8), (2, 8), (7, 6)), 8: ((4, 9), (3, 6), (8, 4)),
+          16: ((5, 8), (3, 6), (9, 4)), 32: ((6, 7), (3, 7), (16, 2))}
+KMS2party, KMS4party, KMS8party, KMS16party, KMS32party = (_kms(k, *_KMS_G[k]) for k in (2, 4, 8, 16, 32))
+KMS2partyblock, KMS4partyblock, KMS8partyblock, KMS16partyblock, KMS32partyblock = (
+    _kms(k, *_KMS_G[k], block=True) for k in (2, 4, 8, 16, 32))
+
+# BASELINE.json config 2: "KMS multi-key k=2, N=1024, l=2" -- NOT a shipped constant of the reference
+# (SURVEY.md 0.5); a legal KMSparams value used as the synthetic performance shape.  Decryption
+# correctness at this shape is not vouched for by the reference.
+KMS2party_N1024_l2 = Params("KMS2party_N1024_l2", KMS, 560, 1024, 2, 64, 2.0**17, 85.4084,
+                            l_gsw=2, logB_gsw=16, l_lev=2, logB_lev=7, l_uni=3, logB_uni=10)

@@ -1,0 +1,372 @@
+"""Host-side mirror of the reference's operator surface for the gate-bootstrapping path.
+
+Reference (Julia, /root/reference/src): exports at MKTFHE.jl:21-35 --
+    setup, party_keygen, CRS, lwe_encrypt, lwe_ith_encrypt, lwe_decrypt      tfhe/scheme.jl
+    bootstrapping!                                                            tfhe/bootstrapping.jl:4
+    NAND, AND, OR, XOR, XNOR, NOR, NOT!                                       tfhe/gate.jl
+plus the internal blindrotate! / keyswitch! named by the north star.  Same names and argument
+meaning (`!` dropped: in-place functions carry a trailing underscore); every ciphertext argument
+is a BATCH: a numpy uint32 array (..., k*n+1) in host memory or a torch CUDA int32/uint32 tensor
+(device memory, zero copy).  All compute goes through the C ABI (include/mktfhe.h); this module
+holds no arithmetic of its own and raises if the HIP library or a gfx950 GPU is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MktError, check
+from .params import CGGI, LMSS, CCS, KMS, KMS_BLOCK, Params
+
+MEM_DEVICE, MEM_HOST = 0, 1
+FMT_INT_COEFF, FMT_F64_FFT = 0, 1
+ARITH_F64REF, ARITH_EXACT = 0, 1
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _arg(x, dtype, writable=False):
+    """-> (pointer, mem kind, keepalive, numpy-or-tensor)"""
+    if _is_torch(x):
+        if not x.is_cuda:
+            raise ValueError("torch tensors must live on the GPU; pass numpy arrays for host memory")
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        if x.element_size() != np.dtype(dtype).itemsize:
+            raise ValueError(f"tensor element size {x.element_size()} does not match {np.dtype(dtype)}")
+        return C.c_void_p(x.data_ptr()), MEM_DEVICE, x
+    a = np.ascontiguousarray(x, dtype=dtype)
+    if writable and a is not x:
+        raise ValueError("output / in-place argument must be a contiguous numpy array of dtype %s" % np.dtype(dtype))
+    return _np_ptr(a), MEM_HOST, a
+
+
+# ------------------------------------------------------------------------------------------------
+# client side: CRS, party_keygen / setup keys, encrypt, decrypt  (CPU, exact integer arithmetic)
+# ------------------------------------------------------------------------------------------------
+def CRS(params: Params, seed=0):
+    """scheme.jl:409-410 CRS(params): l_uni uniform ring polynomials -> (l_uni, N) ring words"""
+    out = np.empty((params.l_uni, params.N), dtype=params.ring_dtype)
+    check(_lib.lib().mkt_client_crs(C.byref(params.c()), seed, _np_ptr(out)))
+    return out
+
+
+class PartyKeys:
+    """One party's secret and evaluation keys (party_keygen, scheme.jl:227,:273,:324; setup for the
+    single-key schemes, scheme.jl:151,:190).  Evaluation keys are in integer (coefficient) form."""
+
+    def __init__(self, params: Params, seed=0, party=0, crs=None):
+        self.params, self.party = params, party
+        h = C.c_void_p()
+        crs_p = _np_ptr(np.ascontiguousarray(crs, dtype=params.ring_dtype)) if crs is not None else None
+        check(_lib.lib().mkt_client_party_keygen(C.byref(params.c()), seed, party, crs_p,
+                                                 params.alpha, params.beta, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _lib.lib().mkt_client_party_destroy(self.h)
+            self.h = None
+
+    def _buf(self, fn, dtype):
+        n = C.c_size_t(0)
+        p = fn(self.h, C.byref(n))
+        if not n.value:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).view(dtype)
+
+    @property
+    def lwekey(self):
+        p = _lib.lib().mkt_client_lwekey(self.h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(self.params.n,))
+
+    @property
+    def brk(self):
+        return self._buf(_lib.lib().mkt_client_brk, self.params.ring_dtype)
+
+    @property
+    def ksk(self):
+        return self._buf(_lib.lib().mkt_client_ksk, np.uint32)
+
+    @property
+    def rlk_d(self):
+        return self._buf(_lib.lib().mkt_client_rlk_d, self.params.ring_dtype)
+
+    @property
+    def rlk_f(self):
+        return self._buf(_lib.lib().mkt_client_rlk_f, self.params.ring_dtype)
+
+    @property
+    def pubkey(self):
+        return self._buf(_lib.lib().mkt_client_pubkey, self.params.ring_dtype)
+
+
+def party_keygen(a, params: Params, seed=0, party=0):
+    """scheme.jl:227/:273/:324 party_keygen(a, params) -> PartyKeys (lwekey + bootstrapping key)"""
+    return PartyKeys(params, seed=seed, party=party, crs=a)
+
+
+def lwe_encrypt(m, key: PartyKeys, params: Params, seed=0):
+    """scheme.jl:352-368 lwe_encrypt(m, key, params) (single-key schemes)"""
+    return lwe_ith_encrypt(m, 0, key, params, seed)
+
+
+def lwe_ith_encrypt(m, i, key: PartyKeys, params: Params, seed=0):
+    """scheme.jl:370-386 lwe_ith_encrypt(m, i, key, params); i is the 0-based party index"""
+    out = np.empty(params.lwe_len, dtype=np.uint32)
+    check(_lib.lib().mkt_client_lwe_encrypt(C.byref(params.c()), key.h, i, int(bool(m)), params.alpha, seed, _np_ptr(out)))
+    return out
+
+
+def lwe_decrypt(ctxt, keys, params: Params):
+    """scheme.jl:388-407 lwe_decrypt(lwe, key(s)[, params]) -> bool (or array of bool for a batch)"""
+    keys = [keys] if isinstance(keys, PartyKeys) else list(keys)
+    arr = (C.c_void_p * len(keys))(*[k.h for k in keys])
+    c = np.ascontiguousarray(ctxt, dtype=np.uint32)
+    flat = c.reshape(-1, params.lwe_len)
+    res = np.empty(flat.shape[0], dtype=bool)
+    for j in range(flat.shape[0]):
+        res[j] = bool(check(_lib.lib().mkt_client_lwe_decrypt(C.byref(params.c()), arr, len(keys), _np_ptr(flat[j]))))
+    return res.reshape(c.shape[:-1]) if c.ndim > 1 else bool(res[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluator: the scheme object lives on one MI355X
+# ------------------------------------------------------------------------------------------------
+class Scheme:
+    """The reference's CGGI / LMSS / CCS / KMS / KMS_block scheme object (scheme.jl:107-116, :168-179,
+    :209-219, :256-265, :301-312) as a per-device engine context: twiddle tables (fft.jl:18-45),
+    monomial table (scheme.jl:121-146) and the pre-transformed evaluation keys, all resident in HBM."""
+
+    def __init__(self, params: Params, device=0, arith=ARITH_F64REF):
+        self.params = params
+        self.device = device
+        h = C.c_void_p()
+        check(_lib.lib().mkt_ctx_create(C.byref(params.c()), arith, device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().mkt_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _ck(self, code):
+        return check(code, self.h)
+
+    # -- keys
+    def load_party(self, party, keys: PartyKeys = None, *, brk=None, ksk=None, rlk_d=None, rlk_f=None, pubkey=None, fmt=FMT_INT_COEFF):
+        L, p = _lib.lib(), self.params
+        if keys is not None:
+            brk, ksk, rlk_d, rlk_f, pubkey = keys.brk, keys.ksk, keys.rlk_d, keys.rlk_f, keys.pubkey
+        kd = np.complex128 if fmt == FMT_F64_FFT else p.ring_dtype
+        if brk is not None:
+            self._ck(L.mkt_load_brk(self.h, party, _np_ptr(np.ascontiguousarray(brk, dtype=kd)), fmt))
+        if ksk is not None:
+            self._ck(L.mkt_load_ksk(self.h, party, _np_ptr(np.ascontiguousarray(ksk, dtype=np.uint32))))
+        if rlk_d is not None:
+            self._ck(L.mkt_load_rlk(self.h, party, _np_ptr(np.ascontiguousarray(rlk_d, dtype=kd)),
+                                    _np_ptr(np.ascontiguousarray(rlk_f, dtype=kd)), fmt))
+        if pubkey is not None:
+            self._ck(L.mkt_load_pubkey(self.h, party, _np_ptr(np.ascontiguousarray(pubkey, dtype=kd)), fmt))
+
+    def load_crs(self, a, fmt=FMT_INT_COEFF):
+        kd = np.complex128 if fmt == FMT_F64_FFT else self.params.ring_dtype
+        self._ck(_lib.lib().mkt_load_crs(self.h, _np_ptr(np.ascontiguousarray(a, dtype=kd)), fmt))
+
+    def set_stream(self, stream_handle):
+        self._ck(_lib.lib().mkt_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self._ck(_lib.lib().mkt_synchronize(self.h))
+
+    # -- tables (tests)
+    def twiddles(self, which):
+        out = np.empty(self.params.N // 2, dtype=np.complex128)
+        self._ck(_lib.lib().mkt_get_twiddles(self.h, which, _np_ptr(out)))
+        return out
+
+    def monomial(self, e):
+        out = np.empty(self.params.N // 2, dtype=np.complex128)
+        self._ck(_lib.lib().mkt_get_monomial(self.h, e, _np_ptr(out)))
+        return out
+
+    # -- timing
+    def enable_timing(self, on=True):
+        self._ck(_lib.lib().mkt_enable_timing(self.h, int(on)))
+
+    def kernel_ms(self, which):
+        """(total ms, launches) of kernel class `which` since enable_timing: 0 whole call, 1 blind
+        rotation, 2 key switch, 3 transform, 4 KMS phase 2"""
+        ms = C.c_double(0)
+        n = self._ck(_lib.lib().mkt_last_kernel_ms(self.h, which, C.byref(ms)))
+        return ms.value, n
+
+    # -- hot path
+    def _batch(self, x):
+        return int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+
+    def gate(self, op, x, y, out=None):
+        px, mem, kx = _arg(x, np.uint32)
+        py, mem2, ky = _arg(y, np.uint32)
+        if mem != mem2:
+            raise ValueError("x and y must both be host arrays or both be GPU tensors")
+        if out is None:
+            out = kx.new_empty(kx.shape) if mem == MEM_DEVICE else np.empty_like(kx)
+        po, mem3, ko = _arg(out, np.uint32, writable=True)
+        if mem3 != mem:
+            raise ValueError("out must live where the inputs live")
+        if tuple(kx.shape) != tuple(ky.shape) or kx.shape[-1] != self.params.lwe_len:
+            raise ValueError("ciphertext shape mismatch")       # reference: @assert length checks
+        self._ck(_lib.lib().mkt_gate_batch(self.h, op, px, py, po, self._batch(kx), mem))
+        return ko
+
+    def bootstrapping_(self, ctxt):
+        p, mem, k = _arg(ctxt, np.uint32, writable=True)
+        if k.shape[-1] != self.params.lwe_len:
+            raise ValueError("ciphertext shape mismatch")
+        self._ck(_lib.lib().mkt_bootstrap_batch(self.h, p, self._batch(k), mem))
+        return k
+
+    def not_(self, ctxt):
+        p, mem, k = _arg(ctxt, np.uint32, writable=True)
+        self._ck(_lib.lib().mkt_not_batch(self.h, p, self._batch(k), mem))
+        return k
+
+    def modswitch(self, ctxt):
+        c = np.ascontiguousarray(ctxt, dtype=np.uint32)
+        B = self._batch(c)
+        at = np.empty(c.shape[:-1] + (self.params.lwe_len - 1,), dtype=np.uint32)
+        bt = np.empty(c.shape[:-1] if c.ndim > 1 else (1,), dtype=np.uint32)
+        self._ck(_lib.lib().mkt_modswitch_batch(self.h, _np_ptr(c), _np_ptr(at), _np_ptr(bt), B, MEM_HOST))
+        return at, bt
+
+    def blindrotate_(self, atilde, acc):
+        pa, mem, ka = _arg(atilde, np.uint32)
+        pc, mem2, kc = _arg(acc, self.params.ring_dtype, writable=True)
+        if mem != mem2:
+            raise ValueError("atilde and acc must live in the same memory")
+        self._ck(_lib.lib().mkt_blindrotate_batch(self.h, pa, pc, self._batch(ka), mem))
+        return kc
+
+    def keyswitch(self, acc):
+        a = np.ascontiguousarray(acc, dtype=self.params.ring_dtype)
+        B = int(np.prod(a.shape[:-2])) if a.ndim > 2 else 1
+        out = np.empty(a.shape[:-2] + (self.params.lwe_len,), dtype=np.uint32)
+        self._ck(_lib.lib().mkt_keyswitch_batch(self.h, _np_ptr(a), _np_ptr(out), B, MEM_HOST))
+        return out
+
+    def kms_phase1(self, atilde):
+        a = np.ascontiguousarray(atilde, dtype=np.uint32)
+        B = self._batch(a)
+        p = self.params
+        rtot = 1 + (p.k - 1) * p.l_lev
+        out = np.empty(a.shape[:-1] + (rtot, 2, p.N // 2), dtype=np.complex128)
+        self._ck(_lib.lib().mkt_kms_phase1_batch(self.h, _np_ptr(a), _np_ptr(out), B, MEM_HOST))
+        return out
+
+    def transform_fwd(self, p, out=None):
+        pp, mem, kp = _arg(p, self.params.ring_dtype)
+        if out is None:
+            if mem == MEM_DEVICE:
+                import torch
+                out = torch.empty(tuple(kp.shape[:-1]) + (self.params.N // 2,), dtype=torch.complex128, device=kp.device)
+            else:
+                out = np.empty(kp.shape[:-1] + (self.params.N // 2,), dtype=np.complex128)
+        po, _, ko = _arg(out, np.complex128, writable=True)
+        self._ck(_lib.lib().mkt_transform_fwd_batch(self.h, pp, po, self._batch(kp), mem))
+        return ko
+
+    def transform_inv(self, t, out=None):
+        pt, mem, kt = _arg(t, np.complex128)
+        if out is None:
+            if mem == MEM_DEVICE:
+                import torch
+                tdt = torch.int64 if self.params.W == 64 else torch.int32
+                out = torch.empty(tuple(kt.shape[:-1]) + (self.params.N,), dtype=tdt, device=kt.device)
+            else:
+                out = np.empty(kt.shape[:-1] + (self.params.N,), dtype=self.params.ring_dtype)
+        po, _, ko = _arg(out, self.params.ring_dtype, writable=True)
+        self._ck(_lib.lib().mkt_transform_inv_batch(self.h, pt, po, self._batch(kt), mem))
+        return ko
+
+    def decompose(self, p, l, logB):
+        a = np.ascontiguousarray(p, dtype=self.params.ring_dtype)
+        B = self._batch(a)
+        out = np.empty(a.shape[:-1] + (l, self.params.N), dtype=self.params.ring_dtype)
+        self._ck(_lib.lib().mkt_decompose_batch(self.h, _np_ptr(a), _np_ptr(out), l, logB, B, MEM_HOST))
+        return out
+
+
+def setup(params: Params, keys=None, a=None, device=0, seed=0):
+    """scheme.jl:151 / :190 setup(params) -> (keys, scheme) for the single-key schemes, and
+    scheme.jl:244 / :292 / :343 setup(a, btk, params) -> scheme for the multi-key ones
+    (keys = list of PartyKeys, a = CRS).  The evaluation keys are uploaded and pre-transformed
+    on `device`."""
+    if not params.multikey:
+        ks = keys if keys is not None else PartyKeys(params, seed=seed, party=0)
+        sch = Scheme(params, device=device)
+        sch.load_party(0, ks)
+        return ks, sch
+    sch = Scheme(params, device=device)
+    sch.load_crs(a)
+    for i, kk in enumerate(keys):
+        sch.load_party(i, kk)
+    return sch
+
+
+def bootstrapping_(ctxt, scheme: Scheme):
+    """bootstrapping.jl:4 bootstrapping!(ctxt, scheme): in place on the batch"""
+    return scheme.bootstrapping_(ctxt)
+
+
+def blindrotate_(atilde, acc, scheme: Scheme):
+    """bootstrapping.jl:32/:114/:234/:369 blindrotate!(atilde, acc, scheme)"""
+    return scheme.blindrotate_(atilde, acc)
+
+
+def keyswitch(acc, scheme: Scheme):
+    """bootstrapping.jl:81/:170/:333/:564/:664 keyswitch!(res, acc, scheme) -> res"""
+    return scheme.keyswitch(acc)
+
+
+def NAND(c1, c2, scheme: Scheme, out=None):
+    """gate.jl:1-8"""
+    return scheme.gate(0, c1, c2, out)
+
+
+def AND(c1, c2, scheme: Scheme, out=None):
+    """gate.jl:10-17"""
+    return scheme.gate(1, c1, c2, out)
+
+
+def OR(c1, c2, scheme: Scheme, out=None):
+    """gate.jl:19-26"""
+    return scheme.gate(2, c1, c2, out)
+
+
+def XOR(c1, c2, scheme: Scheme, out=None):
+    """gate.jl:28-35"""
+    return scheme.gate(3, c1, c2, out)
+
+
+def XNOR(c1, c2, scheme: Scheme, out=None):
+    """gate.jl:37-44"""
+    return scheme.gate(4, c1, c2, out)
+
+
+def NOR(c1, c2, scheme: Scheme, out=None):
+    """gate.jl:46-53"""
+    return scheme.gate(5, c1, c2, out)
+
+
+def NOT_(ctxt, scheme: Scheme):
+    """gate.jl:55-58 NOT!(ctxt): negation, no bootstrap"""
+    return scheme.not_(ctxt)
