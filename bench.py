@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X gate-bootstrapping engine.
+
+Metric (BASELINE.json): NAND gate-bootstraps/s at k parties; transform ("NTT") HBM GB/s vs 8 TB/s.
+A "step" = one mkt_gate_batch call: B independent NAND gates (gate.jl:1-8 -> bootstrapping!,
+bootstrapping.jl:4-27) on ciphertexts already resident in HBM.  Default workload = BASELINE.json
+configs[1]: KMS multi-key k=2, N=1024, batch=1024 (synthetic shape, l_gsw=2 -- SURVEY.md 0.5);
+`--workload kms2party` runs the reference's own KMS2party (N=2048, params.jl:47-53).
+
+  python bench.py [--gpus N --steps K --warmup W]      (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     -- batched forward transform (fft.jl:57-63), HBM->HBM, working set >= 4 GiB,
+                  algorithmic bytes 16*N per transform (64-bit ring), timed with HIP events on the
+                  engine's stream (mkt_last_kernel_ms).
+  cpu_baseline -- the C oracle (restatement of the reference CPU path, F64REF) timed on this box's
+                  host cores on a bounded sample of the same workload; kind "port".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    "kms2_n1024": ("KMS2party_N1024_l2", "KMS k=2, N=1024, l_gsw=2 (BASELINE.json configs[1], synthetic shape)"),
+    "kms2party": ("KMS2party", "KMS2party k=2, N=2048, l_gsw=3 (src/tfhe/params.jl:47-53)"),
+    "cggi": ("CGGIparam", "CGGIparam single-key, N=1024, l=3 (src/tfhe/params.jl:1-6)"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--workload", default="kms2_n1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="gates in the CPU-baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import mktfhe_amd as mk
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    pname, desc = WORKLOADS[args.workload]
+    p = getattr(mk, pname)
+    B = args.batch
+
+    # ---- synthetic inputs: seeded keys (seed 1), encryptions of uniform bits (seed 2) ----
+    if p.multikey:
+        crs = mk.CRS(p, 1)
+        keys = [mk.party_keygen(crs, p, seed=1, party=i) for i in range(p.k)]
+        sch = mk.setup(p, keys=keys, a=crs, device=local)
+    else:
+        crs = None
+        keys = [mk.PartyKeys(p, seed=1)]
+        sch = mk.setup(p, keys=keys[0], device=local)[1]
+    rng = np.random.default_rng(2 + rank)
+    bits = rng.integers(0, 2, 2 * B).astype(bool)
+    # a few hundred distinct fresh encryptions, tiled to the batch (values do not affect timing)
+    uniq = min(2 * B, 256)
+    enc = np.empty((uniq, p.lwe_len), dtype=np.uint32)
+    for j in range(uniq):
+        enc[j] = mk.lwe_ith_encrypt(int(bits[j]), j % p.nparty, keys[j % p.nparty], p, seed=10_000 * (rank + 1) + j)
+    idx = np.arange(2 * B) % uniq
+    bits = bits[idx]
+    allc = enc[idx]
+    x = torch.from_numpy(allc[:B].view(np.int32)).to(dev)
+    y = torch.from_numpy(allc[B:].view(np.int32)).to(dev)
+    out = torch.empty_like(x)
+    sch.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mk.NAND(x, y, sch, out=out)
+    barrier()
+    sch.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mk.NAND(x, y, sch, out=out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rot_ms, rot_n = sch.kernel_ms(1)
+    ks_ms, ks_n = sch.kernel_ms(2)
+    p2_ms, p2_n = sch.kernel_ms(4)
+    sch.enable_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # correctness of what was timed: decrypt a sample, and (rank 0) compare a sub-batch with the oracle
+    res = out.cpu().numpy().view(np.uint32)
+    want = ~(bits[:B] & bits[B:])
+    nchk = min(B, 64)
+    got = mk.lwe_decrypt(res[:nchk], keys if p.multikey else keys[0], p)
+    decrypt_ok = bool(np.array_equal(got, want[:nchk]))
+
+    line = None
+    if rank == 0:
+        gates = world * B * args.steps
+        value = gates / elapsed
+        line = {
+            "metric": "NAND gate-bootstraps/sec", "value": value, "unit": "gates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "params": pname, "parties": p.k, "N": p.N, "n": p.n, "ring_bits": p.W,
+                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "op": "NAND", "arith": "F64REF", "sharding": "gates across GPUs, keys replicated"},
+            "decrypt_ok": decrypt_ok,
+            "kernels_ms_per_step": {"blindrotate": rot_ms / max(args.steps, 1), "kms_phase2": p2_ms / max(args.steps, 1),
+                                    "keyswitch": ks_ms / max(args.steps, 1)},
+        }
+        # f64 work of the blind rotation: F,I: 5*M*log2(M)+6M ; pointwise 8M (6M mul-only)
+        M = p.N // 2
+        lg = int(np.log2(M))
+        rows = (1 + (p.k - 1) * p.l_lev) if p.scheme in (mk.KMS, mk.KMS_BLOCK) else 1
+        per_iter = (2 * p.l_gsw + 2) * (5 * M * lg + 6 * M) + 4 * p.l_gsw * 8 * M + 2 * 6 * M
+        flop = per_iter * p.n * rows * B
+        if rot_ms > 0:
+            line["blindrotate"] = {"f64_gflops": flop * args.steps / (rot_ms * 1e-3) / 1e9, "peak_gflops_nofma": 39300.0,
+                                   "rotations_per_step": rows * B}
+
+    # ---- roofline leg: batched forward transform HBM->HBM ----
+    if rank == 0 and not args.no_roofline:
+        N = p.N
+        nb = (4 << 30) // (16 * N) if p.W == 64 else (4 << 30) // (12 * N)
+        polys = torch.randint(-2**31, 2**31 - 1, (nb, N * (2 if p.W == 64 else 1)), dtype=torch.int32, device=dev)
+        tout = torch.empty((nb, N // 2), dtype=torch.complex128, device=dev)
+        pv = polys.view(torch.int64) if p.W == 64 else polys
+        sch.transform_fwd(pv, out=tout)            # warm-up
+        torch.cuda.synchronize()
+        sch.enable_timing(True)
+        reps = 5
+        for _ in range(reps):
+            sch.transform_fwd(pv, out=tout)
+        ms, cnt = sch.kernel_ms(3)
+        sch.enable_timing(False)
+        bytes_per = N * (p.W // 8 + 8)
+        achieved = nb * bytes_per / (ms / cnt * 1e-3) / 1e9
+        line["roofline"] = {"bound": "hbm", "kernel": "transform_fwd_kernel", "achieved": achieved, "peak": 8000.0,
+                            "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                            "bytes_per_transform": bytes_per, "transforms_per_launch": nb, "avg_launch_ms": ms / cnt}
+        del polys, tout
+
+    # ---- CPU baseline leg (oracle, "port") ----
+    if rank == 0 and not args.no_cpu_baseline:
+        from helpers import oracle_scheme
+        so = oracle_scheme(p, crs, keys)
+        cores = min(os.cpu_count() or 1, 64)
+        sample = args.cpu_sample or max(cores, 64)
+        xs, ys = allc[:sample], allc[B:B + sample]
+        t0 = time.perf_counter()
+        ref = so.gate_batch(0, xs, ys, threads=cores)
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": sample / dt, "unit": "gates/s", "cores": cores, "kind": "port",
+                                "sample": f"{sample} NAND gates of the same workload, C oracle (F64REF restatement of the reference CPU path), {cores} threads, one gate per thread",
+                                "seconds": dt}
+        line["oracle_bitexact"] = bool(np.array_equal(ref, res[:sample]))
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sch.close()
+
+
+if __name__ == "__main__":
+    main()
