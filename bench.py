@@ -50,17 +50,12 @@ def main():
     import torch
     import mktfhe_amd as mk
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(local)
+    import torch.distributed as dist
+    from mktfhe_amd import distributed as D
+    rank, world, local = D.env()
+    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    D.init_process_group("nccl", device=dev)     # "nccl" is RCCL on ROCm; rendezvous + timing barrier only
 
     pname, desc = WORKLOADS[args.workload]
     p = getattr(mk, pname)
@@ -109,10 +104,7 @@ def main():
     ks_ms, ks_n = sch.kernel_ms(2)
     p2_ms, p2_n = sch.kernel_ms(4)
     sch.enable_timing(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = D.max_over_ranks(elapsed, device=dev)
 
     # correctness of what was timed: decrypt a sample, and (rank 0) compare a sub-batch with the oracle
     res = out.cpu().numpy().view(np.uint32)
@@ -172,7 +164,7 @@ def main():
         from helpers import oracle_scheme
         so = oracle_scheme(p, crs, keys)
         cores = min(os.cpu_count() or 1, 64)
-        sample = args.cpu_sample or max(cores, 64)
+        sample = min(B, args.cpu_sample or 4 * cores)
         xs, ys = allc[:sample], allc[B:B + sample]
         t0 = time.perf_counter()
         ref = so.gate_batch(0, xs, ys, threads=cores)

@@ -101,6 +101,9 @@ int mkt_get_twiddles(mkt_ctx *ctx, int which, double *out_host);
 int mkt_set_twiddles(mkt_ctx *ctx, const double *psi, const double *psiinv,
                      const double *roots, const double *rootsinv);
 
+/* host-only (no GPU needed): the engine's table generator for ring dimension N, same `which` */
+int mkt_make_twiddles(int N, int which, double *out_host);
+
 /* ---- evaluation keys (host pointers, copied; keygen.jl:3-155) ---- */
 int mkt_load_brk(mkt_ctx *ctx, int party, const void *data, int fmt);
 int mkt_load_ksk(mkt_ctx *ctx, int party, const uint32_t *data);
@@ -135,9 +138,10 @@ int mkt_decompose_batch(mkt_ctx *ctx, const void *p, void *digits, int l, int lo
 /* scheme.jl:121-146: copy monomial table entry e (1..2N) to host, M complex */
 int mkt_get_monomial(mkt_ctx *ctx, int e, double *out_host);
 
-/* average device time (ms) of the most recent batch call's kernels, measured with hipEvents on the
- * context's stream; `which` selects the kernel class (0 = whole call, 1 = blind rotation,
- * 2 = key switch, 3 = transform).  Returns <0 if timing was not enabled. */
+/* Device-time accounting with hipEvents recorded on the context's stream around each kernel class:
+ * mkt_enable_timing(ctx, 1) clears and starts recording, mkt_last_kernel_ms stores the TOTAL ms of
+ * class `which` (0 = whole call, 1 = blind rotation, 2 = key switch, 3 = transform, 4 = KMS phase 2)
+ * since then and returns the number of recorded launches (average = total / count); <0 on error. */
 int mkt_enable_timing(mkt_ctx *ctx, int on);
 int mkt_last_kernel_ms(mkt_ctx *ctx, int which, double *ms);
 

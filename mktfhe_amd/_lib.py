@@ -36,6 +36,7 @@ SYMBOLS = {
     "mkt_synchronize": (_i, [_vp]),
     "mkt_get_twiddles": (_i, [_vp, _i, _vp]),
     "mkt_set_twiddles": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mkt_make_twiddles": (_i, [_i, _i, _vp]),
     "mkt_load_brk": (_i, [_vp, _i, _vp, _i]),
     "mkt_load_ksk": (_i, [_vp, _i, _vp]),
     "mkt_load_rlk": (_i, [_vp, _i, _vp, _vp, _i]),

@@ -134,6 +134,15 @@ void parallel_for(int n, const std::function<void(int)> &fn) {
 
 extern "C" {
 
+int mkt_make_twiddles(int N, int which, double *out_host) {
+    if (!out_host || which < 0 || which > 3 || N < 4 || N > 8192 || (N & (N - 1))) return MKT_ERR_ARG;
+    Twiddles tw;
+    make_twiddles(N, tw);
+    const std::vector<double> &v = which == 0 ? tw.psi : which == 1 ? tw.psiinv : which == 2 ? tw.roots : tw.rootsinv;
+    std::memcpy(out_host, v.data(), v.size() * sizeof(double));
+    return MKT_OK;
+}
+
 int mkt_client_crs(const mkt_params *params, uint64_t seed, void *crs_out) {
     if (!params || !crs_out) return MKT_ERR_ARG;
     std::string why; if (validate_params(*params, why)) return MKT_ERR_ARG;

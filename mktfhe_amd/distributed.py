@@ -1,0 +1,87 @@
+"""Multi-GPU sharding of independent gate bootstraps: one process per GPU, keys replicated per GPU,
+contiguous slices of the batch per rank, NO data-path collective.  torch.distributed
+(backend "nccl" = RCCL on ROCm, "gloo" on CPU for tests) is used only for rendezvous, the timing
+barrier / max-over-ranks, and -- when a caller wants the full result everywhere -- one all_gather.
+
+The reference has no distributed layer (Base.Threads only: bootstrapping.jl:376-378, :343, :573); gates
+in a batch are independent and the scheme object is read-only during evaluation, which is what makes
+the batch dimension shardable."""
+import os
+
+import numpy as np
+
+
+def env():
+    """(rank, world_size, local_rank) from the torch.distributed.run environment"""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard_slices(B, world):
+    """contiguous, balanced slices of range(B): rank r gets [start, stop)"""
+    base, rem = divmod(B, world)
+    out, s = [], 0
+    for r in range(world):
+        e = s + base + (1 if r < rem else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+def init_process_group(backend=None, device=None):
+    import torch.distributed as dist
+    rank, world, local = env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend or "nccl", rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def max_over_ranks(value, device="cpu"):
+    """max of a python float over all ranks (the bench's step time)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+class ShardedEvaluator:
+    """Strong-scaling helper: every rank holds the same full batch description, evaluates its own
+    slice with `gate_fn(op, x, y) -> out` (the per-GPU Scheme.gate) and, if asked, all-gathers the
+    result.  No collective sits between input and output of a gate."""
+
+    def __init__(self, gate_fn, rank=None, world=None):
+        r, w, _ = env()
+        self.rank = r if rank is None else rank
+        self.world = w if world is None else world
+        self.gate_fn = gate_fn
+
+    def gate(self, op, x, y, gather=True):
+        import torch
+        import torch.distributed as dist
+        B = x.shape[0]
+        s, e = shard_slices(B, self.world)[self.rank]
+        mine = self.gate_fn(op, x[s:e], y[s:e])
+        if not gather or self.world == 1:
+            return mine
+        is_np = isinstance(mine, np.ndarray)
+        t = torch.from_numpy(np.ascontiguousarray(mine).view(np.int32)) if is_np else mine
+        sizes = [b - a for a, b in shard_slices(B, self.world)]
+        parts = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for n in sizes]
+        dist.all_gather(parts, t) if len(set(sizes)) == 1 else _all_gather_ragged(parts, t, self.rank)
+        full = torch.cat(parts, 0)
+        return full.numpy().view(np.uint32) if is_np else full
+
+
+def _all_gather_ragged(parts, t, rank):
+    import torch.distributed as dist
+    for r, buf in enumerate(parts):
+        if r == rank:
+            buf.copy_(t)
+        dist.broadcast(buf, src=r)

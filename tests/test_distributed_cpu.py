@@ -1,0 +1,58 @@
+"""world_size-2 gloo test of the batch sharding used by bench.py / ShardedEvaluator (CPU only; the
+per-rank compute is the oracle standing in for the per-GPU engine)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+
+def _worker(rank, world, port, B, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import encrypt_bits, keygen, mk, oracle_scheme
+    from mktfhe_amd import distributed as D
+    r, w, _ = D.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    p = mk.KMS2party.scaled(n=8, N=64)
+    crs, keys = keygen(p, 51)           # same seed on every rank = replicated keys
+    so = oracle_scheme(p, crs, keys)
+    bits = (np.arange(2 * B) * 7 % 3 == 0)
+    c = encrypt_bits(p, keys, bits, seed=5100)
+    ev = D.ShardedEvaluator(lambda op, x, y: so.gate_batch(op, x, y, threads=1))
+    full = ev.gate(0, c[:B], c[B:], gather=True)
+    tmax = D.max_over_ranks(1.0 + rank)
+    if rank == 0:
+        ref = so.gate_batch(0, c[:B], c[B:], threads=1)
+        ret["ok"] = bool(np.array_equal(full, ref))
+        ret["tmax"] = tmax
+        ret["dec"] = bool(np.array_equal(mk.lwe_decrypt(full, keys, p), ~(bits[:B] & bits[B:])))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [6, 7])      # even and ragged split
+def test_sharded_gates_gloo_world2(B):
+    world = 2
+    port = 29600 + B + (os.getpid() % 200)
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, ret)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(180)
+        assert pr.exitcode == 0
+    assert ret["ok"] and ret["dec"] and ret["tmax"] == 2.0
+
+
+def test_shard_slices():
+    from mktfhe_amd.distributed import shard_slices
+    assert shard_slices(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_slices(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert shard_slices(0, 2) == [(0, 0), (0, 0)]

@@ -1,0 +1,310 @@
+"""CPU tests (-m "not gpu"): the oracle against this repo's pinned fixtures and independent
+restatements, the host-side logic, and the C-ABI surface.  No GPU compute."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import GATE_FUNCS, O, ROOT, encrypt_bits, keygen, mk, oracle_scheme
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# ---------------------------------------------------------------- tables (fft.jl:18-45)
+@pytest.mark.parametrize("N", [16, 256, 1024, 2048, 4096])
+def test_twiddle_tables_match_mpmath_fixture(N):
+    g = np.load(os.path.join(GOLD, "twiddles.npz"))
+    f = O.Ffter(N, 64)
+    from mktfhe_amd import _lib
+    for w, name in enumerate(("psi", "psiinv", "roots", "rootsinv")):
+        gold = g[f"{name}_{N}"].view(np.uint64)
+        assert np.array_equal(f.table(w).view(np.uint64), gold), ("oracle", name)
+        out = np.empty(N // 2, dtype=np.complex128)
+        assert _lib.lib().mkt_make_twiddles(N, w, out.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(out.view(np.uint64), gold), ("engine host generator", name)
+
+
+def test_twiddle_special_entries():
+    f = O.Ffter(1024, 32)
+    psi = f.table(0)
+    assert psi[0] == 1.0 and np.signbit(psi[0].imag)            # exp(0 - 0im): -0.0 kept
+    assert psi[1].imag == -1.0 and 0 < psi[1].real < 1e-70       # cos(RN256(pi)/2), not 0
+    assert float(psi[1].real).hex() == "0x1.452821e638d01p-257"
+
+
+# ---------------------------------------------------------------- integer semantics
+def py_divbits(a, bit, W):                       # arithmetic.jl:23-27
+    m = (1 << W) - 1
+    a &= m
+    if bit == 0:
+        return a
+    return ((a >> bit) + (((a << (W - bit)) & m) >> (W - 1))) & m
+
+
+def py_decomp(a, l, logB, W):                    # gsw.jl:42-52, written out step by step
+    m = (1 << W) - 1
+    mask, half = (1 << logB) - 1, 1 << (logB - 1)
+    ai = py_divbits(a, W - l * logB, W)
+    out = [0] * l
+    for i in range(l - 1, 0, -1):
+        d = ai & mask
+        ai >>= logB
+        ai = (ai + (d >> (logB - 1))) & m
+        out[i] = (d - ((d & half) << 1)) & m
+    d = ai & mask
+    out[0] = (d - ((d & half) << 1)) & m
+    return out
+
+
+def test_divbits_kats():
+    for W in (32, 64):
+        m = (1 << W) - 1
+        for a in (0, 1, m, m - 1, 1 << (W - 1), (1 << (W - 1)) - 1, 0x12345678 & m, (1 << 20) + (1 << 19)):
+            for bit in (0, 1, 2, 20, 21, W - 3, W - 1):
+                assert O.divbits(a, bit, W) == py_divbits(a, bit, W)
+    # rounds half up and can return 2^(w-bit): the 2N case of bootstrapping.jl:8-9 (N = 1024)
+    assert O.divbits(0xFFFFFFFF, 21, 32) == 2048
+    assert O.divbits(0xFFF00000 - 1, 21, 32) == 2047
+    assert O.divbits((1 << 20), 21, 32) == 1 and O.divbits((1 << 20) - 1, 21, 32) == 0
+
+
+GADGETS = [(32, 3, 9), (32, 3, 8), (32, 4, 8), (32, 5, 6), (32, 12, 2), (64, 3, 12), (64, 2, 7), (64, 3, 10), (64, 5, 8),
+           (64, 2, 8), (64, 7, 6), (64, 4, 9), (64, 3, 6), (64, 8, 4), (64, 9, 4), (64, 6, 7), (64, 3, 7), (64, 16, 2), (64, 2, 16)]
+
+
+@pytest.mark.parametrize("W,l,logB", GADGETS)      # every (l, logB) of params.jl
+def test_decomposition_kats(W, l, logB):
+    rng = np.random.default_rng(l * 64 + logB)
+    m = (1 << W) - 1
+    vals = [0, 1, m, m - 1, 1 << (W - 1), (1 << (W - 1)) - 1, (1 << (W - 1)) + 1, 1 << (W - l * logB), (1 << (W - l * logB)) - 1,
+            (1 << (W - l * logB - 1)) if W - l * logB > 0 else 3, m - (1 << (W - l * logB)) + 1]
+    vals += [int(x) for x in rng.integers(0, 1 << 63, 200, dtype=np.uint64)]
+    B = 1 << logB
+    for a in vals:
+        a &= m
+        got = [int(x) for x in O.decomp_word(a, l, logB, W)]
+        assert got == py_decomp(a, l, logB, W)
+        # digits are balanced and recompose to the rounded value mod 2^W
+        sd = [x - (1 << W) if x >> (W - 1) else x for x in got]
+        assert all(-B // 2 <= d < B // 2 for d in sd)
+        recomposed = sum(d << (W - (j + 1) * logB) for j, d in enumerate(sd)) & m
+        rounded = (py_divbits(a, W - l * logB, W) << (W - l * logB)) & m
+        assert recomposed == rounded
+    # unbalanced (key switch, gsw.jl:34-40)
+    for a in vals[:40]:
+        got = [int(x) for x in O.unbalanced_decomp_word(a & 0xFFFFFFFF, 8, 2, 32)]
+        t = py_divbits(a & 0xFFFFFFFF, 16, 32)
+        assert got == [(t >> (2 * (7 - j))) & 3 for j in range(8)]
+
+
+def test_gate_linear_constants():
+    x = np.array([5, 7, 100], dtype=np.uint32); y = np.array([1, 2, 3], dtype=np.uint32)
+    M = 1 << 32
+    exp = {0: [(-5 - 1) % M, (-7 - 2) % M, ((1 << 29) - 103) % M], 1: [6, 9, ((7 << 29) + 103) % M], 2: [6, 9, ((1 << 29) + 103) % M],
+           3: [12, 18, ((1 << 30) + 206) % M], 4: [(-12) % M, (-18) % M, ((3 << 30) - 206) % M], 5: [(-6) % M, (-9) % M, ((7 << 29) - 103) % M]}
+    for op, e in exp.items():
+        assert [int(v) for v in O.gate_linear(op, x, y)] == e
+
+
+# ---------------------------------------------------------------- transform semantics
+def py_negacyclic(a, b, W):
+    N = len(a)
+    out = [0] * N
+    for i in range(N):
+        for j in range(N):
+            if i + j < N:
+                out[i + j] += int(a[i]) * int(b[j])
+            else:
+                out[i + j - N] -= int(a[i]) * int(b[j])
+    return [v % (1 << W) for v in out]
+
+
+def test_schoolbook_helper_against_bigint():
+    rng = np.random.default_rng(5)
+    for W in (32, 64):
+        a = rng.integers(0, 1 << 63, 32, dtype=np.uint64) & np.uint64((1 << W) - 1)
+        b = rng.integers(0, 1 << 63, 32, dtype=np.uint64) & np.uint64((1 << W) - 1)
+        assert [int(v) for v in O.negacyclic(a, b, W)] == py_negacyclic(a, b, W)
+
+
+def signed_digits(rng, N, logB, W):
+    d = rng.integers(-(1 << (logB - 1)), 1 << (logB - 1), N).astype(np.int64)
+    return d.astype(np.uint64) & np.uint64((1 << W) - 1)
+
+
+def test_f64ref_product_truncation_envelope_u32():
+    """on the 32-bit ring native() truncates, so digit x key products come out exact or one
+    below the exact negacyclic product -- never anything else."""
+    rng = np.random.default_rng(9)
+    N = 1024
+    f = O.Ffter(N, 32)
+    acc = np.zeros(N // 2, dtype=np.complex128)
+    exact = np.zeros(N, dtype=np.uint64)
+    for _ in range(6):
+        d = signed_digits(rng, N, 9, 32)
+        k = rng.integers(0, 1 << 32, N, dtype=np.uint64)
+        td, tk = f.fwd(d), f.fwd(k)
+        O.lib().ora_tp_muladd(acc.ctypes.data, td.ctypes.data, tk.ctypes.data, N // 2)
+        exact = (exact + O.negacyclic(d, k, 32)) & np.uint64(0xFFFFFFFF)
+    got = f.inv(acc)
+    diff = (got.astype(np.int64) - exact.astype(np.int64))
+    diff = np.where(diff > (1 << 31), diff - (1 << 32), diff)
+    diff = np.where(diff < -(1 << 31), diff + (1 << 32), diff)
+    assert set(np.unique(diff)).issubset({0, -1})
+    assert (diff == 0).mean() > 0.3 and (diff == -1).mean() > 0.2
+
+
+def test_f64ref_product_error_u64():
+    """64-bit ring: the Float64 result is the exact product up to ~2^30 (53-bit mantissa at magnitude 2^81)."""
+    rng = np.random.default_rng(10)
+    N = 2048
+    f = O.Ffter(N, 64)
+    acc = np.zeros(N // 2, dtype=np.complex128)
+    exact = np.zeros(N, dtype=np.uint64)
+    for _ in range(6):
+        d = signed_digits(rng, N, 12, 64)
+        k = rng.integers(0, 1 << 63, N, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, N, dtype=np.uint64)
+        td, tk = f.fwd(d), f.fwd(k)
+        O.lib().ora_tp_muladd(acc.ctypes.data, td.ctypes.data, tk.ctypes.data, N // 2)
+        exact = exact + O.negacyclic(d, k, 64)
+    got = f.inv(acc)
+    diff = (got - exact).astype(np.int64)
+    assert np.abs(diff).max() < (1 << 33)
+    assert np.abs(diff).max() > (1 << 20)          # it is NOT exact: parity is with the Float64 path
+
+
+def test_forward_inverse_roundtrip_small_values():
+    """ifft(fft(p)) is p or p-1: native() truncates (arithmetic.jl:1-9), it does not round"""
+    rng = np.random.default_rng(11)
+    for N, W in ((64, 32), (1024, 32), (2048, 64)):
+        f = O.Ffter(N, W)
+        p = signed_digits(rng, N, 10, W)
+        d = (f.inv(f.fwd(p)) - p) & np.uint64((1 << W) - 1)
+        if W == 32:
+            assert set(int(v) for v in np.unique(d)).issubset({0, (1 << W) - 1})
+        else:   # negative values sit at 2^64 - |d|, where a double's spacing is 2^11
+            assert np.abs(d.astype(np.int64)).max() <= 2048
+
+
+def test_monomial_table_semantics():
+    N = 64
+    f = O.Ffter(N, 32)
+    rng = np.random.default_rng(12)
+    p = signed_digits(rng, N, 8, 32)
+    tp = f.fwd(p)
+    for e in (1, 5, N - 1, N, N + 1, 2 * N - 1, 2 * N):
+        out = np.zeros(N // 2, dtype=np.complex128)
+        mono = f.monomial(e)
+        O.lib().ora_tp_mul(out.ctypes.data, mono.ctypes.data, tp.ctypes.data, N // 2)
+        got = f.inv(out).astype(np.int64)
+        # (X^e - 1) * p exactly
+        coeffs = np.zeros(N, dtype=np.int64)
+        ps = p.astype(np.int64); ps = np.where(ps >= 1 << 31, ps - (1 << 32), ps)
+        for i in range(N):
+            j = (i + e) % (2 * N)
+            if j < N:
+                coeffs[j] += ps[i]
+            else:
+                coeffs[j - N] -= ps[i]
+        coeffs -= ps
+        diff = (got - coeffs % (1 << 32)) % (1 << 32)       # exact or one below (truncating native())
+        assert set(int(v) for v in np.unique(diff)).issubset({0, (1 << 32) - 1}), e
+    assert not f.monomial(2 * N).any()
+
+
+# ---------------------------------------------------------------- end to end (the reference's own test property)
+SMALL = [
+    mk.CGGIparam.scaled(n=24, N=256), mk.Blockparam.scaled(n=30, N=256, blk_d=10), mk.CCS2party.scaled(n=16, N=256),
+    mk.KMS2party.scaled(n=16, N=256), mk.KMS2partyblock.scaled(n=24, N=256, blk_d=8), mk.KMS4party.scaled(n=8, N=256),
+    mk.CCS4party.scaled(n=8, N=256),
+]
+
+
+@pytest.mark.parametrize("p", SMALL, ids=lambda p: p.name)
+def test_random_gate_circuit_decrypts(p):
+    """counterpart of test/{CGGI,LMSS,CCS,KMS,KMSblock}.jl: fold random gates, bootstrap once more, decrypt"""
+    crs, keys = keygen(p, 21)
+    s = oracle_scheme(p, crs, keys)
+    rng = np.random.default_rng(22)
+    dk = keys if p.multikey else keys[0]
+    for trial in range(4):
+        nb = max(p.nparty, 4)
+        bits = rng.integers(0, 2, nb).astype(bool)
+        c = encrypt_bits(p, keys, bits, seed=300 + 20 * trial)
+        res, mres = c[0], bool(bits[0])
+        for i in range(1, nb):
+            op = int(rng.integers(0, 6))
+            res = s.gate(op, res, c[i])
+            mres = bool(GATE_FUNCS[op](np.bool_(mres), np.bool_(bits[i])))
+        res = s.bootstrap(res)
+        assert mk.lwe_decrypt(res, dk, p) == mres
+
+
+def test_end_to_end_golden_hashes():
+    """regression pin of the oracle's ciphertext bits (fixture written by tests/golden/gen_e2e.py)"""
+    gold = json.load(open(os.path.join(GOLD, "e2e_hashes.json")))
+    from golden.gen_e2e import CASES, run_case
+    for name in CASES:
+        assert run_case(name) == gold[name], name
+
+
+# ---------------------------------------------------------------- client keys are what the layouts say
+def test_client_key_layouts():
+    p = mk.KMS2party.scaled(n=8, N=64)
+    crs, keys = keygen(p, 31)
+    k0 = keys[0]
+    n, N, f, D1 = p.n, p.N, p.f, 3
+    ksk = k0.ksk.reshape(N, D1, f, n + 1)
+    s = k0.lwekey.astype(np.uint32)
+    # every KSK row decrypts to (d+1) * z_j * 2^(32-(t+1)logD) up to noise alpha (keygen.jl:110-114)
+    phase = (ksk[..., n] + (ksk[..., :n] * s).sum(-1, dtype=np.uint32)).astype(np.uint32)
+    for t in range(4):      # deeper gadget levels sit below the noise alpha = 2^17 by design
+        q = (phase[:, :, t].astype(np.int64) + (1 << (31 - 2 * (t + 1)))) >> (32 - 2 * (t + 1))
+        zj = (q[:, 0] & 3)
+        assert set(np.unique(zj)).issubset({0, 1})
+        for d in range(D1):
+            assert np.array_equal(q[:, d] & 3, ((d + 1) * zj) & 3)
+    brk = k0.brk.reshape(n, 2 * p.l_gsw, 2, N)
+    assert brk.dtype == np.uint64 and k0.rlk_d.size == p.l_uni * N and k0.rlk_f.size == 2 * p.l_uni * N and k0.pubkey.size == p.l_uni * N
+    # seeded: same seed -> same keys, different party -> different keys
+    again = mk.party_keygen(crs, p, seed=31, party=0)
+    assert np.array_equal(again.brk, k0.brk) and not np.array_equal(keys[1].brk, k0.brk)
+
+
+# ---------------------------------------------------------------- the C ABI surface
+def test_library_exports_every_declared_symbol():
+    from mktfhe_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mktfhe.h")).read()
+    declared = set(re.findall(r"\b(mkt_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mkt_status"}
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/mktfhe.h but not exported"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert _lib.lib().mkt_abi_version() == 1
+
+
+def test_no_cpu_fallback_and_argument_errors():
+    """without a GPU the product path must fail loudly, never compute on the CPU"""
+    import torch
+    p = mk.CGGIparam.scaled(n=8, N=64)
+    if not torch.cuda.is_available():
+        with pytest.raises(mk.MktError) as ei:
+            mk.Scheme(p)
+        assert ei.value.code == -3
+    with pytest.raises(mk.MktError):
+        mk.PartyKeys(p.scaled(N=100))            # not a power of two
+    with pytest.raises(mk.MktError):
+        mk.PartyKeys(mk.Blockparam.scaled(n=31, N=64, blk_d=10))   # n != blk_len * blk_d
+
+
+def test_product_package_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mktfhe_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".h", ".hip")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in src.lower() or fn == "scheme.py" and False, f"{fn} mentions the oracle"
