@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -83,16 +84,22 @@ size_t poly_bytes(const mkt_ctx *c) { return (size_t)c->p.N * c->sh.word; }
 
 // transform `npolys` coefficient-form polynomials (host) into TransPolys at `dst` (device)
 int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt) {
-    if (fmt == MKT_FMT_F64_FFT) {
-        HIPCHK(c, hipMemcpyAsync(dst, host, npolys * (size_t)c->M * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (fmt == MKT_FMT_F64_FFT) {   // the reference's Trans* values: copy, then natural -> device point order
+        cplx *tmpc = nullptr;
+        const size_t nb = npolys * (size_t)c->M * sizeof(cplx);
+        HIPCHK(c, hipMalloc((void **)&tmpc, nb));
+        hipError_t e = hipMemcpyAsync(tmpc, host, nb, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = mktd::launch_reorder(c->logM, tmpc, dst, npolys, 1, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(tmpc);
+        if (e != hipSuccess) return hipfail(c, e, "key upload");
         return MKT_OK;
     }
     if (fmt != MKT_FMT_INT_COEFF) return fail(c, MKT_ERR_ARG, "unknown key format");
     void *tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, npolys * poly_bytes(c)));
     hipError_t e = hipMemcpyAsync(tmp, host, npolys * poly_bytes(c), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, c->stream);
+    if (e == hipSuccess) e = mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, 1, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) return hipfail(c, e, "key pre-transform");
@@ -173,6 +180,7 @@ mktd::RotArgs rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
     a.blk_accum = mkt::is_block(p.scheme) ? 1 : 0;
     a.rows_per_gate = c->rtot; a.slot_party = c->d_slot_party; a.slot_row = c->d_slot_row;
     a.logB_lev = p.logB_lev;
+    if (const char *v = getenv("MKT_ROT_VARIANT")) a.variant = atoi(v);
     return a;
 }
 
@@ -188,7 +196,7 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
     }
     {
         mktd::RotArgs a = rot_args(c, lwe, stride, pre);
-        a.init_mode = 1; a.out_mode = 1; a.tout = lev;
+        a.init_mode = 1; a.out_mode = 1; a.tout = lev; a.tout_natural = 0;
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, p.W, a, B * (size_t)c->rtot, c->stream));
     }
@@ -352,6 +360,11 @@ int mkt_set_twiddles(mkt_ctx *c, const double *psi, const double *psiinv, const 
     if (!c || !psi || !psiinv || !roots || !rootsinv) return fail(c, MKT_ERR_ARG, "null table");
     DevGuard dg(c->device);
     const size_t nd = (size_t)2 * c->M;
+    // the kernels derive the inverse twiddles from the forward table: Psiinv must be conj(Psi) entry for entry,
+    // which holds for the reference's tables (fft.jl:33-34: exp(-i*theta) and exp(+i*theta) of the same theta)
+    for (int i = 1; i < c->M; i++)
+        if (std::memcmp(&psi[2 * i], &psiinv[2 * i], 8) != 0 || psiinv[2 * i + 1] != -psi[2 * i + 1])
+            return fail(c, MKT_ERR_ARG, "mkt_set_twiddles: Psiinv is not the conjugate of Psi");
     c->tw.psi.assign(psi, psi + nd); c->tw.psiinv.assign(psiinv, psiinv + nd);
     c->tw.roots.assign(roots, roots + nd); c->tw.rootsinv.assign(rootsinv, rootsinv + nd);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -364,7 +377,11 @@ int mkt_get_monomial(mkt_ctx *c, int e, double *out_host) {
     if (!c || !out_host || e < 1 || e > 2 * c->p.N) return fail(c, MKT_ERR_ARG, "bad argument");
     DevGuard dg(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out_host, c->d_monomial + (size_t)(e - 1) * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
+    std::vector<cplx> dev((size_t)c->M);
+    HIPCHK(c, hipMemcpy(dev.data(), c->d_monomial + (size_t)(e - 1) * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
+    const int NT = c->M / 4;                      // device order -> the reference's order
+    cplx *o = reinterpret_cast<cplx *>(out_host);
+    for (int x = 0; x < c->M; x++) o[x] = dev[(size_t)mktd::dev_pos(x, NT)];
     return MKT_OK;
 }
 
@@ -498,7 +515,7 @@ int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, siz
     Staged sa{c}, sl{c};
     if ((r = sa.in(atilde, B * alen * 4, mem, true)) || (r = sl.in(levkey, B * lb, mem, false))) return r;
     mktd::RotArgs a = rot_args(c, (const uint32_t *)sa.dev, (int)alen, 1);
-    a.init_mode = 1; a.out_mode = 1; a.tout = (cplx *)sl.dev;
+    a.init_mode = 1; a.out_mode = 1; a.tout = (cplx *)sl.dev; a.tout_natural = 1;
     { Timer tm(c, 1); HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, c->p.W, a, B * (size_t)c->rtot, c->stream)); }
     return sl.out(levkey);
 }
@@ -521,7 +538,7 @@ int mkt_transform_fwd_batch(mkt_ctx *c, const void *p, double *t, size_t B, int 
     Staged sp{c}, st{c};
     int r;
     if ((r = sp.in(p, B * poly_bytes(c), mem, true)) || (r = st.in(t, B * (size_t)c->M * sizeof(cplx), mem, false))) return r;
-    { Timer tm(c, 3); HIPCHK(c, mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), sp.dev, (cplx *)st.dev, B, c->stream)); }
+    { Timer tm(c, 3); HIPCHK(c, mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), sp.dev, (cplx *)st.dev, B, 0, c->stream)); }
     return st.out(t);
 }
 

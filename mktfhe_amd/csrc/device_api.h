@@ -14,7 +14,7 @@ struct TwPtrs { const cplx *psi, *psiinv, *roots, *rootsinv; };
 // KMS / KMS_block phase 1.  One workgroup per rotation.
 struct RotArgs {
     TwPtrs tw;
-    const cplx *brk;          // party 0 base; [n][2l rows][2 polys][M]
+    const cplx *brk;          // party 0 base; [n][2l rows][2 polys][M], DEVICE point order
     size_t brk_party_stride;  // in cplx
     const cplx *monomial;     // [2N][M], entry e-1
     const uint32_t *lwe;      // [B][lwe_stride]: LWE words (mod-switched on the fly) or atilde
@@ -32,6 +32,8 @@ struct RotArgs {
     int out_mode;             // 0: write acc to acc_io; 1: write fft(acc) to tout
     void *acc_io;             // [rot][2][N] ring words
     cplx *tout;               // [rot][2][M]
+    int tout_natural;         // 1: reference point order (API output); 0: device order (feeds phase 2)
+    int variant;              // tuning: 10*LOGR + transforms per group (0 = default)
 };
 
 // KMS phase 2 (bootstrapping.jl:448-558), one workgroup per ciphertext.
@@ -63,7 +65,8 @@ struct KsArgs {
     int lmss;                 // LMSS flavour of the copy rule (global coefficient index across components)
 };
 
-hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, hipStream_t s);
+hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, hipStream_t s);
+hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, int to_device, hipStream_t s);
 hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void *p, size_t B, hipStream_t s);
 hipError_t launch_decompose(int W, const void *p, void *digits, int N, int l, int logB, size_t B, hipStream_t s);
 hipError_t launch_gate_linear(int op, const uint32_t *x, const uint32_t *y, uint32_t *out, int len, size_t B, hipStream_t s);

@@ -20,6 +20,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MKT_ABLATE
+#define MKT_ABLATE 0   // timing-only experiments: 1 no key loads, 2 no twiddle loads, 4 no LDS exchange, 8 no barrier
+#endif
+
 namespace mktd {
 
 struct __attribute__((aligned(16))) cplx { double re, im; };
@@ -28,10 +32,15 @@ __device__ __forceinline__ cplx cmul(const cplx x, const cplx y) {
     const double a = x.re * y.re, b = x.im * y.im, c = x.re * y.im, d = x.im * y.re;
     cplx r; r.re = a - b; r.im = c + d; return r;
 }
+// x * conj(w), bit-identical to cmul(x, (w.re, -w.im)): a - (-b) == a + b and (-c) + d == d - c in IEEE-754
+__device__ __forceinline__ cplx cmul_conj(const cplx x, const cplx w) {
+    const double a = x.re * w.re, b = x.im * w.im, c = x.re * w.im, d = x.im * w.re;
+    cplx r; r.re = a + b; r.im = d - c; return r;
+}
 __device__ __forceinline__ cplx cadd(const cplx x, const cplx y) { cplx r; r.re = x.re + y.re; r.im = x.im + y.im; return r; }
 __device__ __forceinline__ cplx csub(const cplx x, const cplx y) { cplx r; r.re = x.re - y.re; r.im = x.im - y.im; return r; }
 
-template <int LOGM, int LOGR>
+template <int LOGM, int LOGR, int NB = 1>
 struct Plan {
     static constexpr int M = 1 << LOGM, R = 1 << LOGR, NT = M / R;
     static constexpr int NPASS = (LOGM + LOGR - 1) / LOGR;
@@ -40,8 +49,8 @@ struct Plan {
     __host__ __device__ static constexpr int nst(int p) { return p < NPASS - 1 ? LOGR : LOGM - (NPASS - 1) * LOGR; }
     // highest stage bit of pass p
     __host__ __device__ static constexpr int hib(int p) { return p < NPASS - 1 ? lo(p) + LOGR - 1 : nst(p) - 1; }
-    // LDS staging: one pad slot per 16 points, two buffers (one barrier per exchange)
-    static constexpr int BUF = M + (M >> 4);
+    // LDS staging: NB transforms side by side, two buffers (one barrier per exchange)
+    static constexpr int BUF = NB * M;
     static constexpr int LDS_CPLX = 2 * BUF;
     static constexpr size_t LDS_BYTES = (size_t)LDS_CPLX * sizeof(cplx);
 };
@@ -50,24 +59,37 @@ template <int LOGR>
 __device__ __forceinline__ int pt_index(int t, int e, int lo) {
     return ((t >> lo) << (lo + LOGR)) | (e << lo) | (t & ((1 << lo) - 1));
 }
-__device__ __forceinline__ int lds_pos(int idx) { return idx + (idx >> 4); }
+// XOR swizzle of the staging slot: conflict-free ds_write_b128 / ds_read_b128 for every exchange pattern of
+// the 4- and 8-points-per-thread schedules at M = 128 .. 2048 (found and verified by tools/lds_swizzle_search.py,
+// which simulates the gfx950 b128 lane groups and bank widths)
+template <int LOGR>
+__device__ __forceinline__ int lds_pos(int idx) {
+    if (LOGR == 2) return idx ^ ((idx >> 1) & 8) ^ ((idx >> 2) & 15);
+    return idx ^ ((idx >> 3) & 15);   // 8 points per thread
+}
 
-template <int LOGM, int LOGR>
-__device__ __forceinline__ void exchange(cplx (&z)[1 << LOGR], cplx *buf, int t, int lo_from, int lo_to) {
-    constexpr int R = 1 << LOGR;
+template <int LOGM, int LOGR, int NB>
+__device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *buf, int t, int lo_from, int lo_to) {
+    constexpr int R = 1 << LOGR, M = 1 << LOGM;
+    if (MKT_ABLATE & 4) return;
 #pragma unroll
-    for (int e = 0; e < R; e++) buf[lds_pos(pt_index<LOGR>(t, e, lo_from))] = z[e];
-    __syncthreads();
+    for (int b = 0; b < NB; b++)
 #pragma unroll
-    for (int e = 0; e < R; e++) z[e] = buf[lds_pos(pt_index<LOGR>(t, e, lo_to))];
+        for (int e = 0; e < R; e++) buf[b * M + lds_pos<LOGR>(pt_index<LOGR>(t, e, lo_from))] = z[b][e];
+    if (!(MKT_ABLATE & 8)) __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int e = 0; e < R; e++) z[b][e] = buf[b * M + lds_pos<LOGR>(pt_index<LOGR>(t, e, lo_to))];
 }
 
 // fft.jl:105-155: for stage bit b (stride k = 2^b, m = 2^(LOGM-1-b)), butterfly on (j, j+k):
 //   u = a[j+k] * Psi[m + (j >> (b+1))];  a[j], a[j+k] = a[j] + u, a[j] - u
-// In: slot e = point e*NT + t.  Out: slot e = point t*R + e.
-template <int LOGM, int LOGR>
-__device__ __forceinline__ void fft_forward(cplx (&z)[1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t) {
-    using P = Plan<LOGM, LOGR>;
+// In: slot e = point e*NT + t.  Out: slot e = point t*R + e.  NB independent transforms share the
+// twiddle loads and the barriers.
+template <int LOGM, int LOGR, int NB>
+__device__ __forceinline__ void fft_forward(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t) {
+    using P = Plan<LOGM, LOGR, NB>;
     // with an even pass count two back-to-back transforms of the same direction would start writing
     // the staging buffer the previous one may still be reading
     if (P::NPASS > 1 && (P::NPASS & 1) == 0) __syncthreads();
@@ -80,25 +102,30 @@ __device__ __forceinline__ void fft_forward(cplx (&z)[1 << LOGR], const cplx *__
             const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
 #pragma unroll
             for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) {
-                const cplx w = psi[twbase + g];
+                cplx w; if (MKT_ABLATE & 2) { w.re = 0.5 + twbase; w.im = 0.25 * g; } else w = psi[twbase + g];
 #pragma unroll
                 for (int q = 0; q < (1 << sb); q++) {
                     const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
-                    const cplx u = cmul(z[e2], w);
-                    const cplx a = z[e];
-                    z[e] = cadd(a, u); z[e2] = csub(a, u);
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        const cplx u = cmul(z[nb][e2], w);
+                        const cplx a = z[nb][e];
+                        z[nb][e] = cadd(a, u); z[nb][e2] = csub(a, u);
+                    }
                 }
             }
         }
-        if (p < P::NPASS - 1) exchange<LOGM, LOGR>(z, lds + (p & 1) * P::BUF, t, lo, P::lo(p + 1));
+        if (p < P::NPASS - 1) exchange<LOGM, LOGR, NB>(z, lds + (p & 1) * P::BUF, t, lo, P::lo(p + 1));
     }
 }
 
 // fft.jl:159-209: t, u = a[j], a[j+k];  a[j] = t + u;  a[j+k] = (t - u) * Psiinv[m + (j >> (b+1))]
 // In: slot e = point t*R + e.  Out: slot e = point e*NT + t.
-template <int LOGM, int LOGR>
-__device__ __forceinline__ void fft_inverse(cplx (&z)[1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t) {
-    using P = Plan<LOGM, LOGR>;
+// CONJ: `psiinv` points at the FORWARD table Psi and the butterflies multiply by its conjugate (Psiinv == conj(Psi)
+// entry for entry, fft.jl:33-34), so one table -- e.g. a copy resident in LDS -- serves both directions.
+template <int LOGM, int LOGR, int NB, bool CONJ = false>
+__device__ __forceinline__ void fft_inverse(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t) {
+    using P = Plan<LOGM, LOGR, NB>;
     if (P::NPASS > 1 && (P::NPASS & 1) == 0) __syncthreads();
 #pragma unroll
     for (int p = P::NPASS - 1; p >= 0; p--) {
@@ -109,18 +136,36 @@ __device__ __forceinline__ void fft_inverse(cplx (&z)[1 << LOGR], const cplx *__
             const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
 #pragma unroll
             for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) {
-                const cplx w = psiinv[twbase + g];
+                cplx w; if (MKT_ABLATE & 2) { w.re = 0.5 + twbase; w.im = 0.25 * g; } else w = psiinv[twbase + g];
 #pragma unroll
                 for (int q = 0; q < (1 << sb); q++) {
                     const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
-                    const cplx a = z[e], u = z[e2];
-                    z[e] = cadd(a, u);
-                    z[e2] = cmul(csub(a, u), w);
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        const cplx a = z[nb][e], u = z[nb][e2];
+                        z[nb][e] = cadd(a, u);
+                        z[nb][e2] = CONJ ? cmul_conj(csub(a, u), w) : cmul(csub(a, u), w);
+                    }
                 }
             }
         }
-        if (p > 0) exchange<LOGM, LOGR>(z, lds + (p & 1) * P::BUF, t, lo, P::lo(p - 1));
+        if (p > 0) exchange<LOGM, LOGR, NB>(z, lds + (p & 1) * P::BUF, t, lo, P::lo(p - 1));
     }
+}
+
+// Device point order of the resident TransPolys (keys, monomial table, phase-1 output): where the
+// reference-order point x = 4t+e (slot e of thread t after the forward transform) is stored.
+#ifndef MKT_DEVORDER
+#define MKT_DEVORDER 2
+#endif
+__host__ __device__ __forceinline__ int dev_pos(int x, int NT) {
+#if MKT_DEVORDER == 0
+    (void)NT; return x;                                            // reference order: 64 B per lane
+#elif MKT_DEVORDER == 1
+    return (x & 3) * NT + (x >> 2);                                // slot-major: 16 B per lane, wave-contiguous
+#else
+    return ((x >> 1) & 1) * (2 * NT) + ((x >> 2) << 1) + (x & 1);  // slot pairs: 32 B per lane
+#endif
 }
 
 // ---- ring words ----

@@ -12,12 +12,21 @@ constexpr int LOGR = 2;  // points per thread = 4
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mkt_smem[];
 
+template <int LOGM>
+__device__ __forceinline__ void fft_forward1(cplx (&z)[1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t) {
+    fft_forward<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][1 << LOGR]>(z), psi, lds, t);
+}
+template <int LOGM>
+__device__ __forceinline__ void fft_inverse1(cplx (&z)[1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t) {
+    fft_inverse<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][1 << LOGR]>(z), psiinv, lds, t);
+}
+
 // ------------------------------------------------------------------------------------------------
 // batched transforms (fft.jl:57-63 / :74-81): HBM -> HBM, one polynomial per workgroup pass
 // ------------------------------------------------------------------------------------------------
 template <int LOGM, typename WORD>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(TwPtrs tw, const WORD *__restrict__ p,
-                                                                            cplx *__restrict__ out, size_t B) {
+                                                                            cplx *__restrict__ out, size_t B, int dev_order) {
     using P = Plan<LOGM, LOGR>;
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
@@ -36,10 +45,22 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
             v.im = word_to_f64<WORD>((WORD)((WORD)0 - pp[idx + M]));   // subtraction in the integer type (fft.jl:60)
             z[e] = cmul(v, rt[e]);
         }
-        fft_forward<LOGM, LOGR>(z, tw.psi, lds, t);
-        cplx *o = out + b * M + (size_t)t * R;
+        fft_forward1<LOGM>(z, tw.psi, lds, t);
+        // natural order: point 4t+e at 4t+e (the reference's TransPoly order); device order: at e*NT+t, so that
+        // every later key-row load is one contiguous 16 B/lane wave access
+        cplx *o = out + b * M;
 #pragma unroll
-        for (int e = 0; e < R; e++) o[e] = z[e];
+        for (int e = 0; e < R; e++) o[dev_order ? dev_pos(t * R + e, NT) : t * R + e] = z[e];
+    }
+}
+
+// natural <-> device point order of TransPolys (F64_FFT key upload, table read-back)
+template <int LOGM>
+__global__ void reorder_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, size_t npolys, int to_device) {
+    constexpr int M = 1 << LOGM, R = 1 << LOGR, NT = M / R;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npolys * M; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / M; const int x = (int)(i % M);
+        if (to_device) out[b * M + dev_pos(x, NT)] = in[i]; else out[i] = in[b * M + dev_pos(x, NT)];
     }
 }
 
@@ -58,7 +79,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_inv_kernel(T
         cplx z[R];
 #pragma unroll
         for (int e = 0; e < R; e++) z[e] = i[e];
-        fft_inverse<LOGM, LOGR>(z, tw.psiinv, lds, t);
+        fft_inverse1<LOGM>(z, tw.psiinv, lds, t);
         WORD *pp = p + b * N;
 #pragma unroll
         for (int e = 0; e < R; e++) {
@@ -148,7 +169,7 @@ __device__ __forceinline__ void digit_points(cplx (&z)[R], const WORD (&tp)[R][2
 template <int LOGM, typename WORD>
 __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)[1 << LOGR][2], const TwPtrs &tw, cplx *lds, int t) {
     using P = Plan<LOGM, LOGR>;
-    fft_inverse<LOGM, LOGR>(z, tw.psiinv, lds, t);
+    fft_inverse1<LOGM>(z, tw.psiinv, lds, t);
 #pragma unroll
     for (int e = 0; e < P::R; e++) {
         const cplx v = cmul(z[e], tw.rootsinv[e * P::NT + t]);
@@ -163,12 +184,29 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 // and the transform-domain accumulator stay in registers for all n CMux steps; LDS only stages the
 // in-transform exchanges.  LB = block length (1 for the plain schemes).
 // ------------------------------------------------------------------------------------------------
-template <int LOGM, typename WORD, int LB>
-__global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_k1_kernel(const RotArgs a) {
-    using P = Plan<LOGM, LOGR>;
+template <int LOGM, typename WORD, int LB, int LR, int NB>
+#ifndef MKT_TW_LDS
+#define MKT_TW_LDS 1   // forward twiddle table resident in LDS (A/B: 17.0 vs 20.6 ms at KMS k=2 N=1024)
+#endif
+#ifndef MKT_ROT_MINW
+#define MKT_ROT_MINW 2
+#endif
+__global__ __launch_bounds__((Plan<LOGM, LR>::NT), MKT_ROT_MINW) void blindrotate_k1_kernel(const RotArgs a) {
+    using P = Plan<LOGM, LR, NB>;   // NB transforms at a time share twiddle loads and barriers
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
+#if MKT_TW_LDS
+    // the forward twiddle table stays resident in LDS behind the staging buffers; the inverse uses its conjugate
+    cplx *psi_l = lds + P::LDS_CPLX;
+    for (int i = t; i < M; i += NT) psi_l[i] = a.tw.psi[i];
+    __syncthreads();
+#define MKT_PSI_F psi_l
+#define MKT_INV(NBV, ZZ) fft_inverse<LOGM, LR, NBV, true>(ZZ, psi_l, lds, t)
+#else
+#define MKT_PSI_F a.tw.psi
+#define MKT_INV(NBV, ZZ) fft_inverse<LOGM, LR, NBV, false>(ZZ, a.tw.psiinv, lds, t)
+#endif
     const size_t rot = blockIdx.x;
     const size_t gate = rot / (size_t)a.rows_per_gate;
     const int slot = (int)(rot % (size_t)a.rows_per_gate);
@@ -192,9 +230,6 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_k1_kernel(
             for (int e = 0; e < R; e++) { acc[c][e][0] = 0; acc[c][e][1] = 0; }
         if (t == 0) acc[0][0][0] = (WORD)1 << (W - (row + 1) * a.logB_lev);
     }
-    cplx rt[R];
-#pragma unroll
-    for (int e = 0; e < R; e++) rt[e] = a.tw.roots[e * NT + t];
 
     const int nblk = a.n / LB;
     const int msbit = 32 - a.logN - 1;
@@ -217,35 +252,46 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_k1_kernel(
 #pragma unroll
                 for (int e = 0; e < R; e++) { tacc[q][c][e].re = 0.0; tacc[q][c][e].im = 0.0; }
 
+        // the 2l digit polynomials in MAC order (b digits, then a digits: :63-68), NB at a time
+        for (int g0 = 0; g0 < 2 * l; g0 += NB) {
+            cplx z[NB][R];
 #pragma unroll
-        for (int c = 0; c < 2; c++) {                                    // digits of b first, then of a (:63-68)
-            WORD tp[R][2];
+            for (int h2 = 0; h2 < NB; h2++) {
+                const int g = g0 + h2;
+                const bool isa = g >= l;
+                const int j = isa ? g - l : g;
 #pragma unroll
-            for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(acc[c][e][0]); tp[e][1] = gd.prep(acc[c][e][1]); }
-            for (int j = 0; j < l; j++) {
-                cplx z[R];
-                digit_points<WORD, R>(z, tp, gd, j, rt);                 // :50-51 decompto!
-                fft_forward<LOGM, LOGR>(z, a.tw.psi, lds, t);            // :54-59 fftto!
-#pragma unroll
-                for (int q = 0; q < LB; q++) {
-                    if (ats[q] == 0) continue;
-                    const cplx *krow = brk + (((size_t)(blk * LB + q) * 2 * l + (size_t)(c * l + j)) * 2) * M + (size_t)t * R;
-#pragma unroll
-                    for (int e = 0; e < R; e++) {                        // :63-68 muladdto!(tacc, digit, row)
-                        tacc[q][0][e] = cadd(tacc[q][0][e], cmul(z[e], krow[e]));
-                        tacc[q][1][e] = cadd(tacc[q][1][e], cmul(z[e], krow[M + e]));
-                    }
+                for (int e = 0; e < R; e++) {                            // :50-51 decompto!, fft.jl:57-63 twist
+                    const WORD w0 = isa ? acc[1][e][0] : acc[0][e][0], w1 = isa ? acc[1][e][1] : acc[0][e][1];
+                    const int d0 = gd.digit(gd.prep(w0), j), d1 = gd.digit(gd.prep(w1), j);
+                    cplx v; v.re = (double)d0; v.im = (double)(-d1);
+                    z[h2][e] = cmul(v, a.tw.roots[e * NT + t]);
                 }
             }
+            fft_forward<LOGM, LR, NB>(z, MKT_PSI_F, lds, t);              // :54-59 fftto!
+#pragma unroll
+            for (int h2 = 0; h2 < NB; h2++)
+#pragma unroll
+                for (int q = 0; q < LB; q++) {
+                    if (LB > 1 && ats[q] == 0) continue;
+                    const cplx *krow = brk + (((size_t)(blk * LB + q) * 2 * l + (size_t)(g0 + h2)) * 2) * M;
+#pragma unroll
+                    for (int e = 0; e < R; e++) {                        // :63-68 muladdto!(tacc, digit, row)
+                        cplx kb, ka;
+                        if (MKT_ABLATE & 1) { kb.re = 1.5; kb.im = (double)t; ka.re = 2.5; ka.im = (double)e; } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
+                        tacc[q][0][e] = cadd(tacc[q][0][e], cmul(z[h2][e], kb));
+                        tacc[q][1][e] = cadd(tacc[q][1][e], cmul(z[h2][e], ka));
+                    }
+                }
         }
 
         cplx t2[2][R];
-        if (LB == 1 && !a.blk_accum) {                               // :71 mul!(monomial[atilde], tacc)
-            const cplx *mono = a.monomial + (size_t)(ats[0] - 1) * M + (size_t)t * R;
+        if (LB == 1 && !a.blk_accum) {                                   // :71 mul!(monomial[atilde], tacc)
+            const cplx *mono = a.monomial + (size_t)(ats[0] - 1) * M;
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int e = 0; e < R; e++) t2[c][e] = cmul(mono[e], tacc[0][c][e]);
+                for (int e = 0; e < R; e++) { cplx mv; if (MKT_ABLATE & 1) { mv.re = 0.5; mv.im = (double)e; } else mv = mono[dev_pos(t * R + e, NT)]; t2[c][e] = cmul(mv, tacc[0][c][e]); }
         } else {                                                         // :157 / :648 tacc2 += monomial * tacc
 #pragma unroll
             for (int c = 0; c < 2; c++)
@@ -254,19 +300,28 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_k1_kernel(
 #pragma unroll
             for (int q = 0; q < LB; q++) {
                 if (ats[q] == 0) continue;
-                const cplx *mono = a.monomial + (size_t)(ats[q] - 1) * M + (size_t)t * R;
+                const cplx *mono = a.monomial + (size_t)(ats[q] - 1) * M;
 #pragma unroll
                 for (int c = 0; c < 2; c++)
 #pragma unroll
-                    for (int e = 0; e < R; e++) t2[c][e] = cadd(t2[c][e], cmul(mono[e], tacc[q][c][e]));
+                    for (int e = 0; e < R; e++) t2[c][e] = cadd(t2[c][e], cmul(mono[dev_pos(t * R + e, NT)], tacc[q][c][e]));
             }
         }
+        if (NB == 2) {
+            MKT_INV(2, t2);                                              // :72 ifftto! (b and a together)
+        } else {
+            MKT_INV(1, reinterpret_cast<cplx(&)[1][R]>(t2[0]));
+            MKT_INV(1, reinterpret_cast<cplx(&)[1][R]>(t2[1]));
+        }
 #pragma unroll
-        for (int c = 0; c < 2; c++) {                                    // :72-73 ifftto!, add!
-            WORD w[R][2];
-            inverse_to_words<LOGM, WORD>(t2[c], w, a.tw, lds, t);
+        for (int e = 0; e < R; e++) {
+            const cplx ri = a.tw.rootsinv[e * NT + t];
 #pragma unroll
-            for (int e = 0; e < R; e++) { acc[c][e][0] = (WORD)(acc[c][e][0] + w[e][0]); acc[c][e][1] = (WORD)(acc[c][e][1] + w[e][1]); }
+            for (int c = 0; c < 2; c++) {                                // fft.jl:76-80 untwist + native; :73 add!
+                const cplx v = cmul(t2[c][e], ri);
+                acc[c][e][0] = (WORD)(acc[c][e][0] + native<WORD>(v.re));
+                acc[c][e][1] = (WORD)(acc[c][e][1] + native<WORD>(-v.im));
+            }
         }
     }
 
@@ -279,16 +334,16 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_k1_kernel(
     } else {                                                             // :441 / :657 fftto!(tacc, acc)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            cplx z[R];
+            cplx z[1][R];
 #pragma unroll
             for (int e = 0; e < R; e++) {
                 cplx v; v.re = word_to_f64<WORD>(acc[c][e][0]); v.im = word_to_f64<WORD>((WORD)((WORD)0 - acc[c][e][1]));
-                z[e] = cmul(v, rt[e]);
+                z[0][e] = cmul(v, a.tw.roots[e * NT + t]);
             }
-            fft_forward<LOGM, LOGR>(z, a.tw.psi, lds, t);
-            cplx *o = a.tout + (rot * 2 + c) * M + (size_t)t * R;
+            fft_forward<LOGM, LR, 1>(z, MKT_PSI_F, lds, t);
+            cplx *o = a.tout + (rot * 2 + c) * M;
 #pragma unroll
-            for (int e = 0; e < R; e++) o[e] = z[e];
+            for (int e = 0; e < R; e++) o[a.tout_natural ? t * R + e : dev_pos(t * R + e, NT)] = z[0][e];
         }
     }
 }
@@ -311,7 +366,9 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
     cplx *tx = a.scratch + g * (size_t)2 * (k + 1) * M;
     cplx *ty2 = tx + (size_t)(k + 1) * M;
     const Gadget<WORD> glev(a.l_lev, a.logB_lev), guni(a.l_uni, a.logB_uni);
-    const size_t pt = (size_t)t * R;
+    int dp[R];                     // device point order of this thread's slots
+#pragma unroll
+    for (int e = 0; e < R; e++) dp[e] = dev_pos(t * R + e, NT);
 
     cplx rt[R];
 #pragma unroll
@@ -355,13 +412,13 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
             for (int j = 0; j < iter; j++) {                              // :485-499 LEV multiplication
                 cplx z[R];
                 digit_points<WORD, R>(z, tp, glev, j, rt);
-                fft_forward<LOGM, LOGR>(z, a.tw.psi, lds, t);
-                const cplx *kb = lev + (size_t)(2 * j) * M + pt, *ka = kb + M;
+                fft_forward1<LOGM>(z, a.tw.psi, lds, t);
+                const cplx *kb = lev + (size_t)(2 * j) * M, *ka = kb + M;
 #pragma unroll
-                for (int e = 0; e < R; e++) { txq[e] = cadd(txq[e], cmul(z[e], kb[e])); tyq[e] = cadd(tyq[e], cmul(z[e], ka[e])); }
+                for (int e = 0; e < R; e++) { txq[e] = cadd(txq[e], cmul(z[e], kb[dp[e]])); tyq[e] = cadd(tyq[e], cmul(z[e], ka[dp[e]])); }
             }
 #pragma unroll
-            for (int e = 0; e < R; e++) tx[(size_t)q * M + pt + e] = txq[e];
+            for (int e = 0; e < R; e++) tx[(size_t)q * M + dp[e]] = txq[e];
             WORD yw[R][2];
             inverse_to_words<LOGM, WORD>(tyq, yw, a.tw, lds, t);          // :501-504
 #pragma unroll
@@ -373,17 +430,17 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
             for (int j = 0; j < a.l_uni; j++) {                           // :521-535 u and v
                 cplx z[R];
                 digit_points<WORD, R>(z, tp, guni, j, rt);
-                fft_forward<LOGM, LOGR>(z, a.tw.psi, lds, t);
-                const cplx *kd = rd + (size_t)j * M + pt, *kv = vk + (size_t)j * M + pt;
+                fft_forward1<LOGM>(z, a.tw.psi, lds, t);
+                const cplx *kd = rd + (size_t)j * M, *kv = vk + (size_t)j * M;
 #pragma unroll
                 for (int e = 0; e < R; e++) {
-                    tyu[e] = cadd(tyu[e], cmul(z[e], kd[e]));
-                    const cplx pr = cmul(z[e], kv[e]);
+                    tyu[e] = cadd(tyu[e], cmul(z[e], kd[dp[e]]));
+                    const cplx pr = cmul(z[e], kv[dp[e]]);
                     tv[e] = q == 0 ? csub(tv[e], pr) : cadd(tv[e], pr);   // mulsubto! with crs, muladdto! with b_i
                 }
             }
 #pragma unroll
-            for (int e = 0; e < R; e++) ty2[(size_t)q * M + pt + e] = tyu[e];
+            for (int e = 0; e < R; e++) ty2[(size_t)q * M + dp[e]] = tyu[e];
         }
 
         WORD vw[R][2];
@@ -393,14 +450,14 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
         for (int e = 0; e < R; e++) { tp[e][0] = guni.prep(vw[e][0]); tp[e][1] = guni.prep(vw[e][1]); }      // :541
         cplx tyb[R], tya[R];
 #pragma unroll
-        for (int e = 0; e < R; e++) { tyb[e] = ty2[pt + e]; tya[e].re = tya[e].im = 0.0; }
+        for (int e = 0; e < R; e++) { tyb[e] = ty2[dp[e]]; tya[e].re = tya[e].im = 0.0; }
         for (int i = 0; i < a.l_uni; i++) {                               // :547-550 w
             cplx z[R];
             digit_points<WORD, R>(z, tp, guni, i, rt);
-            fft_forward<LOGM, LOGR>(z, a.tw.psi, lds, t);
-            const cplx *fb = rf + (size_t)(2 * i) * M + pt, *fa = fb + M;
+            fft_forward1<LOGM>(z, a.tw.psi, lds, t);
+            const cplx *fb = rf + (size_t)(2 * i) * M, *fa = fb + M;
 #pragma unroll
-            for (int e = 0; e < R; e++) { tyb[e] = cadd(tyb[e], cmul(z[e], fb[e])); tya[e] = cadd(tya[e], cmul(z[e], fa[e])); }
+            for (int e = 0; e < R; e++) { tyb[e] = cadd(tyb[e], cmul(z[e], fb[dp[e]])); tya[e] = cadd(tya[e], cmul(z[e], fa[dp[e]])); }
         }
         // :553 add!(tx, ty); :556 ifftto!(acc, tx)
         for (int q = 0; q <= idx + 1; q++) {
@@ -408,8 +465,8 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
 #pragma unroll
             for (int e = 0; e < R; e++) {
                 cplx xv, yv;
-                if (q <= idx) xv = tx[(size_t)q * M + pt + e]; else { xv.re = 0.0; xv.im = 0.0; }
-                if (q == 0) yv = tyb[e]; else if (q == idx + 1) yv = tya[e]; else yv = ty2[(size_t)q * M + pt + e];
+                if (q <= idx) xv = tx[(size_t)q * M + dp[e]]; else { xv.re = 0.0; xv.im = 0.0; }
+                if (q == 0) yv = tyb[e]; else if (q == idx + 1) yv = tya[e]; else yv = ty2[(size_t)q * M + dp[e]];
                 s[e] = cadd(xv, yv);
             }
             WORD w[R][2];
@@ -546,18 +603,26 @@ bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
     default: return hipErrorInvalidValue;            \
     }
 
-hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, hipStream_t s) {
+hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, hipStream_t s) {
     if (B == 0) return hipSuccess;
     const int grid = (int)(B < 4096 ? B : 4096);
     MKT_DISPATCH_LOGM(logM, {
         using P = Plan<LM, LOGR>;
         if (W == 64) {
             hipError_t e = set_lds(transform_fwd_kernel<LM, uint64_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, (const uint64_t *)p, t, B);
+            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, (const uint64_t *)p, t, B, dev_order);
         } else {
             hipError_t e = set_lds(transform_fwd_kernel<LM, uint32_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, (const uint32_t *)p, t, B);
+            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, (const uint32_t *)p, t, B, dev_order);
         }
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, int to_device, hipStream_t s) {
+    if (!npolys) return hipSuccess;
+    MKT_DISPATCH_LOGM(logM, {
+        hipLaunchKernelGGL((reorder_kernel<LM>), dim3(blocks_for(npolys << LM, 256)), dim3(256), 0, s, in, out, npolys, to_device);
     });
     return hipGetLastError();
 }
@@ -613,23 +678,37 @@ hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int log
     return hipGetLastError();
 }
 
+template <int LM, typename WORD, int LB, int LR, int NB>
+static hipError_t launch_rot_one(const RotArgs &a, size_t nrot, hipStream_t s) {
+    if constexpr (LM < LR) { return hipErrorInvalidValue; } else {
+        using P = Plan<LM, LR, NB>;
+        const size_t lds_bytes = P::LDS_BYTES + (MKT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
+        hipError_t e = set_lds(blindrotate_k1_kernel<LM, WORD, LB, LR, NB>, lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((blindrotate_k1_kernel<LM, WORD, LB, LR, NB>), dim3((unsigned)nrot), dim3(P::NT), lds_bytes, s, a);
+        return hipGetLastError();
+    }
+}
+
+// variant = 10*LR + NB for the plain schemes (tuning knob).  Only LR == LOGR variants are built: the device
+// point order of the key tables is tied to the points-per-thread of the schedule.
 template <int LM, typename WORD>
 static hipError_t launch_rot_lb(const RotArgs &a, size_t nrot, hipStream_t s) {
-    using P = Plan<LM, LOGR>;
-#define MKT_ROT(LBV)                                                                                          \
-    {                                                                                                         \
-        hipError_t e = set_lds(blindrotate_k1_kernel<LM, WORD, LBV>, P::LDS_BYTES); if (e != hipSuccess) return e; \
-        hipLaunchKernelGGL((blindrotate_k1_kernel<LM, WORD, LBV>), dim3((unsigned)nrot), dim3(P::NT), P::LDS_BYTES, s, a); \
-    }
+    int variant = a.variant;
+    if (variant == 0) variant = LM <= 9 ? 22 : 21;   // pairs of transforms up to M = 512, single transforms above (LDS budget)
+    if ((2 * a.l) % (variant % 10) != 0) variant = (variant / 10) * 10 + 1;
     switch (a.blk_len) {
-    case 1: MKT_ROT(1) break;
-    case 2: MKT_ROT(2) break;
-    case 3: MKT_ROT(3) break;
-    case 4: MKT_ROT(4) break;
+    case 1:
+        switch (variant) {
+        case 21: return launch_rot_one<LM, WORD, 1, 2, 1>(a, nrot, s);
+        case 22: return launch_rot_one<LM, WORD, 1, 2, 2>(a, nrot, s);
+        default: return hipErrorInvalidValue;
+        }
+    case 2: return launch_rot_one<LM, WORD, 2, 2, 2>(a, nrot, s);
+    case 3: return launch_rot_one<LM, WORD, 3, 2, 2>(a, nrot, s);
+    case 4: return launch_rot_one<LM, WORD, 4, 2, 2>(a, nrot, s);
     default: return hipErrorInvalidValue;
     }
-#undef MKT_ROT
-    return hipGetLastError();
 }
 
 hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s) {
