@@ -34,7 +34,7 @@ struct mkt_ctx {
     cplx *d_monomial = nullptr;  // [2N][M]
     // keys
     cplx *d_brk = nullptr;  size_t brk_party_cplx = 0;  std::vector<char> brk_loaded;
-    uint32_t *d_ksk = nullptr; size_t ksk_party_words = 0; std::vector<char> ksk_loaded;
+    uint32_t *d_ksk = nullptr; size_t ksk_party_words = 0; int n1p = 0; std::vector<char> ksk_loaded;
     cplx *d_rlk_d = nullptr, *d_rlk_f = nullptr, *d_pub = nullptr, *d_crs = nullptr;
     std::vector<char> rlk_loaded, pub_loaded; bool crs_loaded = false;
     // rotation slots (KMS phase 1: party-major rows)
@@ -213,7 +213,7 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
 int do_keyswitch(mkt_ctx *c, const void *acc, uint32_t *out, size_t B) {
     const mkt_params &p = c->p;
     mktd::KsArgs a{};
-    a.acc = acc; a.out = out; a.ksk = c->d_ksk; a.ksk_party_stride = c->ksk_party_words;
+    a.acc = acc; a.out = out; a.ksk = c->d_ksk; a.ksk_party_stride = c->ksk_party_words; a.n1p = c->n1p;
     a.N = p.N; a.n = p.n; a.f = p.f; a.logD = p.logD; a.drows = c->sh.ksk_drows; a.kacc = c->sh.kacc;
     a.mk = mkt::is_mk(p.scheme) ? 1 : 0; a.balanced = mkt::is_block(p.scheme) ? 1 : 0; a.lmss = p.scheme == MKT_LMSS ? 1 : 0;
     Timer tm(c, 2);
@@ -299,7 +299,8 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     CK(hipMalloc((void **)&c->d_monomial, (size_t)2 * N * M * sizeof(cplx)));
     c->brk_party_cplx = (size_t)p.n * c->sh.brk_polys * M;
     CK(hipMalloc((void **)&c->d_brk, (size_t)np * c->brk_party_cplx * sizeof(cplx)));
-    c->ksk_party_words = (size_t)c->sh.ksk_kr * N * c->sh.ksk_drows * p.f * (p.n + 1);
+    c->n1p = (p.n + 1 + 3) / 4 * 4;   // device rows padded to 16 B
+    c->ksk_party_words = (size_t)c->sh.ksk_kr * N * c->sh.ksk_drows * p.f * c->n1p;
     CK(hipMalloc((void **)&c->d_ksk, (size_t)np * c->ksk_party_words * sizeof(uint32_t)));
     if (mkt::is_mk(p.scheme)) {
         CK(hipMalloc((void **)&c->d_pub, (size_t)np * p.l_uni * M * sizeof(cplx)));
@@ -396,7 +397,9 @@ int mkt_load_brk(mkt_ctx *c, int party, const void *data, int fmt) {
 int mkt_load_ksk(mkt_ctx *c, int party, const uint32_t *data) {
     if (!c || !data || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
     DevGuard dg(c->device);
-    HIPCHK(c, hipMemcpy(c->d_ksk + (size_t)party * c->ksk_party_words, data, c->ksk_party_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const size_t rows = (size_t)c->sh.ksk_kr * c->p.N * c->sh.ksk_drows * c->p.f, n1 = (size_t)c->p.n + 1;
+    HIPCHK(c, hipMemset(c->d_ksk + (size_t)party * c->ksk_party_words, 0, c->ksk_party_words * sizeof(uint32_t)));
+    HIPCHK(c, hipMemcpy2D(c->d_ksk + (size_t)party * c->ksk_party_words, (size_t)c->n1p * 4, data, n1 * 4, n1 * 4, rows, hipMemcpyHostToDevice));
     c->ksk_loaded[party] = 1;
     return MKT_OK;
 }

@@ -56,8 +56,9 @@ struct Phase2Args {
 struct KsArgs {
     const void *acc;          // [B][1+kacc][N] ring words
     uint32_t *out;            // [B][lwe_len]
-    const uint32_t *ksk;      // party 0 base
+    const uint32_t *ksk;      // party 0 base; [kr][N][drows][f][n1p] rows padded to n1p = 4*ceil((n+1)/4) words
     size_t ksk_party_stride;  // words
+    int n1p;
     int N, n, f, logD, drows;
     int kacc;                 // ring components
     int mk;                   // 1: component i -> party i's KSK and mask block i; 0: single block, ksk comp i

@@ -4,6 +4,8 @@
 #include "device_api.h"
 #include "fft_device.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace mktd {
@@ -24,6 +26,15 @@ __device__ __forceinline__ void fft_inverse1(cplx (&z)[1 << LOGR], const cplx *_
 // ------------------------------------------------------------------------------------------------
 // batched transforms (fft.jl:57-63 / :74-81): HBM -> HBM, one polynomial per workgroup pass
 // ------------------------------------------------------------------------------------------------
+// Batched transforms HBM -> HBM.  Loads are contiguous across the wave (8 B or 4 B per lane), software-pipelined one
+// polynomial ahead in registers.  The reference-order output (point 4t+e) is either stored as 64 B per lane
+// (MKT_FFT_CONTIG_STORE 0) or brought to thread-contiguous ownership by one more staging exchange and stored as
+// contiguous 16 B/lane wave accesses (1).  tools/membench.hip measures the pattern ceilings on this part:
+// copy 4.6-5.4 TB/s, contiguous stores 5.0-5.2, 64 B-strided stores 4.2-4.8.
+#ifndef MKT_FFT_CONTIG_STORE
+#define MKT_FFT_CONTIG_STORE 1
+#endif
+
 template <int LOGM, typename WORD>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(TwPtrs tw, const WORD *__restrict__ p,
                                                                             cplx *__restrict__ out, size_t B, int dev_order) {
@@ -34,33 +45,40 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
     cplx rt[R];
 #pragma unroll
     for (int e = 0; e < R; e++) rt[e] = tw.roots[e * NT + t];
-    for (size_t b = blockIdx.x; b < B; b += gridDim.x) {
-        const WORD *pp = p + b * N;
+    WORD c0[R], c1[R];
+    size_t b = blockIdx.x;
+    if (b < B) {
+#pragma unroll
+        for (int e = 0; e < R; e++) { c0[e] = p[b * N + e * NT + t]; c1[e] = p[b * N + M + e * NT + t]; }
+    }
+    for (; b < B; b += gridDim.x) {
         cplx z[R];
 #pragma unroll
         for (int e = 0; e < R; e++) {
-            const int idx = e * NT + t;
             cplx v;
-            v.re = word_to_f64<WORD>(pp[idx]);
-            v.im = word_to_f64<WORD>((WORD)((WORD)0 - pp[idx + M]));   // subtraction in the integer type (fft.jl:60)
+            v.re = word_to_f64<WORD>(c0[e]);
+            v.im = word_to_f64<WORD>((WORD)((WORD)0 - c1[e]));   // subtraction in the integer type (fft.jl:60)
             z[e] = cmul(v, rt[e]);
         }
-        fft_forward1<LOGM>(z, tw.psi, lds, t);
-        // natural order: point 4t+e at 4t+e (the reference's TransPoly order); device order: at e*NT+t, so that
-        // every later key-row load is one contiguous 16 B/lane wave access
-        cplx *o = out + b * M;
+        const size_t nb = b + gridDim.x;
+        if (nb < B) {
 #pragma unroll
-        for (int e = 0; e < R; e++) o[dev_order ? dev_pos(t * R + e, NT) : t * R + e] = z[e];
-    }
-}
-
-// natural <-> device point order of TransPolys (F64_FFT key upload, table read-back)
-template <int LOGM>
-__global__ void reorder_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, size_t npolys, int to_device) {
-    constexpr int M = 1 << LOGM, R = 1 << LOGR, NT = M / R;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npolys * M; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = i / M; const int x = (int)(i % M);
-        if (to_device) out[b * M + dev_pos(x, NT)] = in[i]; else out[i] = in[b * M + dev_pos(x, NT)];
+            for (int e = 0; e < R; e++) { c0[e] = p[nb * N + e * NT + t]; c1[e] = p[nb * N + M + e * NT + t]; }
+        }
+        if (!(MKT_ABLATE & 16)) fft_forward1<LOGM>(z, tw.psi, lds, t);
+        cplx *o = out + b * M;
+        if (dev_order) {          // resident key tables: device point order
+#pragma unroll
+            for (int e = 0; e < R; e++) o[dev_pos(t * R + e, NT)] = z[e];
+        } else if (MKT_FFT_CONTIG_STORE && P::NPASS > 1) {
+            exchange<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][R]>(z), lds + ((P::NPASS - 1) & 1) * P::BUF, t, 0, P::lo(0));
+            __syncthreads();      // the next transform's first exchange reuses this buffer
+#pragma unroll
+            for (int e = 0; e < R; e++) o[e * NT + t] = z[e];
+        } else {                  // the reference's TransPoly order
+#pragma unroll
+            for (int e = 0; e < R; e++) o[t * R + e] = z[e];
+        }
     }
 }
 
@@ -74,11 +92,26 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_inv_kernel(T
     cplx ri[R];
 #pragma unroll
     for (int e = 0; e < R; e++) ri[e] = tw.rootsinv[e * NT + t];
-    for (size_t b = blockIdx.x; b < B; b += gridDim.x) {
-        const cplx *i = in + b * M + (size_t)t * R;
+    constexpr bool CONTIG = MKT_FFT_CONTIG_STORE && P::NPASS > 1;
+    cplx zn[R];
+    size_t b = blockIdx.x;
+    if (b < B) {
+#pragma unroll
+        for (int e = 0; e < R; e++) zn[e] = in[b * M + (CONTIG ? e * NT + t : t * R + e)];
+    }
+    for (; b < B; b += gridDim.x) {
         cplx z[R];
 #pragma unroll
-        for (int e = 0; e < R; e++) z[e] = i[e];
+        for (int e = 0; e < R; e++) z[e] = zn[e];
+        const size_t nb = b + gridDim.x;
+        if (nb < B) {
+#pragma unroll
+            for (int e = 0; e < R; e++) zn[e] = in[nb * M + (CONTIG ? e * NT + t : t * R + e)];
+        }
+        if (CONTIG) {   // contiguous ownership (e*NT + t) -> the inverse transform's first window (4t + e)
+            __syncthreads();
+            exchange<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][R]>(z), lds + (P::NPASS & 1) * P::BUF, t, P::lo(0), 0);
+        }
         fft_inverse1<LOGM>(z, tw.psiinv, lds, t);
         WORD *pp = p + b * N;
 #pragma unroll
@@ -99,6 +132,16 @@ __global__ void decompose_kernel(const WORD *__restrict__ p, WORD *__restrict__ 
         const size_t b = i / N, c = i % N;
         const WORD tp = gd.prep(p[i]);
         for (int j = 0; j < l; j++) dig[(b * l + j) * N + c] = (WORD)(typename WordTraits<WORD>::S)gd.digit(tp, j);
+    }
+}
+
+// natural <-> device point order of TransPolys (F64_FFT key upload, table read-back)
+template <int LOGM>
+__global__ void reorder_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, size_t npolys, int to_device) {
+    constexpr int M = 1 << LOGM, R = 1 << LOGR, NT = M / R;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npolys * M; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / M; const int x = (int)(i % M);
+        if (to_device) out[b * M + dev_pos(x, NT)] = in[i]; else out[i] = in[b * M + dev_pos(x, NT)];
     }
 }
 
@@ -490,84 +533,110 @@ __device__ __forceinline__ uint32_t extract_word(const WORD *a, int j, int N) { 
     return 0u - (uint32_t)(a[N - j] >> sh);
 }
 
+// out = 0 except: b = acc.b[0] >> (W-32) (:86 / :569) and, for the block schemes, the extracted words that are
+// copied instead of switched (:180-191, :676-679).  The key-switch kernel then accumulates with atomics.
 template <typename WORD>
-__global__ void ks_init_kernel(const WORD *__restrict__ acc, uint32_t *__restrict__ out, int kacc, int N, int lwe_len, size_t B) {
+__global__ void ks_init_kernel(const KsArgs a, size_t B) {
     constexpr int sh = WordTraits<WORD>::W - 32;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < B; g += (size_t)gridDim.x * blockDim.x)
-        out[g * lwe_len + lwe_len - 1] = (uint32_t)(acc[g * (size_t)(1 + kacc) * N] >> sh);   // :86 / :569
+    const int nblocks_out = a.mk ? a.kacc : 1;
+    const int lwe_len = nblocks_out * a.n + 1;
+    const size_t total = B * (size_t)lwe_len;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / lwe_len; const int q = (int)(i % lwe_len);
+        const WORD *accg = reinterpret_cast<const WORD *>(a.acc) + g * (size_t)(1 + a.kacc) * a.N;
+        uint32_t v = 0;
+        if (q == lwe_len - 1) v = (uint32_t)(accg[0] >> sh);
+        else if (a.balanced) {
+            if (a.lmss) { const int c = q / a.N, j = q % a.N; v = extract_word<WORD>(accg + (size_t)(1 + c) * a.N, j, a.N); }
+            else { const int c = q / a.n, j = q % a.n; v = extract_word<WORD>(accg + (size_t)(1 + c) * a.N, j, a.N); }
+        }
+        a.out[i] = v;
+    }
 }
 
-constexpr int KS_THREADS = 256, KS_MAXU = 4;
+// Multi-gate key switch.  One wave handles G ciphertexts, one slab of the extracted coefficients j and one
+// 256-word column chunk of the LWE rows.  Every pre-multiplied row ksk[j][d][t] is loaded ONCE per wave (16 B/lane,
+// rows padded to n1p words) and parked in a lane-private LDS table indexed by digit; each ciphertext then picks
+// its row with one ds_read_b128 at a wave-uniform offset (LDS is used as an indexable register file: no lane ever
+// reads another lane's data, so there are no barriers).  3 row loads per (j,t) instead of 0.75*G is what matters:
+// the gather is bound by L2 / Infinity-Cache bandwidth.  Partial sums over slabs meet in u32 atomics; wrap-around
+// addition is order independent, so the result is deterministic.
+constexpr int KS_LANES = 64, KS_CHUNK_WORDS = 4 * KS_LANES, KS_STAGES = 2, KS_MAXROWS = 5;
 
-template <typename WORD>
-__global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(const KsArgs a) {
-    const int t = threadIdx.x;
-    const size_t g = blockIdx.x;
-    const int N = a.N, n = a.n, n1 = n + 1, f = a.f, logD = a.logD;
-    const WORD *accg = reinterpret_cast<const WORD *>(a.acc) + g * (size_t)(1 + a.kacc) * N;
+template <typename WORD, int G>
+__global__ __launch_bounds__(KS_LANES) void keyswitch_mg_kernel(const KsArgs a, int B, int ngroups, int jslab) {
+    __shared__ uint4 tab[KS_STAGES][KS_MAXROWS][KS_LANES];
+    const int lane = threadIdx.x;
+    const int gg = (int)(blockIdx.x % (unsigned)ngroups), slab = (int)(blockIdx.x / (unsigned)ngroups);
+    const int N = a.N, n = a.n, n1p = a.n1p, f = a.f, logD = a.logD;
+    const int q0 = (int)blockIdx.z * KS_CHUNK_WORDS + 4 * lane;
+    const bool active = q0 < n1p;
     const int nblocks_out = a.mk ? a.kacc : 1;
     const int lwe_len = nblocks_out * n + 1;
-    uint32_t *outg = a.out + g * (size_t)lwe_len;
     const int c_begin = a.mk ? (int)blockIdx.y : 0, c_end = a.mk ? c_begin + 1 : a.kacc;
     const uint32_t Dm = (1u << logD) - 1;
+    const int half = 1 << (logD - 1);
     const Gadget<uint32_t> gb(f, logD);
-    const size_t comp_words = (size_t)N * a.drows * f * n1;
-    uint32_t sum[KS_MAXU];
+    const size_t comp_words = (size_t)N * a.drows * f * n1p;
+    const int g_base = gg * G;
+    const int drows = a.drows;
+    uint4 sum[G];
 #pragma unroll
-    for (int u = 0; u < KS_MAXU; u++) sum[u] = 0;
+    for (int g = 0; g < G; g++) sum[g] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS_STAGES; s++) tab[s][0][lane] = make_uint4(0, 0, 0, 0);   // digit 0 adds nothing
 
     for (int c = c_begin; c < c_end; c++) {
-        const WORD *ac = accg + (size_t)(1 + c) * N;
         const uint32_t *ksk = a.mk ? a.ksk + (size_t)c * a.ksk_party_stride : a.ksk + (size_t)c * comp_words;
         int jstart = 0;
-        if (a.balanced) {   // block schemes: the first words are copied (added at the end), not switched
+        if (a.balanced) {
             if (a.lmss) { const long cur = (long)c * N; jstart = cur >= n ? 0 : (cur + N <= n ? N : (int)(n - cur)); }
             else jstart = n;
         }
-        for (int j = jstart; j < N; j++) {
-            const uint32_t w = extract_word<WORD>(ac, j, N);
-            const uint32_t *rowj = ksk + (size_t)j * a.drows * f * n1;
-            if (!a.balanced) {
-                const uint32_t tt = divbits<uint32_t>(w, 32 - f * logD);     // gsw.jl:34-40
-                for (int td = 0; td < f; td++) {
-                    const uint32_t d = (tt >> (logD * (f - 1 - td))) & Dm;
-                    if (d == 0) continue;
-                    const uint32_t *row = rowj + ((size_t)(d - 1) * f + td) * n1;
+        int j0 = slab * jslab, j1 = j0 + jslab;
+        if (j0 < jstart) j0 = jstart;
+        if (j1 > N) j1 = N;
+        for (int j = j0; j < j1; j++) {
+            uint32_t tt[G];   // wave-uniform: the prepared digit word of every ciphertext of the group
 #pragma unroll
-                    for (int u = 0; u < KS_MAXU; u++) { const int q = t + u * KS_THREADS; if (q < n1) sum[u] += row[q]; }
+            for (int g = 0; g < G; g++) {
+                const int gi = g_base + g < B ? g_base + g : B - 1;
+                const WORD *ac = reinterpret_cast<const WORD *>(a.acc) + ((size_t)gi * (1 + a.kacc) + 1 + c) * N;
+                const uint32_t w = extract_word<WORD>(ac, j, N);
+                tt[g] = a.balanced ? gb.prep(w) : divbits<uint32_t>(w, 32 - f * logD);   // gsw.jl:42-52 / :34-40
+            }
+            const uint32_t *rowj = ksk + (size_t)j * drows * f * n1p + q0;
+            for (int td = 0; td < f; td++) {
+                const int st = td & (KS_STAGES - 1);
+                const int shift = logD * (f - 1 - td);
+                for (int d = 1; d <= drows; d++) {
+                    uint4 r = make_uint4(0, 0, 0, 0);
+                    if (active) r = *reinterpret_cast<const uint4 *>(rowj + ((size_t)(d - 1) * f + td) * n1p);
+                    tab[st][d][lane] = r;
+                    if (a.balanced) tab[st][drows + d][lane] = make_uint4(0u - r.x, 0u - r.y, 0u - r.z, 0u - r.w);
                 }
-            } else {
-                const uint32_t tp = gb.prep(w);                              // gsw.jl:42-52
-                for (int td = 0; td < f; td++) {
-                    const int d = gb.digit(tp, td);
-                    if (d == 0) continue;
-                    const int ad = d > 0 ? d : -d;
-                    const uint32_t *row = rowj + ((size_t)(ad - 1) * f + td) * n1;
-                    if (d > 0) {
 #pragma unroll
-                        for (int u = 0; u < KS_MAXU; u++) { const int q = t + u * KS_THREADS; if (q < n1) sum[u] += row[q]; }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < KS_MAXU; u++) { const int q = t + u * KS_THREADS; if (q < n1) sum[u] -= row[q]; }
-                    }
+                for (int g = 0; g < G; g++) {
+                    int idx = (int)((tt[g] >> shift) & Dm);
+                    if (a.balanced) { idx -= half; if (idx < 0) idx = drows - idx; }   // -1 -> drows+1, -2 -> drows+2
+                    const uint4 v = tab[st][idx][lane];
+                    sum[g].x += v.x; sum[g].y += v.y; sum[g].z += v.z; sum[g].w += v.w;
                 }
             }
         }
     }
-    // write the mask block (+ copied words for the block schemes) and fold b
+    if (!active) return;
     const int blk = a.mk ? c_begin : 0;
 #pragma unroll
-    for (int u = 0; u < KS_MAXU; u++) {
-        const int q = t + u * KS_THREADS;
-        if (q < n) {
-            uint32_t v = sum[u];
-            if (a.balanced) {
-                if (a.lmss) { const int c = q / N, j = q % N; v += extract_word<WORD>(accg + (size_t)(1 + c) * N, j, N); }
-                else v += extract_word<WORD>(accg + (size_t)(1 + blk) * N, q, N);
-            }
-            outg[(size_t)blk * n + q] = v;
-        } else if (q == n) {
-            atomicAdd(&outg[lwe_len - 1], sum[u]);
+    for (int g = 0; g < G; g++) {
+        if (g_base + g >= B) break;
+        uint32_t *outg = a.out + (size_t)(g_base + g) * lwe_len;
+        const uint32_t v[4] = {sum[g].x, sum[g].y, sum[g].z, sum[g].w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = q0 + u;
+            if (q < n) { if (v[u]) atomicAdd(&outg[(size_t)blk * n + q], v[u]); }
+            else if (q == n) { if (v[u]) atomicAdd(&outg[lwe_len - 1], v[u]); }
         }
     }
 }
@@ -605,15 +674,19 @@ bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
 
 hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, hipStream_t s) {
     if (B == 0) return hipSuccess;
-    const int grid = (int)(B < 4096 ? B : 4096);
+    int gmax = 4096;
+    if (const char *e = getenv("MKT_FFT_GRID")) { if (atoi(e) > 0) gmax = atoi(e); }
+    const int grid = (int)(B < (size_t)gmax ? B : (size_t)gmax);
     MKT_DISPATCH_LOGM(logM, {
         using P = Plan<LM, LOGR>;
         if (W == 64) {
-            hipError_t e = set_lds(transform_fwd_kernel<LM, uint64_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, (const uint64_t *)p, t, B, dev_order);
+            constexpr size_t LB = P::LDS_BYTES;
+            hipError_t e = set_lds(transform_fwd_kernel<LM, uint64_t>, LB); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), LB, s, tw, (const uint64_t *)p, t, B, dev_order);
         } else {
-            hipError_t e = set_lds(transform_fwd_kernel<LM, uint32_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, (const uint32_t *)p, t, B, dev_order);
+            constexpr size_t LB = P::LDS_BYTES;
+            hipError_t e = set_lds(transform_fwd_kernel<LM, uint32_t>, LB); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), LB, s, tw, (const uint32_t *)p, t, B, dev_order);
         }
     });
     return hipGetLastError();
@@ -633,11 +706,13 @@ hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void 
     MKT_DISPATCH_LOGM(logM, {
         using P = Plan<LM, LOGR>;
         if (W == 64) {
-            hipError_t e = set_lds(transform_inv_kernel<LM, uint64_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((transform_inv_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, t, (uint64_t *)p, B);
+            constexpr size_t LB = P::LDS_BYTES;
+            hipError_t e = set_lds(transform_inv_kernel<LM, uint64_t>, LB); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((transform_inv_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), LB, s, tw, t, (uint64_t *)p, B);
         } else {
-            hipError_t e = set_lds(transform_inv_kernel<LM, uint32_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((transform_inv_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), P::LDS_BYTES, s, tw, t, (uint32_t *)p, B);
+            constexpr size_t LB = P::LDS_BYTES;
+            hipError_t e = set_lds(transform_inv_kernel<LM, uint32_t>, LB); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((transform_inv_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), LB, s, tw, t, (uint32_t *)p, B);
         }
     });
     return hipGetLastError();
@@ -737,16 +812,30 @@ hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hip
 
 hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
-    if (a.n + 1 > KS_THREADS * KS_MAXU) return hipErrorInvalidValue;
-    const int lwe_len = (a.mk ? a.kacc : 1) * a.n + 1;
-    const dim3 grid((unsigned)B, a.mk ? a.kacc : 1);
+    int G = 32, target_blocks = 1024;   // swept on MI355X (tools/ks_sweep.sh): 1.6 ms vs 4.7 ms single-gate at KMS k=2 N=1024
+    if (const char *e = getenv("MKT_KS_G")) G = atoi(e);
+    if (const char *e = getenv("MKT_KS_BLOCKS")) target_blocks = atoi(e);
+    const int ngroups = (int)((B + G - 1) / G);
+    const int parties = a.mk ? a.kacc : 1;
+    // enough workgroups to fill the chip (~8 per CU), slabs of at least 8 coefficients
+    int slabs = (target_blocks + ngroups * parties - 1) / (ngroups * parties);
+    if (slabs < 1) slabs = 1;
+    if (slabs > a.N / 8) slabs = a.N / 8;
+    const int jslab = (a.N + slabs - 1) / slabs;
+    slabs = (a.N + jslab - 1) / jslab;
+    const dim3 grid((unsigned)(ngroups * slabs), (unsigned)parties, (unsigned)((a.n1p + KS_CHUNK_WORDS - 1) / KS_CHUNK_WORDS));
+    if ((1 << (a.logD - 1)) > 2 && a.balanced) return hipErrorInvalidValue;   // digit table holds |d| <= 2
+    if (a.drows > (a.balanced ? 2 : 4)) return hipErrorInvalidValue;
+    const size_t total = B * (size_t)(parties * a.n + 1);
+#define MKT_KS_LAUNCH(WT, GV) hipLaunchKernelGGL((keyswitch_mg_kernel<WT, GV>), grid, dim3(KS_LANES), 0, s, a, (int)B, ngroups, jslab)
     if (W == 64) {
-        hipLaunchKernelGGL(ks_init_kernel<uint64_t>, dim3(blocks_for(B, 256)), dim3(256), 0, s, (const uint64_t *)a.acc, a.out, a.kacc, a.N, lwe_len, B);
-        hipLaunchKernelGGL(keyswitch_kernel<uint64_t>, grid, dim3(KS_THREADS), 0, s, a);
+        hipLaunchKernelGGL(ks_init_kernel<uint64_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
+        if (G == 8) MKT_KS_LAUNCH(uint64_t, 8); else if (G == 32) MKT_KS_LAUNCH(uint64_t, 32); else MKT_KS_LAUNCH(uint64_t, 16);
     } else {
-        hipLaunchKernelGGL(ks_init_kernel<uint32_t>, dim3(blocks_for(B, 256)), dim3(256), 0, s, (const uint32_t *)a.acc, a.out, a.kacc, a.N, lwe_len, B);
-        hipLaunchKernelGGL(keyswitch_kernel<uint32_t>, grid, dim3(KS_THREADS), 0, s, a);
+        hipLaunchKernelGGL(ks_init_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
+        if (G == 8) MKT_KS_LAUNCH(uint32_t, 8); else if (G == 32) MKT_KS_LAUNCH(uint32_t, 32); else MKT_KS_LAUNCH(uint32_t, 16);
     }
+#undef MKT_KS_LAUNCH
     return hipGetLastError();
 }
 
