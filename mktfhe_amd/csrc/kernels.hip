@@ -31,6 +31,9 @@ __device__ __forceinline__ void fft_inverse1(cplx (&z)[1 << LOGR], const cplx *_
 // (MKT_FFT_CONTIG_STORE 0) or brought to thread-contiguous ownership by one more staging exchange and stored as
 // contiguous 16 B/lane wave accesses (1).  tools/membench.hip measures the pattern ceilings on this part:
 // copy 4.6-5.4 TB/s, contiguous stores 5.0-5.2, 64 B-strided stores 4.2-4.8.
+#ifndef MKT_FFT_TW_LDS
+#define MKT_FFT_TW_LDS 1
+#endif
 #ifndef MKT_FFT_CONTIG_STORE
 #define MKT_FFT_CONTIG_STORE 1
 #endif
@@ -42,6 +45,14 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
+#if MKT_FFT_TW_LDS
+    cplx *psi_l = lds + P::LDS_CPLX;          // the twiddle table stays in LDS for all polynomials of this workgroup
+    for (int i = t; i < M; i += NT) psi_l[i] = tw.psi[i];
+    __syncthreads();
+    const cplx *psi_f = psi_l;
+#else
+    const cplx *psi_f = tw.psi;
+#endif
     cplx rt[R];
 #pragma unroll
     for (int e = 0; e < R; e++) rt[e] = tw.roots[e * NT + t];
@@ -65,7 +76,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
 #pragma unroll
             for (int e = 0; e < R; e++) { c0[e] = p[nb * N + e * NT + t]; c1[e] = p[nb * N + M + e * NT + t]; }
         }
-        if (!(MKT_ABLATE & 16)) fft_forward1<LOGM>(z, tw.psi, lds, t);
+        if (!(MKT_ABLATE & 16)) fft_forward1<LOGM>(z, psi_f, lds, t);
         cplx *o = out + b * M;
         if (dev_order) {          // resident key tables: device point order
 #pragma unroll
@@ -674,17 +685,17 @@ bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
 
 hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, hipStream_t s) {
     if (B == 0) return hipSuccess;
-    int gmax = 4096;
+    int gmax = 5120;   // swept on MI355X (tools/fft_ab.sh)
     if (const char *e = getenv("MKT_FFT_GRID")) { if (atoi(e) > 0) gmax = atoi(e); }
     const int grid = (int)(B < (size_t)gmax ? B : (size_t)gmax);
     MKT_DISPATCH_LOGM(logM, {
         using P = Plan<LM, LOGR>;
         if (W == 64) {
-            constexpr size_t LB = P::LDS_BYTES;
+            constexpr size_t LB = P::LDS_BYTES + (MKT_FFT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
             hipError_t e = set_lds(transform_fwd_kernel<LM, uint64_t>, LB); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((transform_fwd_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), LB, s, tw, (const uint64_t *)p, t, B, dev_order);
         } else {
-            constexpr size_t LB = P::LDS_BYTES;
+            constexpr size_t LB = P::LDS_BYTES + (MKT_FFT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
             hipError_t e = set_lds(transform_fwd_kernel<LM, uint32_t>, LB); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((transform_fwd_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), LB, s, tw, (const uint32_t *)p, t, B, dev_order);
         }
