@@ -147,6 +147,9 @@ int ensure_workspace(mkt_ctx *c, size_t gates) {
     if (mkt::is_kms(p.scheme)) {
         HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * (size_t)c->rtot * 2 * c->M * sizeof(cplx)));
         HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)2 * (p.k + 1) * c->M * sizeof(cplx)));
+    } else if (p.scheme == MKT_CCS) {
+        HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * poly_bytes(c)));    // v scratch (ring words)
+        HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)(p.k + 1) * c->M * sizeof(cplx)));
     }
     c->ws_gates = gates;
     return MKT_OK;
@@ -158,6 +161,7 @@ int check_ready(mkt_ctx *c, bool need_brk, bool need_ksk) {
     for (int i = 0; i < c->sh.nparty; i++) {
         if (need_brk && !c->brk_loaded[i]) return fail(c, MKT_ERR_STATE, "bootstrapping key not loaded");
         if (need_ksk && !c->ksk_loaded[i]) return fail(c, MKT_ERR_STATE, "key-switching key not loaded");
+        if (need_brk && c->p.scheme == MKT_CCS && !c->pub_loaded[i]) return fail(c, MKT_ERR_STATE, "public key not loaded");
         if (need_brk && mkt::is_kms(c->p.scheme) && (!c->rlk_loaded[i] || !c->pub_loaded[i])) return fail(c, MKT_ERR_STATE, "rlk / public key not loaded");
     }
     if (need_brk && mkt::is_mk(c->p.scheme) && !c->crs_loaded) return fail(c, MKT_ERR_STATE, "crs not loaded");
@@ -165,8 +169,7 @@ int check_ready(mkt_ctx *c, bool need_brk, bool need_ksk) {
 }
 
 int unsupported_scheme(mkt_ctx *c) {
-    if (c->p.scheme == MKT_CCS) return fail(c, MKT_ERR_UNSUPPORTED, "CCS blind rotation is not implemented yet");
-    if (!mkt::is_kms(c->p.scheme) && c->p.k != 1) return fail(c, MKT_ERR_UNSUPPORTED, "single-key schemes are implemented for RLWE length k = 1");
+    if (!mkt::is_mk(c->p.scheme) && c->p.k != 1) return fail(c, MKT_ERR_UNSUPPORTED, "single-key schemes are implemented for RLWE length k = 1");
     return MKT_OK;
 }
 
@@ -187,6 +190,15 @@ mktd::RotArgs rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
 // blind rotation of `B` accumulators resident at `acc` ([B][1+k][N]); atilde source described by (lwe, stride, pre)
 int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const uint32_t *lin_for_tv, void *acc, cplx *lev, cplx *scratch, size_t B) {
     const mkt_params &p = c->p;
+    if (p.scheme == MKT_CCS) {
+        mktd::CcsArgs q{};
+        q.tw = c->twp(); q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.logN = c->logN; q.k = p.k;
+        q.l = p.l_uni; q.logB = p.logB_uni; q.brk = c->d_brk; q.brk_party_stride = c->brk_party_cplx; q.pub_b = c->d_pub; q.crs = c->d_crs;
+        q.monomial = c->d_monomial; q.acc = acc; q.scratch = scratch; q.vscratch = lev;
+        Timer tm(c, 1);
+        HIPCHK(c, mktd::launch_ccs_blindrotate(c->logM, p.W, q, B, c->stream));
+        return MKT_OK;
+    }
     if (!mkt::is_kms(p.scheme)) {
         mktd::RotArgs a = rot_args(c, lwe, stride, pre);
         a.init_mode = 0; a.out_mode = 0; a.acc_io = acc;
@@ -227,7 +239,7 @@ int bootstrap_chunk(mkt_ctx *c, const uint32_t *lin, uint32_t *out, size_t B) {
     int r;
     if (!mkt::is_kms(p.scheme)) {
         HIPCHK(c, mktd::launch_testvector(p.W, lin, c->sh.lwe_len, c->logN, c->sh.kacc, c->ws_acc, B, c->stream));
-        if ((r = do_blindrotate(c, lin, c->sh.lwe_len, 0, nullptr, c->ws_acc, nullptr, nullptr, B))) return r;
+        if ((r = do_blindrotate(c, lin, c->sh.lwe_len, 0, nullptr, c->ws_acc, c->ws_lev, c->ws_scratch, B))) return r;
     } else {
         if ((r = do_blindrotate(c, lin, c->sh.lwe_len, 0, lin, c->ws_acc, c->ws_lev, c->ws_scratch, B))) return r;
     }

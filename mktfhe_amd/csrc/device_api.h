@@ -53,6 +53,22 @@ struct Phase2Args {
     cplx *scratch;            // [B][2*(k+1)][M]
 };
 
+// CCS blind rotation (bootstrapping.jl:234-328), one workgroup per ciphertext.
+struct CcsArgs {
+    TwPtrs tw;
+    const uint32_t *lwe;      // [B][lwe_stride] LWE words or atilde
+    int lwe_stride, pre_switched;
+    int n, logN, k, l, logB;
+    const cplx *brk;          // [party][n][3l][M]: d[l], then (f[j].b, f[j].a) j-major; device point order
+    size_t brk_party_stride;
+    const cplx *pub_b;        // [party][l][M]
+    const cplx *crs;          // [l][M]
+    const cplx *monomial;
+    void *acc;                // [B][1+k][N] ring words, in place
+    cplx *scratch;            // [B][k+1][M]
+    void *vscratch;           // [B][N] ring words
+};
+
 struct KsArgs {
     const void *acc;          // [B][1+kacc][N] ring words
     uint32_t *out;            // [B][lwe_len]
@@ -76,6 +92,7 @@ hipError_t launch_modswitch(const uint32_t *lwe, uint32_t *atilde, uint32_t *bti
 hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int logN, int kacc, void *acc, size_t B, hipStream_t s);
 hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s);
 hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hipStream_t s);
+hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, hipStream_t s);
 hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s);
 bool transform_supported(int logM);
 

@@ -532,6 +532,133 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// CCS blind rotation (bootstrapping.jl:234-328): k*n hybrid products on a growing prefix of the mask.
+// One workgroup per ciphertext; the accumulator lives in the caller's buffer (L2-resident), transform-domain
+// partial results in a per-ciphertext scratch; every thread only touches its own points / coefficients.
+// Floating-point summation order is the reference's: u (:279-284), then w with the b digits of v0 (:313-316),
+// then w with the digits of v_1..v_np (:317-320) -- which is why u for the current party's mask polynomial is
+// computed first and parked in registers.
+// ------------------------------------------------------------------------------------------------
+template <int LOGM, typename WORD>
+__global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel(const CcsArgs a) {
+    using P = Plan<LOGM, LOGR>;
+    constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
+    cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
+    cplx *psi_l = lds + P::LDS_CPLX;
+    const int t = threadIdx.x;
+    for (int i = t; i < M; i += NT) psi_l[i] = a.tw.psi[i];
+    __syncthreads();
+    const size_t g = blockIdx.x;
+    const int k = a.k, l = a.l, n = a.n;
+    WORD *acc = reinterpret_cast<WORD *>(a.acc) + g * (size_t)(k + 1) * N;
+    cplx *sc = a.scratch + g * (size_t)(k + 1) * M;
+    WORD *vsc = reinterpret_cast<WORD *>(a.vscratch) + g * (size_t)N;
+    const Gadget<WORD> gd(l, a.logB);
+    const int msbit = 32 - a.logN - 1;
+    int dp[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) dp[e] = dev_pos(t * R + e, NT);
+    cplx rt[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) rt[e] = a.tw.roots[e * NT + t];
+
+    // u and v of one input polynomial q (:279-294): tu = sum_j dig_j * d[j]; tv = -/+ sum_j dig_j * (crs | b_{q-1})[j]
+    auto uv = [&](int q, const cplx *ud, cplx (&tu)[R], cplx (&tvq)[R]) {
+        WORD tp[R][2];
+#pragma unroll
+        for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(acc[(size_t)q * N + e * NT + t]); tp[e][1] = gd.prep(acc[(size_t)q * N + M + e * NT + t]); }
+#pragma unroll
+        for (int e = 0; e < R; e++) { tu[e].re = tu[e].im = 0.0; tvq[e].re = tvq[e].im = 0.0; }
+        const cplx *vk = q == 0 ? a.crs : a.pub_b + (size_t)(q - 1) * l * M;
+        for (int j = 0; j < l; j++) {
+            cplx z[R];
+            digit_points<WORD, R>(z, tp, gd, j, rt);
+            fft_forward1<LOGM>(z, psi_l, lds, t);
+            const cplx *kd = ud + (size_t)j * M, *kv = vk + (size_t)j * M;
+#pragma unroll
+            for (int e = 0; e < R; e++) {
+                tu[e] = cadd(tu[e], cmul(z[e], kd[dp[e]]));
+                const cplx pr = cmul(z[e], kv[dp[e]]);
+                tvq[e] = q == 0 ? csub(tvq[e], pr) : cadd(tvq[e], pr);          // :290 mulsubto!, :293 muladdto!
+            }
+        }
+    };
+    // w contribution of one v polynomial given as words (:313-320)
+    auto wpart = [&](const WORD (&vw)[R][2], const cplx *uf, cplx (&tb)[R], cplx (&ta)[R]) {
+        WORD tp[R][2];
+#pragma unroll
+        for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(vw[e][0]); tp[e][1] = gd.prep(vw[e][1]); }
+        for (int j = 0; j < l; j++) {
+            cplx z[R];
+            digit_points<WORD, R>(z, tp, gd, j, rt);
+            fft_forward1<LOGM>(z, psi_l, lds, t);
+            const cplx *fb = uf + (size_t)(2 * j) * M, *fa = fb + M;
+#pragma unroll
+            for (int e = 0; e < R; e++) { tb[e] = cadd(tb[e], cmul(z[e], fb[dp[e]])); ta[e] = cadd(ta[e], cmul(z[e], fa[dp[e]])); }
+        }
+    };
+    auto inv_words = [&](cplx (&z)[R], WORD (&w)[R][2]) {                        // fft.jl:74-81
+        fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t);
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            const cplx v = cmul(z[e], a.tw.rootsinv[e * NT + t]);
+            w[e][0] = native<WORD>(v.re); w[e][1] = native<WORD>(-v.im);
+        }
+    };
+
+    for (int idx = 0; idx < k; idx++) {
+        const int np = idx + 1;
+        const uint32_t *at_src = a.lwe + g * (size_t)a.lwe_stride + (size_t)idx * n;
+        for (int i = 0; i < n; i++) {
+            const uint32_t v0 = at_src[i];
+            const uint32_t at = a.pre_switched ? v0 : divbits<uint32_t>(v0, msbit);
+            if (at == 0) continue;                                               // :261
+            const cplx *uni = a.brk + (size_t)idx * a.brk_party_stride + (size_t)i * 3 * l * M;
+            const cplx *ud = uni, *uf = uni + (size_t)l * M;
+            cplx ta[R], tb[R], tu[R], tvq[R];
+            WORD vw[R][2];
+            // u of the current party's mask polynomial first; its v is parked in the scratch
+            uv(np, ud, ta, tvq);
+            inv_words(tvq, vw);                                                  // :298-300
+#pragma unroll
+            for (int e = 0; e < R; e++) { vsc[e * NT + t] = vw[e][0]; vsc[M + e * NT + t] = vw[e][1]; }
+            // b polynomial: u_b, v0, w(v0)
+            uv(0, ud, tb, tvq);
+            inv_words(tvq, vw);                                                  // :297
+            wpart(vw, uf, tb, ta);                                               // :313-316
+            // earlier parties' mask polynomials
+            for (int q = 1; q < np; q++) {
+                uv(q, ud, tu, tvq);
+#pragma unroll
+                for (int e = 0; e < R; e++) sc[(size_t)q * M + dp[e]] = tu[e];
+                inv_words(tvq, vw);
+                wpart(vw, uf, tb, ta);                                           // :317-320 (j1 = q)
+            }
+#pragma unroll
+            for (int e = 0; e < R; e++) { vw[e][0] = vsc[e * NT + t]; vw[e][1] = vsc[M + e * NT + t]; }
+            wpart(vw, uf, tb, ta);                                               // :317-320 (j1 = np)
+            // :322-324 mul!(monomial, tacc); ifftto!; add!
+            const cplx *mono = a.monomial + (size_t)(at - 1) * M;
+            for (int q = 0; q <= np; q++) {
+                cplx s[R];
+#pragma unroll
+                for (int e = 0; e < R; e++) {
+                    const cplx x = q == 0 ? tb[e] : (q == np ? ta[e] : sc[(size_t)q * M + dp[e]]);
+                    s[e] = cmul(mono[dp[e]], x);
+                }
+                WORD w[R][2];
+                inv_words(s, w);
+#pragma unroll
+                for (int e = 0; e < R; e++) {
+                    acc[(size_t)q * N + e * NT + t] = (WORD)(acc[(size_t)q * N + e * NT + t] + w[e][0]);
+                    acc[(size_t)q * N + M + e * NT + t] = (WORD)(acc[(size_t)q * N + M + e * NT + t] + w[e][1]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sample extract + LWE key switch.  bootstrapping.jl:81-109 (CGGI), :170-229 (LMSS), :333-364 (CCS),
 // :564-594 (KMS), :664-695 (KMS_block).  Gather-accumulate of pre-multiplied LWE rows; u32 wrap adds
 // are order independent, so the per-party partial sums (and the atomics on b) are deterministic.
@@ -816,6 +943,22 @@ hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hip
         } else {
             hipError_t e = set_lds(kms_phase2_kernel<LM, uint32_t>, P::LDS_BYTES); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((kms_phase2_kernel<LM, uint32_t>), dim3((unsigned)B), dim3(P::NT), P::LDS_BYTES, s, a);
+        }
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    MKT_DISPATCH_LOGM(logM, {
+        using P = Plan<LM, LOGR>;
+        constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
+        if (W == 64) {
+            hipError_t e = set_lds(ccs_blindrotate_kernel<LM, uint64_t>, LB); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((ccs_blindrotate_kernel<LM, uint64_t>), dim3((unsigned)B), dim3(P::NT), LB, s, a);
+        } else {
+            hipError_t e = set_lds(ccs_blindrotate_kernel<LM, uint32_t>, LB); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((ccs_blindrotate_kernel<LM, uint32_t>), dim3((unsigned)B), dim3(P::NT), LB, s, a);
         }
     });
     return hipGetLastError();

@@ -92,6 +92,9 @@ SMALL = [
     mk.KMS4party.scaled(n=10, N=256),
     mk.KMS2partyblock.scaled(n=24, N=256, blk_d=8),
     mk.KMS2party_N1024_l2.scaled(n=12),
+    mk.CCS2party.scaled(n=12, N=256),
+    mk.CCS4party.scaled(n=6, N=256),
+    mk.CCS8party.scaled(n=4, N=512),
 ]
 
 
@@ -144,7 +147,7 @@ def test_stages_small(require_gpu, p):
     _stage_check(p)
 
 
-FULL = [mk.CGGIparam, mk.Blockparam, mk.KMS2party, mk.KMS2partyblock, mk.KMS2party_N1024_l2]
+FULL = [mk.CGGIparam, mk.Blockparam, mk.KMS2party, mk.KMS2partyblock, mk.KMS2party_N1024_l2, mk.CCS2party]
 
 
 @pytest.mark.parametrize("p", FULL, ids=lambda p: p.name)
