@@ -12,3 +12,5 @@ from .scheme import (  # noqa: F401
     MEM_DEVICE, MEM_HOST, FMT_INT_COEFF, FMT_F64_FFT, ARITH_F64REF, ARITH_EXACT,
 )
 from ._lib import MktError, LIB_PATH  # noqa: F401
+from . import keyblob  # noqa: F401,E402
+from . import circuit  # noqa: F401,E402

@@ -1,0 +1,130 @@
+"""Levelised gate-circuit evaluation on top of the batched gate primitive.
+
+The reference's tests fold gates one at a time (test/KMS.jl:29-34).  Here a circuit is a DAG of two-input
+bootstrapped gates (gate.jl:1-53) and free NOTs (gate.jl:55-58); gates of equal depth and equal type are
+evaluated in ONE mkt_gate_batch call, over all `B` independent input sets at once, with ciphertexts staying
+where they are (GPU tensors stay in HBM between levels).
+"""
+from collections import defaultdict
+
+import numpy as np
+
+from .params import NAND_OP, AND_OP, OR_OP, XOR_OP, XNOR_OP, NOR_OP
+
+_NOT = -1
+
+
+class Circuit:
+    def __init__(self):
+        self.nodes = []      # (op, a, b) ; inputs: ("in", index, None)
+        self.n_inputs = 0
+        self.outputs = []
+
+    def input(self):
+        self.nodes.append(("in", self.n_inputs, None))
+        self.n_inputs += 1
+        return len(self.nodes) - 1
+
+    def gate(self, op, a, b):
+        assert 0 <= op <= 5 and 0 <= a < len(self.nodes) and 0 <= b < len(self.nodes)
+        self.nodes.append((op, a, b))
+        return len(self.nodes) - 1
+
+    def NAND(self, a, b): return self.gate(NAND_OP, a, b)
+    def AND(self, a, b): return self.gate(AND_OP, a, b)
+    def OR(self, a, b): return self.gate(OR_OP, a, b)
+    def XOR(self, a, b): return self.gate(XOR_OP, a, b)
+    def XNOR(self, a, b): return self.gate(XNOR_OP, a, b)
+    def NOR(self, a, b): return self.gate(NOR_OP, a, b)
+
+    def NOT(self, a):
+        self.nodes.append((_NOT, a, None))
+        return len(self.nodes) - 1
+
+    def output(self, w):
+        self.outputs.append(w)
+        return w
+
+    def levels(self):
+        """-> (depth per node, {level: {op: [node ids]}}) ; NOT and inputs cost no level"""
+        depth = []
+        for op, a, b in self.nodes:
+            if op == "in":
+                depth.append(0)
+            elif op == _NOT:
+                depth.append(depth[a])
+            else:
+                depth.append(1 + max(depth[a], depth[b]))
+        sched = defaultdict(lambda: defaultdict(list))
+        for i, (op, a, b) in enumerate(self.nodes):
+            if op not in ("in", _NOT):
+                sched[depth[i]][op].append(i)
+        return depth, sched
+
+    def plain(self, bits):
+        """reference evaluation on plaintext bits: bits (n_inputs, ...) bool"""
+        f = {0: lambda x, y: ~(x & y), 1: lambda x, y: x & y, 2: lambda x, y: x | y, 3: lambda x, y: x ^ y,
+             4: lambda x, y: ~(x ^ y), 5: lambda x, y: ~(x | y)}
+        v = []
+        for op, a, b in self.nodes:
+            v.append(bits[a] if op == "in" else (~v[a] if op == _NOT else f[op](v[a], v[b])))
+        return [v[w] for w in self.outputs]
+
+
+def _cat(xs):
+    if type(xs[0]).__module__.startswith("torch"):
+        import torch
+        return torch.cat(xs, 0)
+    return np.concatenate(xs, 0)
+
+
+def evaluate(circ: Circuit, inputs, gate_fn, not_fn):
+    """inputs: list of n_inputs arrays [B, lwe_len] (numpy or GPU tensors).  gate_fn(op, x, y) -> out is the
+    batched gate (Scheme.gate), not_fn(x) -> negated COPY.  Returns the output ciphertext arrays [B, lwe_len].
+    Number of gate_fn calls = number of distinct (level, op) pairs, independent of the circuit width."""
+    assert len(inputs) == circ.n_inputs
+    depth, sched = circ.levels()
+    val = [None] * len(circ.nodes)
+
+    def resolve(i):
+        if val[i] is None:
+            op, a, _ = circ.nodes[i]
+            val[i] = inputs[a] if op == "in" else not_fn(resolve(a))
+        return val[i]
+
+    B = inputs[0].shape[0] if circ.n_inputs else 0
+    for lvl in sorted(sched):
+        for op, ids in sched[lvl].items():
+            x = _cat([resolve(circ.nodes[i][1]) for i in ids])
+            y = _cat([resolve(circ.nodes[i][2]) for i in ids])
+            out = gate_fn(op, x, y)
+            for j, i in enumerate(ids):
+                val[i] = out[j * B:(j + 1) * B]
+    return [resolve(w) for w in circ.outputs]
+
+
+def evaluate_on(circ: Circuit, inputs, scheme):
+    """evaluate with an engine Scheme (GPU tensors or numpy arrays)"""
+    def not_fn(x):
+        y = x.clone() if hasattr(x, "clone") else x.copy()
+        scheme.not_(y)
+        return y
+    return evaluate(circ, inputs, lambda op, x, y: scheme.gate(op, x, y), not_fn)
+
+
+def ripple_adder(nbits):
+    """nbits-bit adder: inputs a0..a{n-1}, b0..b{n-1} (LSB first), outputs s0..s{n-1}, carry"""
+    c = Circuit()
+    a = [c.input() for _ in range(nbits)]
+    b = [c.input() for _ in range(nbits)]
+    carry = None
+    for i in range(nbits):
+        p = c.XOR(a[i], b[i])
+        g = c.AND(a[i], b[i])
+        if carry is None:
+            c.output(p); carry = g
+        else:
+            c.output(c.XOR(p, carry))
+            carry = c.OR(g, c.AND(p, carry))
+    c.output(carry)
+    return c

@@ -317,7 +317,8 @@ __global__ __launch_bounds__((Plan<LOGM, LR>::NT), MKT_ROT_MINW) void blindrotat
 #pragma unroll
                 for (int e = 0; e < R; e++) {                            // :50-51 decompto!, fft.jl:57-63 twist
                     const WORD w0 = isa ? acc[1][e][0] : acc[0][e][0], w1 = isa ? acc[1][e][1] : acc[0][e][1];
-                    const int d0 = gd.digit(gd.prep(w0), j), d1 = gd.digit(gd.prep(w1), j);
+                    int d0, d1;
+                    if (MKT_ABLATE & 32) { d0 = (int)(w0 & 7) - 4 + j; d1 = (int)(w1 & 7) - 3; } else { d0 = gd.digit(gd.prep(w0), j); d1 = gd.digit(gd.prep(w1), j); }
                     cplx v; v.re = (double)d0; v.im = (double)(-d1);
                     z[h2][e] = cmul(v, a.tw.roots[e * NT + t]);
                 }

@@ -274,3 +274,40 @@ def test_empty_and_single(require_gpu):
     one = sg.gate(2, c[0], c[1])                                       # un-batched 1-D ciphertexts
     assert one.shape == (p.lwe_len,) and mk.lwe_decrypt(one, keys[0], p) is True
     sg.close()
+
+
+def test_keyblob_upload(require_gpu):
+    """evaluation keys travel as flat versioned blobs: same outputs as direct upload"""
+    p = mk.KMS2party.scaled(n=12, N=256)
+    crs, keys = keygen(p, 9)
+    sg = mk.Scheme(p)
+    mk.keyblob.load_into(sg, mk.keyblob.dump_crs(p, crs))
+    for kk in keys:
+        mk.keyblob.load_into(sg, mk.keyblob.dump_party(kk))
+    so = oracle_scheme(p, crs, keys)
+    c = encrypt_bits(p, keys, [1, 0, 0, 1], seed=90)
+    assert np.array_equal(sg.gate(5, c[:2], c[2:]), np.stack([so.gate(5, c[j], c[2 + j]) for j in range(2)]))
+    with pytest.raises(ValueError):
+        mk.keyblob.load_into(mk.Scheme(p.scaled(n=10)), mk.keyblob.dump_party(keys[0]))
+    sg.close()
+
+
+def test_circuit_on_device(require_gpu):
+    """4-bit adder, 64 independent input sets, ciphertexts resident in HBM between levels"""
+    import torch
+    from mktfhe_amd import circuit as CI
+    p = mk.KMS2party
+    crs, keys = keygen(p, 14)
+    sg = gpu_scheme(p, crs, keys)
+    circ = CI.ripple_adder(4)
+    B = 64
+    rng = np.random.default_rng(15)
+    bits = rng.integers(0, 2, (8, B)).astype(bool)
+    pool = {(i, v): mk.lwe_ith_encrypt(v, i % 2, keys[i % 2], p, seed=1500 + 2 * i + v) for i in range(8) for v in (0, 1)}
+    inputs = [torch.from_numpy(np.stack([pool[(i, int(bits[i, j]))] for j in range(B)]).view(np.int32)).cuda() for i in range(8)]
+    outs = CI.evaluate_on(circ, inputs, sg)
+    torch.cuda.synchronize()
+    got = sum(mk.lwe_decrypt(o.cpu().numpy().view(np.uint32), keys, p).astype(int) << i for i, o in enumerate(outs))
+    a = sum(bits[i].astype(int) << i for i in range(4)); b = sum(bits[4 + i].astype(int) << i for i in range(4))
+    assert np.array_equal(got, a + b)
+    sg.close()

@@ -308,3 +308,52 @@ def test_product_package_does_not_import_oracle():
             if fn.endswith((".py", ".cpp", ".h", ".hip")):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in src.lower() or fn == "scheme.py" and False, f"{fn} mentions the oracle"
+
+
+def test_keyblob_roundtrip_and_corruption():
+    p = mk.KMS2party.scaled(n=8, N=64)
+    crs, keys = keygen(p, 61)
+    blob = mk.keyblob.dump_party(keys[1])
+    pd, party, secs = mk.keyblob.load(blob)
+    assert party == 1 and pd["N"] == 64 and pd["scheme"] == mk.KMS
+    for name in ("brk", "ksk", "rlk_d", "rlk_f", "pubkey"):
+        assert np.array_equal(secs[name], getattr(keys[1], name)), name
+    assert "lwekey" not in secs                                   # secrets never leave
+    cb = mk.keyblob.dump_crs(p, crs)
+    assert np.array_equal(mk.keyblob.load(cb)[2]["crs"].reshape(crs.shape), crs) and mk.keyblob.load(cb)[1] == -1
+    bad = bytearray(blob); bad[200] ^= 1
+    with pytest.raises(ValueError):
+        mk.keyblob.load(bytes(bad))
+    with pytest.raises(ValueError):
+        mk.keyblob.load(b"garbage" * 20)
+
+
+def test_circuit_levelisation_with_oracle_backend():
+    """the levelised scheduler (batched per level and gate type) against plaintext evaluation; CPU backend = oracle"""
+    from mktfhe_amd import circuit as CI
+    p = mk.CGGIparam.scaled(n=16, N=128)
+    crs, keys = keygen(p, 71)
+    so = oracle_scheme(p, crs, keys)
+    circ = CI.ripple_adder(3)
+    depth, sched = circ.levels()
+    assert max(depth) == 5 and circ.n_inputs == 6          # xor/and, then 2 levels per further bit
+    B = 4
+    rng = np.random.default_rng(72)
+    bits = rng.integers(0, 2, (6, B)).astype(bool)
+    inputs = [np.stack([mk.lwe_encrypt(int(bits[i, j]), keys[0], p, seed=7200 + 10 * i + j) for j in range(B)]) for i in range(6)]
+    calls = []
+    def gate_fn(op, x, y):
+        calls.append((op, x.shape[0]))
+        return so.gate_batch(op, x, y, threads=4)
+    outs = CI.evaluate(circ, inputs, gate_fn, lambda x: (0 - x.astype(np.int64)).astype(np.uint32))
+    want = circ.plain(bits)
+    for o, w in zip(outs, want):
+        assert np.array_equal(mk.lwe_decrypt(o, keys[0], p), w)
+    a = sum(bits[i].astype(int) << i for i in range(3)); b = sum(bits[3 + i].astype(int) << i for i in range(3))
+    got = sum(mk.lwe_decrypt(o, keys[0], p).astype(int) << i for i, o in enumerate(outs))
+    assert np.array_equal(got, a + b)
+    assert len(calls) == sum(len(v) for v in sched.values())   # one batched call per (level, gate type)
+    # NOT is free and composes
+    c2 = CI.Circuit(); x = c2.input(); y = c2.input(); c2.output(c2.NOT(c2.NAND(x, c2.NOT(y))))
+    o2 = CI.evaluate(c2, inputs[:2], gate_fn, lambda v: (0 - v.astype(np.int64)).astype(np.uint32))
+    assert np.array_equal(mk.lwe_decrypt(o2[0], keys[0], p), bits[0] & ~bits[1])
