@@ -32,6 +32,11 @@ WORKLOADS = {
     "kms2_n1024": ("KMS2party_N1024_l2", "KMS k=2, N=1024, l_gsw=2 (BASELINE.json configs[1], synthetic shape)"),
     "kms2party": ("KMS2party", "KMS2party k=2, N=2048, l_gsw=3 (src/tfhe/params.jl:47-53)"),
     "cggi": ("CGGIparam", "CGGIparam single-key, N=1024, l=3 (src/tfhe/params.jl:1-6)"),
+    "lmss": ("Blockparam", "Blockparam LMSS block-binary single-key, N=1024 (src/tfhe/params.jl:8-13)"),
+    "kms2partyblock": ("KMS2partyblock", "KMS2partyblock k=2, N=2048, block-binary keys (src/tfhe/params.jl:87-93)"),
+    "kms4party": ("KMS4party", "KMS4party k=4, N=2048 (src/tfhe/params.jl:55-61)"),
+    "ccs2party": ("CCS2party", "CCS2party k=2, N=1024 (src/tfhe/params.jl:15-21)"),
+    "ccs8party": ("CCS8party", "CCS8party k=8, N=1024 (src/tfhe/params.jl:31-37)"),
 }
 
 
@@ -131,9 +136,10 @@ def main():
         M = p.N // 2
         lg = int(np.log2(M))
         rows = (1 + (p.k - 1) * p.l_lev) if p.scheme in (mk.KMS, mk.KMS_BLOCK) else 1
-        per_iter = (2 * p.l_gsw + 2) * (5 * M * lg + 6 * M) + 4 * p.l_gsw * 8 * M + 2 * 6 * M
+        lg_ = max(p.l_gsw, 1)
+        per_iter = (2 * lg_ + 2) * (5 * M * lg + 6 * M) + 4 * lg_ * 8 * M + 2 * 6 * M
         flop = per_iter * p.n * rows * B
-        if rot_ms > 0:
+        if rot_ms > 0 and p.scheme != mk.CCS:
             line["blindrotate"] = {"f64_gflops": flop * args.steps / (rot_ms * 1e-3) / 1e9, "peak_gflops_nofma": 39300.0,
                                    "rotations_per_step": rows * B}
 
