@@ -392,7 +392,7 @@ int mkt_get_monomial(mkt_ctx *c, int e, double *out_host) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<cplx> dev((size_t)c->M);
     HIPCHK(c, hipMemcpy(dev.data(), c->d_monomial + (size_t)(e - 1) * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
-    const int NT = c->M / 4;                      // device order -> the reference's order
+    const int NT = c->M >> MKT_LOGR;              // device order -> the reference's order
     cplx *o = reinterpret_cast<cplx *>(out_host);
     for (int x = 0; x < c->M; x++) o[x] = dev[(size_t)mktd::dev_pos(x, NT)];
     return MKT_OK;

@@ -158,13 +158,17 @@ __device__ __forceinline__ void fft_inverse(cplx (&z)[NB][1 << LOGR], const cplx
 #ifndef MKT_DEVORDER
 #define MKT_DEVORDER 2
 #endif
+#ifndef MKT_LOGR
+#define MKT_LOGR 2   // points per thread = 2^MKT_LOGR in every transform schedule (and in dev_pos)
+#endif
 __host__ __device__ __forceinline__ int dev_pos(int x, int NT) {
+    constexpr int LR = MKT_LOGR, RM = (1 << LR) - 1;
 #if MKT_DEVORDER == 0
-    (void)NT; return x;                                            // reference order: 64 B per lane
+    (void)NT; return x;                                            // reference order: 16*R B per lane
 #elif MKT_DEVORDER == 1
-    return (x & 3) * NT + (x >> 2);                                // slot-major: 16 B per lane, wave-contiguous
+    return (x & RM) * NT + (x >> LR);                              // slot-major: 16 B per lane, wave-contiguous
 #else
-    return ((x >> 1) & 1) * (2 * NT) + ((x >> 2) << 1) + (x & 1);  // slot pairs: 32 B per lane
+    return ((x & RM) >> 1) * (2 * NT) + ((x >> LR) << 1) + (x & 1); // slot pairs: 32 B per lane
 #endif
 }
 

@@ -10,7 +10,7 @@
 
 namespace mktd {
 
-constexpr int LOGR = 2;  // points per thread = 4
+constexpr int LOGR = MKT_LOGR;  // points per thread (4 by default)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mkt_smem[];
 
@@ -238,14 +238,17 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 // and the transform-domain accumulator stay in registers for all n CMux steps; LDS only stages the
 // in-transform exchanges.  LB = block length (1 for the plain schemes).
 // ------------------------------------------------------------------------------------------------
-template <int LOGM, typename WORD, int LB, int LR, int NB>
 #ifndef MKT_TW_LDS
 #define MKT_TW_LDS 1   // forward twiddle table resident in LDS (A/B: 17.0 vs 20.6 ms at KMS k=2 N=1024)
 #endif
 #ifndef MKT_ROT_MINW
 #define MKT_ROT_MINW 2
 #endif
-__global__ __launch_bounds__((Plan<LOGM, LR>::NT), MKT_ROT_MINW) void blindrotate_k1_kernel(const RotArgs a) {
+// 3 waves/SIMD (<= 168 VGPRs) pays at M >= 1024 with single transforms (44.5 vs 47.7 ms at KMS2party); elsewhere 2
+template <int LOGM, int NB> struct RotOcc { static constexpr int MINW = (LOGM >= 10 && NB == 1 && MKT_LOGR == 2) ? 3 : MKT_ROT_MINW; };
+
+template <int LOGM, typename WORD, int LB, int LR, int NB>
+__global__ __launch_bounds__((Plan<LOGM, LR>::NT), (RotOcc<LOGM, NB>::MINW)) void blindrotate_k1_kernel(const RotArgs a) {
     using P = Plan<LOGM, LR, NB>;   // NB transforms at a time share twiddle loads and barriers
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
@@ -336,6 +339,7 @@ __global__ __launch_bounds__((Plan<LOGM, LR>::NT), MKT_ROT_MINW) void blindrotat
                         if (MKT_ABLATE & 1) { kb.re = 1.5; kb.im = (double)t; ka.re = 2.5; ka.im = (double)e; } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
                         tacc[q][0][e] = cadd(tacc[q][0][e], cmul(z[h2][e], kb));
                         tacc[q][1][e] = cadd(tacc[q][1][e], cmul(z[h2][e], ka));
+                        if (RotOcc<LOGM, NB>::MINW >= 3) __builtin_amdgcn_sched_barrier(0);   // keep the key-row live ranges short at 3 waves/SIMD
                     }
                 }
         }
@@ -914,13 +918,13 @@ static hipError_t launch_rot_lb(const RotArgs &a, size_t nrot, hipStream_t s) {
     switch (a.blk_len) {
     case 1:
         switch (variant) {
-        case 21: return launch_rot_one<LM, WORD, 1, 2, 1>(a, nrot, s);
-        case 22: return launch_rot_one<LM, WORD, 1, 2, 2>(a, nrot, s);
+        case 21: return launch_rot_one<LM, WORD, 1, LOGR, 1>(a, nrot, s);
+        case 22: return launch_rot_one<LM, WORD, 1, LOGR, 2>(a, nrot, s);
         default: return hipErrorInvalidValue;
         }
-    case 2: return launch_rot_one<LM, WORD, 2, 2, 2>(a, nrot, s);
-    case 3: return launch_rot_one<LM, WORD, 3, 2, 2>(a, nrot, s);
-    case 4: return launch_rot_one<LM, WORD, 4, 2, 2>(a, nrot, s);
+    case 2: return launch_rot_one<LM, WORD, 2, LOGR, 2>(a, nrot, s);
+    case 3: return launch_rot_one<LM, WORD, 3, LOGR, 2>(a, nrot, s);
+    case 4: return launch_rot_one<LM, WORD, 4, LOGR, 2>(a, nrot, s);
     default: return hipErrorInvalidValue;
     }
 }
