@@ -21,7 +21,8 @@ int validate_params(const mkt_params &p, std::string &why) {
     if (p.W != 32 && p.W != 64) return bad("W must be 32 or 64");
     if (p.k < 1 || p.k > 64) return bad("k out of range");
     if (p.n < 1) return bad("n must be positive");
-    if (p.f < 1 || p.logD < 1 || p.f * p.logD > 32 || p.logD > 8) return bad("bad key-switch gadget");
+    if (p.f < 1 || p.logD < 1 || p.f * p.logD > 32 || p.logD > 5) return bad("bad key-switch gadget (f*logD <= 32, logD <= 5)");
+    if (p.n + 1 > 16384) return bad("n too large");
     auto gadget = [&](int l, int logB) { return l >= 1 && logB >= 1 && logB <= 31 && l * logB <= p.W && l <= 32; };
     if (p.scheme == MKT_CCS) { if (!gadget(p.l_uni, p.logB_uni)) return bad("bad uni gadget"); }
     else if (!gadget(p.l_gsw, p.logB_gsw)) return bad("bad gsw gadget");

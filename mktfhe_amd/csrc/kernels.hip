@@ -704,11 +704,14 @@ __global__ void ks_init_kernel(const KsArgs a, size_t B) {
 // reads another lane's data, so there are no barriers).  3 row loads per (j,t) instead of 0.75*G is what matters:
 // the gather is bound by L2 / Infinity-Cache bandwidth.  Partial sums over slabs meet in u32 atomics; wrap-around
 // addition is order independent, so the result is deterministic.
-constexpr int KS_LANES = 64, KS_CHUNK_WORDS = 4 * KS_LANES, KS_STAGES = 2, KS_MAXROWS = 5;
+constexpr int KS_LANES = 64, KS_CHUNK_WORDS = 4 * KS_LANES, KS_STAGES = 2;
 
 template <typename WORD, int G>
 __global__ __launch_bounds__(KS_LANES) void keyswitch_mg_kernel(const KsArgs a, int B, int ngroups, int jslab) {
-    __shared__ uint4 tab[KS_STAGES][KS_MAXROWS][KS_LANES];
+    // digit table: [stage][1 + drows (+ drows negated rows for balanced digits)][lane]
+    uint4 *tabp = reinterpret_cast<uint4 *>(mkt_smem);
+    const int trows = 1 + a.drows * (a.balanced ? 2 : 1);
+#define tab(s, r, l) tabp[((s) * trows + (r)) * KS_LANES + (l)]
     const int lane = threadIdx.x;
     const int gg = (int)(blockIdx.x % (unsigned)ngroups), slab = (int)(blockIdx.x / (unsigned)ngroups);
     const int N = a.N, n = a.n, n1p = a.n1p, f = a.f, logD = a.logD;
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(KS_LANES) void keyswitch_mg_kernel(const KsArgs a, 
 #pragma unroll
     for (int g = 0; g < G; g++) sum[g] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int s = 0; s < KS_STAGES; s++) tab[s][0][lane] = make_uint4(0, 0, 0, 0);   // digit 0 adds nothing
+    for (int s = 0; s < KS_STAGES; s++) tab(s, 0, lane) = make_uint4(0, 0, 0, 0);   // digit 0 adds nothing
 
     for (int c = c_begin; c < c_end; c++) {
         const uint32_t *ksk = a.mk ? a.ksk + (size_t)c * a.ksk_party_stride : a.ksk + (size_t)c * comp_words;
@@ -755,19 +758,20 @@ __global__ __launch_bounds__(KS_LANES) void keyswitch_mg_kernel(const KsArgs a, 
                 for (int d = 1; d <= drows; d++) {
                     uint4 r = make_uint4(0, 0, 0, 0);
                     if (active) r = *reinterpret_cast<const uint4 *>(rowj + ((size_t)(d - 1) * f + td) * n1p);
-                    tab[st][d][lane] = r;
-                    if (a.balanced) tab[st][drows + d][lane] = make_uint4(0u - r.x, 0u - r.y, 0u - r.z, 0u - r.w);
+                    tab(st, d, lane) = r;
+                    if (a.balanced) tab(st, drows + d, lane) = make_uint4(0u - r.x, 0u - r.y, 0u - r.z, 0u - r.w);
                 }
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     int idx = (int)((tt[g] >> shift) & Dm);
                     if (a.balanced) { idx -= half; if (idx < 0) idx = drows - idx; }   // -1 -> drows+1, -2 -> drows+2
-                    const uint4 v = tab[st][idx][lane];
+                    const uint4 v = tab(st, idx, lane);
                     sum[g].x += v.x; sum[g].y += v.y; sum[g].z += v.z; sum[g].w += v.w;
                 }
             }
         }
     }
+#undef tab
     if (!active) return;
     const int blk = a.mk ? c_begin : 0;
 #pragma unroll
@@ -983,10 +987,10 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     const int jslab = (a.N + slabs - 1) / slabs;
     slabs = (a.N + jslab - 1) / jslab;
     const dim3 grid((unsigned)(ngroups * slabs), (unsigned)parties, (unsigned)((a.n1p + KS_CHUNK_WORDS - 1) / KS_CHUNK_WORDS));
-    if ((1 << (a.logD - 1)) > 2 && a.balanced) return hipErrorInvalidValue;   // digit table holds |d| <= 2
-    if (a.drows > (a.balanced ? 2 : 4)) return hipErrorInvalidValue;
+    const size_t ks_lds = (size_t)KS_STAGES * (1 + a.drows * (a.balanced ? 2 : 1)) * KS_LANES * sizeof(uint4);
+    if (ks_lds > 64 * 1024) return hipErrorInvalidValue;   // logD <= 5
     const size_t total = B * (size_t)(parties * a.n + 1);
-#define MKT_KS_LAUNCH(WT, GV) hipLaunchKernelGGL((keyswitch_mg_kernel<WT, GV>), grid, dim3(KS_LANES), 0, s, a, (int)B, ngroups, jslab)
+#define MKT_KS_LAUNCH(WT, GV) hipLaunchKernelGGL((keyswitch_mg_kernel<WT, GV>), grid, dim3(KS_LANES), ks_lds, s, a, (int)B, ngroups, jslab)
     if (W == 64) {
         hipLaunchKernelGGL(ks_init_kernel<uint64_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
         if (G == 8) MKT_KS_LAUNCH(uint64_t, 8); else if (G == 32) MKT_KS_LAUNCH(uint64_t, 32); else MKT_KS_LAUNCH(uint64_t, 16);

@@ -95,6 +95,10 @@ SMALL = [
     mk.CCS2party.scaled(n=12, N=256),
     mk.CCS4party.scaled(n=6, N=256),
     mk.CCS8party.scaled(n=4, N=512),
+    mk.CGGIparam.scaled(n=20, N=256, f=5, logD=3),          # other key-switch gadgets
+    mk.Blockparam.scaled(n=30, N=256, blk_d=10, f=4, logD=3),
+    mk.KMS8party.scaled(n=4, N=256),                        # larger party counts / gadget shapes (params.jl:63-85)
+    mk.CCS16party.scaled(n=2, N=256),
 ]
 
 
