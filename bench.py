@@ -58,9 +58,14 @@ def main():
     import torch.distributed as dist
     from mktfhe_amd import distributed as D
     rank, world, local = D.env()
+    # MKT_BENCH_BACKEND=gloo + MKT_BENCH_SHARE_GPU=1: smoke-test the multi-process path on a 1-GPU box
+    backend = os.environ.get("MKT_BENCH_BACKEND", "nccl")
+    if os.environ.get("MKT_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    D.init_process_group("nccl", device=dev)     # "nccl" is RCCL on ROCm; rendezvous + timing barrier only
+    D.init_process_group(backend, device=dev)     # "nccl" is RCCL on ROCm; rendezvous + timing barrier only
+    red_dev = dev if backend == "nccl" else "cpu"
 
     pname, desc = WORKLOADS[args.workload]
     p = getattr(mk, pname)
@@ -109,7 +114,7 @@ def main():
     ks_ms, ks_n = sch.kernel_ms(2)
     p2_ms, p2_n = sch.kernel_ms(4)
     sch.enable_timing(False)
-    elapsed = D.max_over_ranks(elapsed, device=dev)
+    elapsed = D.max_over_ranks(elapsed, device=red_dev)
 
     # correctness of what was timed: decrypt a sample, and (rank 0) compare a sub-batch with the oracle
     res = out.cpu().numpy().view(np.uint32)

@@ -917,7 +917,7 @@ static hipError_t launch_rot_one(const RotArgs &a, size_t nrot, hipStream_t s) {
 template <int LM, typename WORD>
 static hipError_t launch_rot_lb(const RotArgs &a, size_t nrot, hipStream_t s) {
     int variant = a.variant;
-    if (variant == 0) variant = LM <= 9 ? 22 : 21;   // pairs of transforms up to M = 512, single transforms above (LDS budget)
+    if (variant == 0) variant = (LM <= 9 || a.blk_len > 1) ? 22 : 21;   // pairs of transforms up to M = 512 and for the block schemes, single transforms above (measured)
     if ((2 * a.l) % (variant % 10) != 0) variant = (variant / 10) * 10 + 1;
     switch (a.blk_len) {
     case 1:
@@ -926,9 +926,9 @@ static hipError_t launch_rot_lb(const RotArgs &a, size_t nrot, hipStream_t s) {
         case 22: return launch_rot_one<LM, WORD, 1, LOGR, 2>(a, nrot, s);
         default: return hipErrorInvalidValue;
         }
-    case 2: return launch_rot_one<LM, WORD, 2, LOGR, 2>(a, nrot, s);
-    case 3: return launch_rot_one<LM, WORD, 3, LOGR, 2>(a, nrot, s);
-    case 4: return launch_rot_one<LM, WORD, 4, LOGR, 2>(a, nrot, s);
+    case 2: return variant % 10 == 1 ? launch_rot_one<LM, WORD, 2, LOGR, 1>(a, nrot, s) : launch_rot_one<LM, WORD, 2, LOGR, 2>(a, nrot, s);
+    case 3: return variant % 10 == 1 ? launch_rot_one<LM, WORD, 3, LOGR, 1>(a, nrot, s) : launch_rot_one<LM, WORD, 3, LOGR, 2>(a, nrot, s);
+    case 4: return variant % 10 == 1 ? launch_rot_one<LM, WORD, 4, LOGR, 1>(a, nrot, s) : launch_rot_one<LM, WORD, 4, LOGR, 2>(a, nrot, s);
     default: return hipErrorInvalidValue;
     }
 }
