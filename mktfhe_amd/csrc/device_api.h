@@ -91,6 +91,7 @@ hipError_t launch_negate(uint32_t *x, size_t words, hipStream_t s);
 hipError_t launch_modswitch(const uint32_t *lwe, uint32_t *atilde, uint32_t *btilde, int len, int logN, size_t B, hipStream_t s);
 hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int logN, int kacc, void *acc, size_t B, hipStream_t s);
 hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s);
+hipError_t launch_blindrotate_kr(int logM, int W, int kr, const RotArgs &a, size_t nrot, hipStream_t s);
 hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hipStream_t s);
 hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, hipStream_t s);
 hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s);

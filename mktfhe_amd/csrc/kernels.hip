@@ -408,6 +408,87 @@ __global__ __launch_bounds__((Plan<LOGM, LR>::NT), (RotOcc<LOGM, NB>::MINW)) voi
 }
 
 // ------------------------------------------------------------------------------------------------
+// CGGI blind rotation with RLWE length KR > 1 (bootstrapping.jl:32-76 with k = KR): the general-k form of the
+// kernel above for the plain single-key scheme; no shipped parameter set uses it (params.jl:1-13 have k = 1),
+// so it is kept simple: one transform at a time, KR+1 accumulators in registers.
+// brk layout [n][(KR+1)*l rows][KR+1 polys][M] (device point order), acc [rot][KR+1][N].
+// ------------------------------------------------------------------------------------------------
+template <int LOGM, typename WORD, int KR>
+__global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(const RotArgs a) {
+    using P = Plan<LOGM, LOGR>;
+    constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, NP = KR + 1;
+    cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
+    cplx *psi_l = lds + P::LDS_CPLX;
+    const int t = threadIdx.x;
+    for (int i = t; i < M; i += NT) psi_l[i] = a.tw.psi[i];
+    __syncthreads();
+    const size_t rot = blockIdx.x;
+    const uint32_t *at_src = a.lwe + rot * (size_t)a.lwe_stride;
+    const Gadget<WORD> gd(a.l, a.logB);
+    const int l = a.l;
+    int dp[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) dp[e] = dev_pos(t * R + e, NT);
+    WORD *accg = reinterpret_cast<WORD *>(a.acc_io) + rot * (size_t)NP * N;
+    WORD acc[NP][R][2];
+#pragma unroll
+    for (int c = 0; c < NP; c++)
+#pragma unroll
+        for (int e = 0; e < R; e++) { acc[c][e][0] = accg[c * N + e * NT + t]; acc[c][e][1] = accg[c * N + M + e * NT + t]; }
+    const int msbit = 32 - a.logN - 1;
+    for (int idx = 0; idx < a.n; idx++) {
+        const uint32_t v0 = at_src[idx];
+        const uint32_t at = a.pre_switched ? v0 : divbits<uint32_t>(v0, msbit);
+        if (at == 0) continue;                                           // :48
+        cplx tacc[NP][R];
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int e = 0; e < R; e++) { tacc[q][e].re = 0.0; tacc[q][e].im = 0.0; }
+        const cplx *brk = a.brk + (size_t)idx * NP * l * NP * M;
+#pragma unroll
+        for (int c = 0; c < NP; c++) {                                   // b digits, then a_0, a_1 ... (:63-68)
+            WORD tp[R][2];
+#pragma unroll
+            for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(acc[c][e][0]); tp[e][1] = gd.prep(acc[c][e][1]); }
+            for (int j = 0; j < l; j++) {
+                cplx z[R];
+#pragma unroll
+                for (int e = 0; e < R; e++) {
+                    const int d0 = gd.digit(tp[e][0], j), d1 = gd.digit(tp[e][1], j);
+                    cplx v; v.re = (double)d0; v.im = (double)(-d1);
+                    z[e] = cmul(v, a.tw.roots[e * NT + t]);
+                }
+                fft_forward1<LOGM>(z, psi_l, lds, t);
+                const cplx *row = brk + (size_t)(c * l + j) * NP * M;
+#pragma unroll
+                for (int q = 0; q < NP; q++)
+#pragma unroll
+                    for (int e = 0; e < R; e++) tacc[q][e] = cadd(tacc[q][e], cmul(z[e], row[(size_t)q * M + dp[e]]));
+            }
+        }
+        const cplx *mono = a.monomial + (size_t)(at - 1) * M;
+#pragma unroll
+        for (int q = 0; q < NP; q++) {                                   // :71-73
+            cplx s[R];
+#pragma unroll
+            for (int e = 0; e < R; e++) s[e] = cmul(mono[dp[e]], tacc[q][e]);
+            fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(s), psi_l, lds, t);
+#pragma unroll
+            for (int e = 0; e < R; e++) {
+                const cplx v = cmul(s[e], a.tw.rootsinv[e * NT + t]);
+                acc[q][e][0] = (WORD)(acc[q][e][0] + native<WORD>(v.re));
+                acc[q][e][1] = (WORD)(acc[q][e][1] + native<WORD>(-v.im));
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NP; c++)
+#pragma unroll
+        for (int e = 0; e < R; e++) { accg[c * N + e * NT + t] = acc[c][e][0]; accg[c * N + M + e * NT + t] = acc[c][e][1]; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // KMS phase 2 (bootstrapping.jl:448-558): k sequential merges, one workgroup per ciphertext.
 // < 1 % of the bootstrap's transforms; polynomials stream through a per-ciphertext scratch area,
 // every thread only ever touches its own points / coefficients, so no inter-thread ordering is needed
@@ -938,6 +1019,26 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
     MKT_DISPATCH_LOGM(logM, {
         if (W == 64) return launch_rot_lb<LM, uint64_t>(a, nrot, s);
         return launch_rot_lb<LM, uint32_t>(a, nrot, s);
+    });
+    return hipSuccess;
+}
+
+template <int LM, typename WORD, int KR>
+static hipError_t launch_kr_one(const RotArgs &a, size_t nrot, hipStream_t s) {
+    using P = Plan<LM, LOGR>;
+    constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
+    hipError_t e = set_lds(blindrotate_kr_kernel<LM, WORD, KR>, LB);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((blindrotate_kr_kernel<LM, WORD, KR>), dim3((unsigned)nrot), dim3(P::NT), LB, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_blindrotate_kr(int logM, int W, int kr, const RotArgs &a, size_t nrot, hipStream_t s) {
+    if (!nrot) return hipSuccess;
+    if (kr < 2 || kr > 3) return hipErrorInvalidValue;
+    MKT_DISPATCH_LOGM(logM, {
+        if (W == 64) return kr == 2 ? launch_kr_one<LM, uint64_t, 2>(a, nrot, s) : launch_kr_one<LM, uint64_t, 3>(a, nrot, s);
+        return kr == 2 ? launch_kr_one<LM, uint32_t, 2>(a, nrot, s) : launch_kr_one<LM, uint32_t, 3>(a, nrot, s);
     });
     return hipSuccess;
 }

@@ -99,6 +99,8 @@ SMALL = [
     mk.Blockparam.scaled(n=30, N=256, blk_d=10, f=4, logD=3),
     mk.KMS8party.scaled(n=4, N=256),                        # larger party counts / gadget shapes (params.jl:63-85)
     mk.CCS16party.scaled(n=2, N=256),
+    mk.CGGIparam.scaled(n=16, N=256, k=2),                  # RLWE length > 1 (TFHEparams_bin.k, scheme.jl:6-20)
+    mk.CGGIparam.scaled(n=12, N=512, k=3, l_gsw=2, logB_gsw=10),
 ]
 
 
