@@ -208,12 +208,13 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
             HIPCHK(c, mktd::launch_blindrotate_kr(c->logM, p.W, p.k, a, B, c->stream));
             return MKT_OK;
         }
+        a.ngates = B;
         HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, p.W, a, B, c->stream));
         return MKT_OK;
     }
     {
         mktd::RotArgs a = rot_args(c, lwe, stride, pre);
-        a.init_mode = 1; a.out_mode = 1; a.tout = lev; a.tout_natural = 0;
+        a.init_mode = 1; a.out_mode = 1; a.tout = lev; a.tout_natural = 0; a.ngates = B;
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, p.W, a, B * (size_t)c->rtot, c->stream));
     }
@@ -535,7 +536,7 @@ int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, siz
     Staged sa{c}, sl{c};
     if ((r = sa.in(atilde, B * alen * 4, mem, true)) || (r = sl.in(levkey, B * lb, mem, false))) return r;
     mktd::RotArgs a = rot_args(c, (const uint32_t *)sa.dev, (int)alen, 1);
-    a.init_mode = 1; a.out_mode = 1; a.tout = (cplx *)sl.dev; a.tout_natural = 1;
+    a.init_mode = 1; a.out_mode = 1; a.tout = (cplx *)sl.dev; a.tout_natural = 1; a.ngates = B;
     { Timer tm(c, 1); HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, c->p.W, a, B * (size_t)c->rtot, c->stream)); }
     return sl.out(levkey);
 }

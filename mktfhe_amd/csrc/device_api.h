@@ -25,6 +25,7 @@ struct RotArgs {
     int blk_len;              // 1, or the block length of LMSS / KMS_block
     int blk_accum;            // block schemes: tacc2 += monomial*tacc form (bootstrapping.jl:157,:648)
     int rows_per_gate;        // rotations per ciphertext
+    size_t ngates;            // ciphertexts in this launch (grid = ngates * rows_per_gate)
     const int *slot_party;    // [rows_per_gate]
     const int *slot_row;      // [rows_per_gate]
     int init_mode;            // 0: load acc from acc_io; 1: trivial RLEV row b = 2^(W-(row+1)*logB_lev)

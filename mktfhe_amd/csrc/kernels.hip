@@ -264,9 +264,11 @@ __global__ __launch_bounds__((Plan<LOGM, LR>::NT), (RotOcc<LOGM, NB>::MINW)) voi
 #define MKT_PSI_F a.tw.psi
 #define MKT_INV(NBV, ZZ) fft_inverse<LOGM, LR, NBV, false>(ZZ, a.tw.psiinv, lds, t)
 #endif
-    const size_t rot = blockIdx.x;
-    const size_t gate = rot / (size_t)a.rows_per_gate;
-    const int slot = (int)(rot % (size_t)a.rows_per_gate);
+    // workgroups are dealt slot-major (all ciphertexts' rotations of one party/row are adjacent), so the workgroups
+    // resident at any time stream the SAME party's key rows through L2; results are stored ciphertext-major
+    const size_t gate = blockIdx.x % (size_t)a.ngates;
+    const int slot = (int)(blockIdx.x / (size_t)a.ngates);
+    const size_t rot = gate * (size_t)a.rows_per_gate + slot;
     const int party = a.slot_party[slot], row = a.slot_row[slot];
     const uint32_t *at_src = a.lwe + gate * (size_t)a.lwe_stride + (size_t)party * a.n;
     const cplx *brk = a.brk + (size_t)party * a.brk_party_stride;
