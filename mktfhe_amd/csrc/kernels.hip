@@ -38,10 +38,11 @@ __device__ __forceinline__ void fft_inverse1(cplx (&z)[1 << LOGR], const cplx *_
 #define MKT_FFT_CONTIG_STORE 1
 #endif
 
-template <int LOGM, typename WORD>
+// NBT polynomials per workgroup iteration share the twiddle reads and the barriers (2 pays up to M = 512)
+template <int LOGM, typename WORD, int NBT>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(TwPtrs tw, const WORD *__restrict__ p,
                                                                             cplx *__restrict__ out, size_t B, int dev_order) {
-    using P = Plan<LOGM, LOGR>;
+    using P = Plan<LOGM, LOGR, NBT>;
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
@@ -56,39 +57,45 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
     cplx rt[R];
 #pragma unroll
     for (int e = 0; e < R; e++) rt[e] = tw.roots[e * NT + t];
-    WORD c0[R], c1[R];
-    size_t b = blockIdx.x;
-    if (b < B) {
+    // software pipeline: the next polynomials' coefficients are in flight while these are transformed
+    WORD c0[NBT][R], c1[NBT][R];
+    const size_t groups = (B + NBT - 1) / NBT;
+    size_t g = blockIdx.x;
+    auto load = [&](size_t gi) {
 #pragma unroll
-        for (int e = 0; e < R; e++) { c0[e] = p[b * N + e * NT + t]; c1[e] = p[b * N + M + e * NT + t]; }
-    }
-    for (; b < B; b += gridDim.x) {
-        cplx z[R];
+        for (int u = 0; u < NBT; u++) {
+            const size_t b = gi * NBT + u < B ? gi * NBT + u : B - 1;
 #pragma unroll
-        for (int e = 0; e < R; e++) {
-            cplx v;
-            v.re = word_to_f64<WORD>(c0[e]);
-            v.im = word_to_f64<WORD>((WORD)((WORD)0 - c1[e]));   // subtraction in the integer type (fft.jl:60)
-            z[e] = cmul(v, rt[e]);
+            for (int e = 0; e < R; e++) { c0[u][e] = p[b * N + e * NT + t]; c1[u][e] = p[b * N + M + e * NT + t]; }
         }
-        const size_t nb = b + gridDim.x;
-        if (nb < B) {
+    };
+    if (g < groups) load(g);
+    for (; g < groups; g += gridDim.x) {
+        cplx z[NBT][R];
 #pragma unroll
-            for (int e = 0; e < R; e++) { c0[e] = p[nb * N + e * NT + t]; c1[e] = p[nb * N + M + e * NT + t]; }
-        }
-        if (!(MKT_ABLATE & 16)) fft_forward1<LOGM>(z, psi_f, lds, t);
-        cplx *o = out + b * M;
-        if (dev_order) {          // resident key tables: device point order
+        for (int u = 0; u < NBT; u++)
 #pragma unroll
-            for (int e = 0; e < R; e++) o[dev_pos(t * R + e, NT)] = z[e];
-        } else if (MKT_FFT_CONTIG_STORE && P::NPASS > 1) {
-            exchange<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][R]>(z), lds + ((P::NPASS - 1) & 1) * P::BUF, t, 0, P::lo(0));
+            for (int e = 0; e < R; e++) {
+                cplx v;
+                v.re = word_to_f64<WORD>(c0[u][e]);
+                v.im = word_to_f64<WORD>((WORD)((WORD)0 - c1[u][e]));   // subtraction in the integer type (fft.jl:60)
+                z[u][e] = cmul(v, rt[e]);
+            }
+        if (g + gridDim.x < groups) load(g + gridDim.x);
+        if (!(MKT_ABLATE & 16)) fft_forward<LOGM, LOGR, NBT>(z, psi_f, lds, t);
+        const bool contig = !dev_order && MKT_FFT_CONTIG_STORE && P::NPASS > 1;
+        if (contig) {
+            exchange<LOGM, LOGR, NBT>(z, lds + ((P::NPASS - 1) & 1) * P::BUF, t, 0, P::lo(0));
             __syncthreads();      // the next transform's first exchange reuses this buffer
+        }
 #pragma unroll
-            for (int e = 0; e < R; e++) o[e * NT + t] = z[e];
-        } else {                  // the reference's TransPoly order
+        for (int u = 0; u < NBT; u++) {
+            const size_t b = g * NBT + u;
+            if (b >= B) break;
+            cplx *o = out + b * M;
 #pragma unroll
-            for (int e = 0; e < R; e++) o[t * R + e] = z[e];
+            for (int e = 0; e < R; e++)   // device point order for resident tables; else the reference's TransPoly order
+                o[dev_order ? dev_pos(t * R + e, NT) : (contig ? e * NT + t : t * R + e)] = z[u][e];
         }
     }
 }
@@ -902,24 +909,33 @@ bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
     default: return hipErrorInvalidValue;            \
     }
 
+template <int LM, typename WORD, int NBT>
+static hipError_t launch_fwd_one(TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, int gmax, hipStream_t s) {
+    using P = Plan<LM, LOGR, NBT>;
+    constexpr size_t LB = P::LDS_BYTES + (MKT_FFT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
+    const size_t groups = (B + NBT - 1) / NBT;
+    const int grid = (int)(groups < (size_t)gmax ? groups : (size_t)gmax);
+    hipError_t e = set_lds(transform_fwd_kernel<LM, WORD, NBT>, LB);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((transform_fwd_kernel<LM, WORD, NBT>), dim3(grid), dim3(P::NT), LB, s, tw, (const WORD *)p, t, B, dev_order);
+    return hipGetLastError();
+}
+
 hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, hipStream_t s) {
     if (B == 0) return hipSuccess;
-    int gmax = 5120;   // swept on MI355X (tools/fft_ab.sh)
+    // swept on MI355X (tools/fft_nb.sh): two polynomials per iteration and a larger grid pay up to M = 512
+    int gmax = logM <= 9 ? 10240 : 5120, nbt = logM <= 9 ? 2 : 1;
     if (const char *e = getenv("MKT_FFT_GRID")) { if (atoi(e) > 0) gmax = atoi(e); }
-    const int grid = (int)(B < (size_t)gmax ? B : (size_t)gmax);
+    if (const char *e = getenv("MKT_FFT_NB")) nbt = atoi(e);
     MKT_DISPATCH_LOGM(logM, {
-        using P = Plan<LM, LOGR>;
-        if (W == 64) {
-            constexpr size_t LB = P::LDS_BYTES + (MKT_FFT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
-            hipError_t e = set_lds(transform_fwd_kernel<LM, uint64_t>, LB); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), LB, s, tw, (const uint64_t *)p, t, B, dev_order);
-        } else {
-            constexpr size_t LB = P::LDS_BYTES + (MKT_FFT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
-            hipError_t e = set_lds(transform_fwd_kernel<LM, uint32_t>, LB); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((transform_fwd_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), LB, s, tw, (const uint32_t *)p, t, B, dev_order);
+        if (nbt == 2 && LM <= 10) {
+            if (W == 64) return launch_fwd_one<LM, uint64_t, 2>(tw, p, t, B, dev_order, gmax, s);
+            return launch_fwd_one<LM, uint32_t, 2>(tw, p, t, B, dev_order, gmax, s);
         }
+        if (W == 64) return launch_fwd_one<LM, uint64_t, 1>(tw, p, t, B, dev_order, gmax, s);
+        return launch_fwd_one<LM, uint32_t, 1>(tw, p, t, B, dev_order, gmax, s);
     });
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, int to_device, hipStream_t s) {
