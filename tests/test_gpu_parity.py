@@ -317,3 +317,15 @@ def test_circuit_on_device(require_gpu):
     a = sum(bits[i].astype(int) << i for i in range(4)); b = sum(bits[4 + i].astype(int) << i for i in range(4))
     assert np.array_equal(got, a + b)
     sg.close()
+
+
+def test_c_example_through_the_abi(require_gpu, tmp_path):
+    """examples/kms_nand.c: a plain C caller (gcc, no Python) of include/mktfhe.h"""
+    import os, subprocess
+    from helpers import ROOT
+    exe = str(tmp_path / "kms_nand")
+    lib = os.path.join(ROOT, "mktfhe_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "kms_nand.c"),
+                           "-o", exe, "-L" + lib, "-lmktfhe_hip", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe, "24", "256"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
