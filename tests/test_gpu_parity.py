@@ -329,3 +329,30 @@ def test_c_example_through_the_abi(require_gpu, tmp_path):
                            "-o", exe, "-L" + lib, "-lmktfhe_hip", "-Wl,-rpath," + lib])
     out = subprocess.run([exe, "24", "256"], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=24, N=256), mk.KMS2party.scaled(n=12, N=256), mk.Blockparam.scaled(n=30, N=256, blk_d=10),
+                               mk.CCS2party.scaled(n=10, N=256)], ids=lambda p: p.name)
+def test_blindrotate_special_exponents(require_gpu, p):
+    """atilde = 0 is skipped (bootstrapping.jl:48), atilde = 2N multiplies by the zero table entry (scheme.jl:125),
+    atilde = N is X^N - 1 = -2; whole blocks of zeros for the block schemes; btilde at 0 / N / N+1 / 2N"""
+    crs, keys = keygen(p, 4)
+    so = oracle_scheme(p, crs, keys)
+    sg = gpu_scheme(p, crs, keys)
+    N, nat = p.N, p.lwe_len - 1
+    rng = np.random.default_rng(5)
+    rows = []
+    for pattern in range(6):
+        at = rng.integers(0, 2 * N + 1, nat).astype(np.uint32)
+        if pattern == 0: at[:] = 0
+        if pattern == 1: at[::2] = 0; at[1::4] = 2 * N
+        if pattern == 2: at[:] = 2 * N
+        if pattern == 3: at[: nat // 2] = 0; at[nat // 2:] = N
+        if pattern == 4: at[:6] = [0, 0, 0, 1, 0, 2 * N][: min(6, nat)]
+        rows.append(at)
+    at = np.stack(rows)
+    acc0 = np.stack([so.testvector(bt) for bt in (0, 1, N, N + 1, 2 * N, 2 * N - 1)])
+    ref = np.stack([so.blindrotate(at[j], acc0[j]) for j in range(6)])
+    got = sg.blindrotate_(at, acc0.astype(p.ring_dtype).copy())
+    assert np.array_equal(got.astype(np.uint64), ref)
+    sg.close()
