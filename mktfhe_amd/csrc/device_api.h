@@ -35,6 +35,7 @@ struct RotArgs {
     cplx *tout;               // [rot][2][M]
     int tout_natural;         // 1: reference point order (API output); 0: device order (feeds phase 2)
     int variant;              // tuning: 10*LOGR + transforms per group (0 = default)
+    int stagger;              // start-up delay of alternate workgroup groups, in units of 512 cycles (0 = off)
 };
 
 // KMS phase 2 (bootstrapping.jl:448-558), one workgroup per ciphertext.

@@ -260,6 +260,12 @@ __global__ __launch_bounds__((Plan<LOGM, LR>::NT), (RotOcc<LOGM, NB>::MINW)) voi
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
+    // co-resident workgroups run the same loop in near lock-step and then fight for the VALU and the LDS at the same
+    // moments; delaying every other group of 256 workgroups (= every other workgroup of a CU under round-robin
+    // dispatch; speed only, never correctness) de-phases them
+    if (a.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+        for (int s = 0; s < a.stagger; s++) __builtin_amdgcn_s_sleep(8);
+    }
 #if MKT_TW_LDS
     // the forward twiddle table stays resident in LDS behind the staging buffers; the inverse uses its conjugate
     cplx *psi_l = lds + P::LDS_CPLX;
