@@ -68,8 +68,13 @@ __device__ __forceinline__ int lds_pos(int idx) {
     return idx ^ ((idx >> 3) & 15);   // 8 points per thread
 }
 
+// ---- point re-distribution between passes -------------------------------------------------------------------
+// Through LDS (any pattern): two staging buffers, the exchange after pass p uses buffer p & 1, one s_barrier per
+// exchange.  A wave can only reach its NEXT write into a buffer after the barrier of an exchange in between, which
+// every wave passes after finishing its reads from that buffer; where two consecutive LDS exchanges (the last of one
+// transform, the first of the next) would use the same buffer, the transform starts with a guard barrier (Route).
 template <int LOGM, int LOGR, int NB>
-__device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *buf, int t, int lo_from, int lo_to) {
+__device__ __forceinline__ void exchange_lds(cplx (&z)[NB][1 << LOGR], cplx *buf, int t, int lo_from, int lo_to) {
     constexpr int R = 1 << LOGR, M = 1 << LOGM;
     if (MKT_ABLATE & 4) return;
 #pragma unroll
@@ -83,74 +88,203 @@ __device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *buf, in
         for (int e = 0; e < R; e++) z[b][e] = buf[b * M + lds_pos<LOGR>(pt_index<LOGR>(t, e, lo_to))];
 }
 
+// Inside a wave (LOGR == 2): when the thread bits that trade places with the slot bits are lane bits, the exchange
+// is a 4x4 transpose among 4 lanes (2 rounds of pairwise swaps with lane ^ d) or, for the odd last window, one
+// pairwise swap -- done with DPP / ds_swizzle register moves: no LDS store traffic (the busiest resource of the
+// blind rotation: ~25 % of a wave's time sat in ds_write + wait) and no barrier.
+struct LaneX { int lane; int m4; };
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ LaneX make_lanex() {
+    LaneX x; x.lane = (int)(threadIdx.x & 63);
+    x.m4 = dpp_mov<0x124>(x.lane) == (x.lane ^ 4);   // does row_ror:4 deliver lane^4 to this lane? (else row_ror:12 does)
+    return x;
+}
+template <int D>
+__device__ __forceinline__ int xor_lane(int v, const LaneX &lx) {
+    if constexpr (D == 1) return dpp_mov<0xB1>(v);                 // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return dpp_mov<0x4E>(v);            // quad_perm [2,3,0,1]
+    else if constexpr (D == 4) { const int a = dpp_mov<0x124>(v), b = dpp_mov<0x12C>(v); return lx.m4 ? a : b; }   // row_ror:4 / :12
+    else if constexpr (D == 8) return dpp_mov<0x128>(v);           // row_ror:8
+    else if constexpr (D == 16) return __builtin_amdgcn_ds_swizzle(v, (16 << 10) | 0x1F);   // BitMode xor 16
+    else return __shfl_xor(v, 32);
+}
+template <int D>
+__device__ __forceinline__ void swap_pair(cplx &x0, cplx &x1, bool b, const LaneX &lx) {
+    // lane with b = 0 gives x1 and receives the partner's x0 into x1; lane with b = 1 gives x0, receives into x0
+    int a0[4], a1[4];
+    __builtin_memcpy(a0, &x0, 16); __builtin_memcpy(a1, &x1, 16);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int snd = b ? a0[w] : a1[w];
+        const int rcv = xor_lane<D>(snd, lx);
+        a0[w] = b ? rcv : a0[w];
+        a1[w] = b ? a1[w] : rcv;
+    }
+    __builtin_memcpy(&x0, a0, 16); __builtin_memcpy(&x1, a1, 16);
+}
+// full transpose between thread bits [LO, LO+2) (lane bits) and the two slot bits
+template <int LO, int NB>
+__device__ __forceinline__ void exchange_lane_full(cplx (&z)[NB][4], const LaneX &lx) {
+    const bool b0 = (lx.lane >> LO) & 1, b1 = (lx.lane >> (LO + 1)) & 1;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+        swap_pair<(1 << LO)>(z[nb][0], z[nb][1], b0, lx);          // lane bit LO   <-> slot bit 0
+        swap_pair<(1 << LO)>(z[nb][2], z[nb][3], b0, lx);
+        swap_pair<(2 << LO)>(z[nb][0], z[nb][2], b1, lx);          // lane bit LO+1 <-> slot bit 1
+        swap_pair<(2 << LO)>(z[nb][1], z[nb][3], b1, lx);
+    }
+}
+// odd last window, forward direction: slots (b2,b1) with thread bit0 = b0  ->  slots (b1,b0) with thread bit0 = b2
+template <int NB>
+__device__ __forceinline__ void exchange_lane_odd_fwd(cplx (&z)[NB][4], const LaneX &lx) {
+    const bool lam = lx.lane & 1;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+        cplx n[4];
+#pragma unroll
+        for (int b1 = 0; b1 < 2; b1++) {
+            cplx A = z[nb][b1], Bq = z[nb][2 + b1];                // old slots (b2 = 0, b1), (b2 = 1, b1)
+            // keep the one with b2 == lam, trade the other: swap_pair gives/receives exactly that
+            swap_pair<1>(A, Bq, lam, lx);                          // lam = 0: receives into Bq ; lam = 1: receives into A
+            // after the swap: lam = 0 holds A = own(0,b1), Bq = partner's (0,b1) ; lam = 1 holds A = partner's (1,b1), Bq = own (1,b1)
+            n[2 * b1 + 0] = A;                                     // new slot (b1, b0 = 0): b0 = thread bit of the source
+            n[2 * b1 + 1] = Bq;                                    // new slot (b1, b0 = 1)
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) z[nb][e] = n[e];
+    }
+}
+// inverse direction: slots (b1,b0) with thread bit0 = b2  ->  slots (b2,b1) with thread bit0 = b0
+template <int NB>
+__device__ __forceinline__ void exchange_lane_odd_inv(cplx (&z)[NB][4], const LaneX &lx) {
+    const bool lam = lx.lane & 1;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+        cplx n[4];
+#pragma unroll
+        for (int b1 = 0; b1 < 2; b1++) {
+            cplx A = z[nb][2 * b1], Bq = z[nb][2 * b1 + 1];        // old slots (b1, b0 = 0), (b1, b0 = 1)
+            swap_pair<1>(A, Bq, lam, lx);
+            n[b1] = A;                                             // new slot (b2 = 0, b1)
+            n[2 + b1] = Bq;                                        // new slot (b2 = 1, b1)
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) z[nb][e] = n[e];
+    }
+}
+
+#ifndef MKT_LANE_EXCHANGE
+#define MKT_LANE_EXCHANGE 4   // 0: every exchange through LDS; 1: in-wave wherever legal; 2: only the odd last window;
+                              // 3: 2 + quad-local (d = 1, 2); 4 (default, measured): 2 for odd log2 M, 1 for even
+#endif
+
+// which route the exchange between two windows of the schedule takes (compile time): 0 LDS, 1 in-wave 4x4, 2 odd window
+template <int LOGM, int LOGR>
+struct Route {
+    using P = Plan<LOGM, LOGR>;
+    static constexpr int LANEBITS = (LOGM - LOGR) < 6 ? (LOGM - LOGR) : 6;   // thread bits that are lane bits
+    __host__ __device__ static constexpr int of(int lo_a, int lo_b) {
+        const int lomin = lo_a < lo_b ? lo_a : lo_b, diff = lo_a < lo_b ? lo_b - lo_a : lo_a - lo_b;
+        constexpr int MODE = MKT_LANE_EXCHANGE == 4 ? ((LOGM & 1) ? 2 : 1) : MKT_LANE_EXCHANGE;
+        if ((MODE == 1 || (MODE == 3 && lomin == 0)) && LOGR == 2 && diff == 2 && lomin + 2 <= LANEBITS && lomin + 2 <= 5) return 1;
+        if (MODE >= 1 && LOGR == 2 && diff == 1 && lomin == 0 && LANEBITS >= 1) return 2;
+        return 0;
+    }
+    // staging buffer (pass parity) of the first / last LDS exchange of a forward and of an inverse transform, -1 if none
+    __host__ __device__ static constexpr int fwd_first() { for (int p = 0; p < P::NPASS - 1; p++) if (of(P::lo(p), P::lo(p + 1)) == 0) return p & 1; return -1; }
+    __host__ __device__ static constexpr int fwd_last() { for (int p = P::NPASS - 2; p >= 0; p--) if (of(P::lo(p), P::lo(p + 1)) == 0) return p & 1; return -1; }
+    __host__ __device__ static constexpr int inv_first() { for (int p = P::NPASS - 1; p >= 1; p--) if (of(P::lo(p), P::lo(p - 1)) == 0) return p & 1; return -1; }
+    __host__ __device__ static constexpr int inv_last() { for (int p = 1; p <= P::NPASS - 1; p++) if (of(P::lo(p), P::lo(p - 1)) == 0) return p & 1; return -1; }
+    // a transform must open with a barrier if its first LDS exchange reuses the buffer of the previous transform's last
+    static constexpr bool guard_fwd = fwd_first() >= 0 && (fwd_first() == fwd_last() || fwd_first() == inv_last());
+    static constexpr bool guard_inv = inv_first() >= 0 && (inv_first() == fwd_last() || inv_first() == inv_last());
+};
+
+// one exchange between the windows lo_from / lo_to of the schedule, by the cheapest legal route; PASS = the pass
+// whose output is exchanged (selects the staging buffer)
+template <int LOGM, int LOGR, int NB, int LO_FROM, int LO_TO, bool FWD, int PASS>
+__device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *lds, int t, const LaneX &lx) {
+    constexpr int R = Route<LOGM, LOGR>::of(LO_FROM, LO_TO);
+    if constexpr (R == 1) exchange_lane_full<(LO_FROM < LO_TO ? LO_FROM : LO_TO), NB>(z, lx);
+    else if constexpr (R == 2) { if constexpr (FWD) exchange_lane_odd_fwd<NB>(z, lx); else exchange_lane_odd_inv<NB>(z, lx); }
+    else exchange_lds<LOGM, LOGR, NB>(z, lds + (PASS & 1) * Plan<LOGM, LOGR, NB>::BUF, t, LO_FROM, LO_TO);
+}
+
 // fft.jl:105-155: for stage bit b (stride k = 2^b, m = 2^(LOGM-1-b)), butterfly on (j, j+k):
 //   u = a[j+k] * Psi[m + (j >> (b+1))];  a[j], a[j+k] = a[j] + u, a[j] - u
 // In: slot e = point e*NT + t.  Out: slot e = point t*R + e.  NB independent transforms share the
 // twiddle loads and the barriers.
-template <int LOGM, int LOGR, int NB>
-__device__ __forceinline__ void fft_forward(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t) {
+template <int LOGM, int LOGR, int NB, int PASS = 0>
+__device__ __forceinline__ void fft_forward_pass(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t, const LaneX &lx) {
     using P = Plan<LOGM, LOGR, NB>;
-    // with an even pass count two back-to-back transforms of the same direction would start writing
-    // the staging buffer the previous one may still be reading
-    if (P::NPASS > 1 && (P::NPASS & 1) == 0) __syncthreads();
+    constexpr int p = PASS, lo = P::lo(p);
 #pragma unroll
-    for (int p = 0; p < P::NPASS; p++) {
-        const int lo = P::lo(p);
+    for (int s = 0; s < P::nst(p); s++) {
+        const int b = P::hib(p) - s, sb = b - lo;
+        const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
 #pragma unroll
-        for (int s = 0; s < P::nst(p); s++) {
-            const int b = P::hib(p) - s, sb = b - lo;
-            const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
+        for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) {
+            cplx w; if (MKT_ABLATE & 2) { w.re = 0.5 + twbase; w.im = 0.25 * g; } else w = psi[twbase + g];
 #pragma unroll
-            for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) {
-                cplx w; if (MKT_ABLATE & 2) { w.re = 0.5 + twbase; w.im = 0.25 * g; } else w = psi[twbase + g];
+            for (int q = 0; q < (1 << sb); q++) {
+                const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
 #pragma unroll
-                for (int q = 0; q < (1 << sb); q++) {
-                    const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++) {
-                        const cplx u = cmul(z[nb][e2], w);
-                        const cplx a = z[nb][e];
-                        z[nb][e] = cadd(a, u); z[nb][e2] = csub(a, u);
-                    }
+                for (int nb = 0; nb < NB; nb++) {
+                    const cplx u = cmul(z[nb][e2], w);
+                    const cplx a = z[nb][e];
+                    z[nb][e] = cadd(a, u); z[nb][e2] = csub(a, u);
                 }
             }
         }
-        if (p < P::NPASS - 1) exchange<LOGM, LOGR, NB>(z, lds + (p & 1) * P::BUF, t, lo, P::lo(p + 1));
     }
+    if constexpr (p < P::NPASS - 1) {
+        exchange<LOGM, LOGR, NB, P::lo(p), P::lo(p + 1), true, PASS>(z, lds, t, lx);
+        fft_forward_pass<LOGM, LOGR, NB, PASS + 1>(z, psi, lds, t, lx);
+    }
+}
+template <int LOGM, int LOGR, int NB>
+__device__ __forceinline__ void fft_forward(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t, const LaneX &lx) {
+    if (Route<LOGM, LOGR>::guard_fwd) __syncthreads();
+    fft_forward_pass<LOGM, LOGR, NB, 0>(z, psi, lds, t, lx);
 }
 
 // fft.jl:159-209: t, u = a[j], a[j+k];  a[j] = t + u;  a[j+k] = (t - u) * Psiinv[m + (j >> (b+1))]
 // In: slot e = point t*R + e.  Out: slot e = point e*NT + t.
 // CONJ: `psiinv` points at the FORWARD table Psi and the butterflies multiply by its conjugate (Psiinv == conj(Psi)
 // entry for entry, fft.jl:33-34), so one table -- e.g. a copy resident in LDS -- serves both directions.
-template <int LOGM, int LOGR, int NB, bool CONJ = false>
-__device__ __forceinline__ void fft_inverse(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t) {
+template <int LOGM, int LOGR, int NB, bool CONJ, int PASS>
+__device__ __forceinline__ void fft_inverse_pass(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t, const LaneX &lx) {
     using P = Plan<LOGM, LOGR, NB>;
-    if (P::NPASS > 1 && (P::NPASS & 1) == 0) __syncthreads();
+    constexpr int p = PASS, lo = P::lo(p);
 #pragma unroll
-    for (int p = P::NPASS - 1; p >= 0; p--) {
-        const int lo = P::lo(p);
+    for (int s = P::nst(p) - 1; s >= 0; s--) {
+        const int b = P::hib(p) - s, sb = b - lo;
+        const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
 #pragma unroll
-        for (int s = P::nst(p) - 1; s >= 0; s--) {
-            const int b = P::hib(p) - s, sb = b - lo;
-            const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
+        for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) {
+            cplx w; if (MKT_ABLATE & 2) { w.re = 0.5 + twbase; w.im = 0.25 * g; } else w = psiinv[twbase + g];
 #pragma unroll
-            for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) {
-                cplx w; if (MKT_ABLATE & 2) { w.re = 0.5 + twbase; w.im = 0.25 * g; } else w = psiinv[twbase + g];
+            for (int q = 0; q < (1 << sb); q++) {
+                const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
 #pragma unroll
-                for (int q = 0; q < (1 << sb); q++) {
-                    const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++) {
-                        const cplx a = z[nb][e], u = z[nb][e2];
-                        z[nb][e] = cadd(a, u);
-                        z[nb][e2] = CONJ ? cmul_conj(csub(a, u), w) : cmul(csub(a, u), w);
-                    }
+                for (int nb = 0; nb < NB; nb++) {
+                    const cplx a = z[nb][e], u = z[nb][e2];
+                    z[nb][e] = cadd(a, u);
+                    z[nb][e2] = CONJ ? cmul_conj(csub(a, u), w) : cmul(csub(a, u), w);
                 }
             }
         }
-        if (p > 0) exchange<LOGM, LOGR, NB>(z, lds + (p & 1) * P::BUF, t, lo, P::lo(p - 1));
     }
+    if constexpr (p > 0) {
+        exchange<LOGM, LOGR, NB, P::lo(p), P::lo(p - 1), false, PASS>(z, lds, t, lx);
+        fft_inverse_pass<LOGM, LOGR, NB, CONJ, PASS - 1>(z, psiinv, lds, t, lx);
+    }
+}
+template <int LOGM, int LOGR, int NB, bool CONJ = false>
+__device__ __forceinline__ void fft_inverse(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t, const LaneX &lx) {
+    if (Route<LOGM, LOGR>::guard_inv) __syncthreads();
+    fft_inverse_pass<LOGM, LOGR, NB, CONJ, Plan<LOGM, LOGR, NB>::NPASS - 1>(z, psiinv, lds, t, lx);
 }
 
 // Device point order of the resident TransPolys (keys, monomial table, phase-1 output): where the

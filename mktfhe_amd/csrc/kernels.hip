@@ -14,13 +14,17 @@ constexpr int LOGR = MKT_LOGR;  // points per thread (4 by default)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mkt_smem[];
 
+// per-thread exchange state: lane facts for the in-wave exchanges
+struct XS { LaneX lx; };
+__device__ __forceinline__ XS make_xs() { XS x; x.lx = make_lanex(); return x; }
+
 template <int LOGM>
-__device__ __forceinline__ void fft_forward1(cplx (&z)[1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t) {
-    fft_forward<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][1 << LOGR]>(z), psi, lds, t);
+__device__ __forceinline__ void fft_forward1(cplx (&z)[1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t, XS &xs) {
+    fft_forward<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][1 << LOGR]>(z), psi, lds, t, xs.lx);
 }
 template <int LOGM>
-__device__ __forceinline__ void fft_inverse1(cplx (&z)[1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t) {
-    fft_inverse<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][1 << LOGR]>(z), psiinv, lds, t);
+__device__ __forceinline__ void fft_inverse1(cplx (&z)[1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t, XS &xs) {
+    fft_inverse<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][1 << LOGR]>(z), psiinv, lds, t, xs.lx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -46,6 +50,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
+    XS xs = make_xs();
 #if MKT_FFT_TW_LDS
     cplx *psi_l = lds + P::LDS_CPLX;          // the twiddle table stays in LDS for all polynomials of this workgroup
     for (int i = t; i < M; i += NT) psi_l[i] = tw.psi[i];
@@ -82,11 +87,12 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
                 z[u][e] = cmul(v, rt[e]);
             }
         if (g + gridDim.x < groups) load(g + gridDim.x);
-        if (!(MKT_ABLATE & 16)) fft_forward<LOGM, LOGR, NBT>(z, psi_f, lds, t);
+        if (!(MKT_ABLATE & 16)) fft_forward<LOGM, LOGR, NBT>(z, psi_f, lds, t, xs.lx);
         const bool contig = !dev_order && MKT_FFT_CONTIG_STORE && P::NPASS > 1;
         if (contig) {
-            exchange<LOGM, LOGR, NBT>(z, lds + ((P::NPASS - 1) & 1) * P::BUF, t, 0, P::lo(0));
-            __syncthreads();      // the next transform's first exchange reuses this buffer
+            __syncthreads();
+            exchange_lds<LOGM, LOGR, NBT>(z, lds + ((P::NPASS - 1) & 1) * P::BUF, t, 0, P::lo(0));
+            __syncthreads();      // the next transform's exchanges reuse the buffers
         }
 #pragma unroll
         for (int u = 0; u < NBT; u++) {
@@ -107,6 +113,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_inv_kernel(T
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
+    XS xs = make_xs();
     cplx ri[R];
 #pragma unroll
     for (int e = 0; e < R; e++) ri[e] = tw.rootsinv[e * NT + t];
@@ -128,9 +135,10 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_inv_kernel(T
         }
         if (CONTIG) {   // contiguous ownership (e*NT + t) -> the inverse transform's first window (4t + e)
             __syncthreads();
-            exchange<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][R]>(z), lds + (P::NPASS & 1) * P::BUF, t, P::lo(0), 0);
+            exchange_lds<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][R]>(z), lds + (P::NPASS & 1) * P::BUF, t, P::lo(0), 0);
+            __syncthreads();
         }
-        fft_inverse1<LOGM>(z, tw.psiinv, lds, t);
+        fft_inverse1<LOGM>(z, tw.psiinv, lds, t, xs);
         WORD *pp = p + b * N;
 #pragma unroll
         for (int e = 0; e < R; e++) {
@@ -228,9 +236,9 @@ __device__ __forceinline__ void digit_points(cplx (&z)[R], const WORD (&tp)[R][2
 
 // inverse transform of a transform-domain accumulator followed by native() (fft.jl:74-81)
 template <int LOGM, typename WORD>
-__device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)[1 << LOGR][2], const TwPtrs &tw, cplx *lds, int t) {
+__device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)[1 << LOGR][2], const TwPtrs &tw, cplx *lds, int t, XS &xs) {
     using P = Plan<LOGM, LOGR>;
-    fft_inverse1<LOGM>(z, tw.psiinv, lds, t);
+    fft_inverse1<LOGM>(z, tw.psiinv, lds, t, xs);
 #pragma unroll
     for (int e = 0; e < P::R; e++) {
         const cplx v = cmul(z[e], tw.rootsinv[e * P::NT + t]);
@@ -251,15 +259,19 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 #ifndef MKT_ROT_MINW
 #define MKT_ROT_MINW 2
 #endif
-// 3 waves/SIMD (<= 168 VGPRs) pays at M >= 1024 with single transforms (44.5 vs 47.7 ms at KMS2party); elsewhere 2
+// Occupancy the register allocator is told to hit EXACTLY (amdgpu_waves_per_eu(min, max)): 3 waves/SIMD pays at
+// M >= 1024 with single transforms; elsewhere LDS admits 2 and the allocator should then use all 256 VGPRs --
+// builds that stopped at ~186 or chose <= 168 for a third wave LDS cannot host ran up to 25 % slower
 template <int LOGM, int NB> struct RotOcc { static constexpr int MINW = (LOGM >= 10 && NB == 1 && MKT_LOGR == 2) ? 3 : MKT_ROT_MINW; };
 
 template <int LOGM, typename WORD, int LB, int LR, int NB>
-__global__ __launch_bounds__((Plan<LOGM, LR>::NT), (RotOcc<LOGM, NB>::MINW)) void blindrotate_k1_kernel(const RotArgs a) {
+__global__ __launch_bounds__((Plan<LOGM, LR>::NT)) __attribute__((amdgpu_waves_per_eu(RotOcc<LOGM, NB>::MINW, RotOcc<LOGM, NB>::MINW)))
+void blindrotate_k1_kernel(const RotArgs a) {
     using P = Plan<LOGM, LR, NB>;   // NB transforms at a time share twiddle loads and barriers
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
+    XS xs = make_xs();
     // co-resident workgroups run the same loop in near lock-step and then fight for the VALU and the LDS at the same
     // moments; delaying every other group of 256 workgroups (= every other workgroup of a CU under round-robin
     // dispatch; speed only, never correctness) de-phases them
@@ -272,10 +284,10 @@ __global__ __launch_bounds__((Plan<LOGM, LR>::NT), (RotOcc<LOGM, NB>::MINW)) voi
     for (int i = t; i < M; i += NT) psi_l[i] = a.tw.psi[i];
     __syncthreads();
 #define MKT_PSI_F psi_l
-#define MKT_INV(NBV, ZZ) fft_inverse<LOGM, LR, NBV, true>(ZZ, psi_l, lds, t)
+#define MKT_INV(NBV, ZZ) fft_inverse<LOGM, LR, NBV, true>(ZZ, psi_l, lds, t, xs.lx)
 #else
 #define MKT_PSI_F a.tw.psi
-#define MKT_INV(NBV, ZZ) fft_inverse<LOGM, LR, NBV, false>(ZZ, a.tw.psiinv, lds, t)
+#define MKT_INV(NBV, ZZ) fft_inverse<LOGM, LR, NBV, false>(ZZ, a.tw.psiinv, lds, t, xs.lx)
 #endif
     // workgroups are dealt slot-major (all ciphertexts' rotations of one party/row are adjacent), so the workgroups
     // resident at any time stream the SAME party's key rows through L2; results are stored ciphertext-major
@@ -341,7 +353,7 @@ __global__ __launch_bounds__((Plan<LOGM, LR>::NT), (RotOcc<LOGM, NB>::MINW)) voi
                     z[h2][e] = cmul(v, a.tw.roots[e * NT + t]);
                 }
             }
-            fft_forward<LOGM, LR, NB>(z, MKT_PSI_F, lds, t);              // :54-59 fftto!
+            fft_forward<LOGM, LR, NB>(z, MKT_PSI_F, lds, t, xs.lx);  // :54-59 fftto!
 #pragma unroll
             for (int h2 = 0; h2 < NB; h2++)
 #pragma unroll
@@ -414,7 +426,7 @@ __global__ __launch_bounds__((Plan<LOGM, LR>::NT), (RotOcc<LOGM, NB>::MINW)) voi
                 cplx v; v.re = word_to_f64<WORD>(acc[c][e][0]); v.im = word_to_f64<WORD>((WORD)((WORD)0 - acc[c][e][1]));
                 z[0][e] = cmul(v, a.tw.roots[e * NT + t]);
             }
-            fft_forward<LOGM, LR, 1>(z, MKT_PSI_F, lds, t);
+            fft_forward<LOGM, LR, 1>(z, MKT_PSI_F, lds, t, xs.lx);
             cplx *o = a.tout + (rot * 2 + c) * M;
 #pragma unroll
             for (int e = 0; e < R; e++) o[a.tout_natural ? t * R + e : dev_pos(t * R + e, NT)] = z[0][e];
@@ -435,6 +447,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     cplx *psi_l = lds + P::LDS_CPLX;
     const int t = threadIdx.x;
+    XS xs = make_xs();
     for (int i = t; i < M; i += NT) psi_l[i] = a.tw.psi[i];
     __syncthreads();
     const size_t rot = blockIdx.x;
@@ -474,7 +487,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(
                     cplx v; v.re = (double)d0; v.im = (double)(-d1);
                     z[e] = cmul(v, a.tw.roots[e * NT + t]);
                 }
-                fft_forward1<LOGM>(z, psi_l, lds, t);
+                fft_forward1<LOGM>(z, psi_l, lds, t, xs);
                 const cplx *row = brk + (size_t)(c * l + j) * NP * M;
 #pragma unroll
                 for (int q = 0; q < NP; q++)
@@ -488,7 +501,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(
             cplx s[R];
 #pragma unroll
             for (int e = 0; e < R; e++) s[e] = cmul(mono[dp[e]], tacc[q][e]);
-            fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(s), psi_l, lds, t);
+            fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(s), psi_l, lds, t, xs.lx);
 #pragma unroll
             for (int e = 0; e < R; e++) {
                 const cplx v = cmul(s[e], a.tw.rootsinv[e * NT + t]);
@@ -515,6 +528,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
+    XS xs = make_xs();
     const size_t g = blockIdx.x;
     const int k = a.k;
     WORD *acc = reinterpret_cast<WORD *>(a.acc) + g * (size_t)(k + 1) * N;
@@ -567,7 +581,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
             for (int j = 0; j < iter; j++) {                              // :485-499 LEV multiplication
                 cplx z[R];
                 digit_points<WORD, R>(z, tp, glev, j, rt);
-                fft_forward1<LOGM>(z, a.tw.psi, lds, t);
+                fft_forward1<LOGM>(z, a.tw.psi, lds, t, xs);
                 const cplx *kb = lev + (size_t)(2 * j) * M, *ka = kb + M;
 #pragma unroll
                 for (int e = 0; e < R; e++) { txq[e] = cadd(txq[e], cmul(z[e], kb[dp[e]])); tyq[e] = cadd(tyq[e], cmul(z[e], ka[dp[e]])); }
@@ -575,7 +589,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
 #pragma unroll
             for (int e = 0; e < R; e++) tx[(size_t)q * M + dp[e]] = txq[e];
             WORD yw[R][2];
-            inverse_to_words<LOGM, WORD>(tyq, yw, a.tw, lds, t);          // :501-504
+            inverse_to_words<LOGM, WORD>(tyq, yw, a.tw, lds, t, xs);          // :501-504
 #pragma unroll
             for (int e = 0; e < R; e++) { tp[e][0] = guni.prep(yw[e][0]); tp[e][1] = guni.prep(yw[e][1]); }   // :508-509
             cplx tyu[R];
@@ -585,7 +599,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
             for (int j = 0; j < a.l_uni; j++) {                           // :521-535 u and v
                 cplx z[R];
                 digit_points<WORD, R>(z, tp, guni, j, rt);
-                fft_forward1<LOGM>(z, a.tw.psi, lds, t);
+                fft_forward1<LOGM>(z, a.tw.psi, lds, t, xs);
                 const cplx *kd = rd + (size_t)j * M, *kv = vk + (size_t)j * M;
 #pragma unroll
                 for (int e = 0; e < R; e++) {
@@ -599,7 +613,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
         }
 
         WORD vw[R][2];
-        inverse_to_words<LOGM, WORD>(tv, vw, a.tw, lds, t);               // :538
+        inverse_to_words<LOGM, WORD>(tv, vw, a.tw, lds, t, xs);               // :538
         WORD tp[R][2];
 #pragma unroll
         for (int e = 0; e < R; e++) { tp[e][0] = guni.prep(vw[e][0]); tp[e][1] = guni.prep(vw[e][1]); }      // :541
@@ -609,7 +623,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
         for (int i = 0; i < a.l_uni; i++) {                               // :547-550 w
             cplx z[R];
             digit_points<WORD, R>(z, tp, guni, i, rt);
-            fft_forward1<LOGM>(z, a.tw.psi, lds, t);
+            fft_forward1<LOGM>(z, a.tw.psi, lds, t, xs);
             const cplx *fb = rf + (size_t)(2 * i) * M, *fa = fb + M;
 #pragma unroll
             for (int e = 0; e < R; e++) { tyb[e] = cadd(tyb[e], cmul(z[e], fb[dp[e]])); tya[e] = cadd(tya[e], cmul(z[e], fa[dp[e]])); }
@@ -625,7 +639,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
                 s[e] = cadd(xv, yv);
             }
             WORD w[R][2];
-            inverse_to_words<LOGM, WORD>(s, w, a.tw, lds, t);
+            inverse_to_words<LOGM, WORD>(s, w, a.tw, lds, t, xs);
 #pragma unroll
             for (int e = 0; e < R; e++) { acc[(size_t)q * N + e * NT + t] = w[e][0]; acc[(size_t)q * N + M + e * NT + t] = w[e][1]; }
         }
@@ -647,6 +661,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     cplx *psi_l = lds + P::LDS_CPLX;
     const int t = threadIdx.x;
+    XS xs = make_xs();
     for (int i = t; i < M; i += NT) psi_l[i] = a.tw.psi[i];
     __syncthreads();
     const size_t g = blockIdx.x;
@@ -674,7 +689,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
         for (int j = 0; j < l; j++) {
             cplx z[R];
             digit_points<WORD, R>(z, tp, gd, j, rt);
-            fft_forward1<LOGM>(z, psi_l, lds, t);
+            fft_forward1<LOGM>(z, psi_l, lds, t, xs);
             const cplx *kd = ud + (size_t)j * M, *kv = vk + (size_t)j * M;
 #pragma unroll
             for (int e = 0; e < R; e++) {
@@ -692,14 +707,14 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
         for (int j = 0; j < l; j++) {
             cplx z[R];
             digit_points<WORD, R>(z, tp, gd, j, rt);
-            fft_forward1<LOGM>(z, psi_l, lds, t);
+            fft_forward1<LOGM>(z, psi_l, lds, t, xs);
             const cplx *fb = uf + (size_t)(2 * j) * M, *fa = fb + M;
 #pragma unroll
             for (int e = 0; e < R; e++) { tb[e] = cadd(tb[e], cmul(z[e], fb[dp[e]])); ta[e] = cadd(ta[e], cmul(z[e], fa[dp[e]])); }
         }
     };
     auto inv_words = [&](cplx (&z)[R], WORD (&w)[R][2]) {                        // fft.jl:74-81
-        fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t);
+        fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t, xs.lx);
 #pragma unroll
         for (int e = 0; e < R; e++) {
             const cplx v = cmul(z[e], a.tw.rootsinv[e * NT + t]);
