@@ -4,6 +4,8 @@ Integer outputs (ciphertext words, accumulators, digits) and the Float64 transfo
 are compared as raw bits -- the F64REF mode reproduces the reference's operation sequence, so
 equality is exact, tolerance 0.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -356,3 +358,14 @@ def test_blindrotate_special_exponents(require_gpu, p):
     got = sg.blindrotate_(at, acc0.astype(p.ring_dtype).copy())
     assert np.array_equal(got.astype(np.uint64), ref)
     sg.close()
+
+
+def test_fixture_replay_path(require_gpu, tmp_path):
+    """tools/replay_fixture.py replays fixtures in the format tools/dump_fixture.jl (Julia reference, unexecuted here)
+    writes; the path is exercised with a fixture written by the oracle in the same format"""
+    import subprocess, sys
+    from helpers import ROOT
+    d = str(tmp_path / "fx")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "replay_fixture.py"), "--make", d])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "replay_fixture.py"), d], capture_output=True, text=True)
+    assert out.returncode == 0 and "True" in out.stdout, out.stdout + out.stderr
