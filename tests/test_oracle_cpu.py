@@ -1,6 +1,7 @@
 """CPU tests (-m "not gpu"): the oracle against this repo's pinned fixtures and independent
 restatements, the host-side logic, and the C-ABI surface.  No GPU compute."""
 import ctypes as C
+import sys
 import hashlib
 import json
 import os
@@ -357,3 +358,19 @@ def test_circuit_levelisation_with_oracle_backend():
     c2 = CI.Circuit(); x = c2.input(); y = c2.input(); c2.output(c2.NOT(c2.NAND(x, c2.NOT(y))))
     o2 = CI.evaluate(c2, inputs[:2], gate_fn, lambda v: (0 - v.astype(np.int64)).astype(np.uint32))
     assert np.array_equal(mk.lwe_decrypt(o2[0], keys[0], p), bits[0] & ~bits[1])
+
+
+def test_lds_staging_swizzle_is_conflict_free_in_the_bank_model():
+    """the XOR swizzle shipped in csrc/fft_device.h (lds_pos) has zero bank conflicts for every exchange pattern of the
+    4-points-per-thread schedule in the gfx950 b128 bank model (tools/lds_swizzle_search.py); PMC confirms on hardware"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_swizzle_search as S
+    S.LOGR = 2
+    swz = lambda i: i ^ ((i >> 1) & 8) ^ ((i >> 2) & 15)
+    for LOGM in (7, 8, 9, 10, 11):
+        M = 1 << LOGM
+        assert sorted(swz(i) for i in range(M)) == list(range(M))          # a permutation of the staging slots
+        rd, ird, wr, iwr = S.evaluate(LOGM, swz)
+        assert (rd, wr) == (ird, iwr), LOGM
+        rd0, _, wr0, _ = S.evaluate(LOGM, lambda i: i)
+        assert rd0 > ird and wr0 > iwr                                     # the identity layout does conflict
