@@ -91,7 +91,8 @@ int mkt_abi_version(void);
 int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx **out);
 int mkt_ctx_destroy(mkt_ctx *ctx);
 const char *mkt_last_error(const mkt_ctx *ctx); /* ctx may be NULL: last creation error */
-/* HIP stream (hipStream_t) all subsequent batch calls are enqueued on; NULL = default stream */
+/* HIP stream (hipStream_t) all subsequent batch calls are enqueued on; NULL = default stream.  The per-batch workspace
+ * belongs to the context: calls on one context must not overlap (one context per host thread / stream). */
 int mkt_set_stream(mkt_ctx *ctx, void *hip_stream);
 int mkt_synchronize(mkt_ctx *ctx);
 
