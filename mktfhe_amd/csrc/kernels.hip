@@ -43,6 +43,30 @@ __device__ __forceinline__ void fft_inverse1(cplx (&z)[1 << LOGR], const cplx *_
 #endif
 
 // NBT polynomials per workgroup iteration share the twiddle reads and the barriers (2 pays up to M = 512)
+#ifndef MKT_FFT_NT
+#define MKT_FFT_NT 3      // bit 0: nontemporal coefficient loads, bit 1: nontemporal result stores (streamed once: +10-16 % on MI355X)
+#endif
+#ifndef MKT_FFT_PF
+#define MKT_FFT_PF 2      // polynomial groups in flight per workgroup ahead of the one being transformed
+#endif
+typedef double __attribute__((ext_vector_type(2))) mkt_d2;
+template <typename T> __device__ __forceinline__ T stream_load(const T *p) {
+    if (MKT_FFT_NT & 1) return __builtin_nontemporal_load(p);
+    return *p;
+}
+__device__ __forceinline__ cplx stream_load_c(const cplx *p) {
+    if (MKT_FFT_NT & 1) { mkt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const mkt_d2 *>(p)); return cplx{v.x, v.y}; }
+    return *p;
+}
+__device__ __forceinline__ void stream_store_c(cplx *p, cplx z) {
+    if (MKT_FFT_NT & 2) { mkt_d2 v = {z.re, z.im}; __builtin_nontemporal_store(v, reinterpret_cast<mkt_d2 *>(p)); }
+    else *p = z;
+}
+template <typename T> __device__ __forceinline__ void stream_store(T *p, T v) {
+    if (MKT_FFT_NT & 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 template <int LOGM, typename WORD, int NBT>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(TwPtrs tw, const WORD *__restrict__ p,
                                                                             cplx *__restrict__ out, size_t B, int dev_order) {
@@ -62,46 +86,53 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
     cplx rt[R];
 #pragma unroll
     for (int e = 0; e < R; e++) rt[e] = tw.roots[e * NT + t];
-    // software pipeline: the next polynomials' coefficients are in flight while these are transformed
-    WORD c0[NBT][R], c1[NBT][R];
+    // software pipeline: the coefficients of this workgroup's next PF polynomial groups are in flight while one is transformed
+    constexpr int PF = MKT_FFT_PF;
+    WORD c0[PF][NBT][R], c1[PF][NBT][R];
     const size_t groups = (B + NBT - 1) / NBT;
-    size_t g = blockIdx.x;
-    auto load = [&](size_t gi) {
+    auto load = [&](int d, size_t gi) {
 #pragma unroll
         for (int u = 0; u < NBT; u++) {
             const size_t b = gi * NBT + u < B ? gi * NBT + u : B - 1;
 #pragma unroll
-            for (int e = 0; e < R; e++) { c0[u][e] = p[b * N + e * NT + t]; c1[u][e] = p[b * N + M + e * NT + t]; }
+            for (int e = 0; e < R; e++) { c0[d][u][e] = stream_load(&p[b * N + e * NT + t]); c1[d][u][e] = stream_load(&p[b * N + M + e * NT + t]); }
         }
     };
-    if (g < groups) load(g);
-    for (; g < groups; g += gridDim.x) {
-        cplx z[NBT][R];
 #pragma unroll
-        for (int u = 0; u < NBT; u++)
+    for (int d = 0; d < PF; d++)
+        if (blockIdx.x + (size_t)d * gridDim.x < groups) load(d, blockIdx.x + (size_t)d * gridDim.x);
+    for (size_t g0 = blockIdx.x; g0 < groups; g0 += (size_t)PF * gridDim.x) {
 #pragma unroll
-            for (int e = 0; e < R; e++) {
-                cplx v;
-                v.re = word_to_f64<WORD>(c0[u][e]);
-                v.im = word_to_f64<WORD>((WORD)((WORD)0 - c1[u][e]));   // subtraction in the integer type (fft.jl:60)
-                z[u][e] = cmul(v, rt[e]);
+        for (int d = 0; d < PF; d++) {
+            const size_t g = g0 + (size_t)d * gridDim.x;
+            if (g >= groups) break;
+            cplx z[NBT][R];
+#pragma unroll
+            for (int u = 0; u < NBT; u++)
+#pragma unroll
+                for (int e = 0; e < R; e++) {
+                    cplx v;
+                    v.re = word_to_f64<WORD>(c0[d][u][e]);
+                    v.im = word_to_f64<WORD>((WORD)((WORD)0 - c1[d][u][e]));   // subtraction in the integer type (fft.jl:60)
+                    z[u][e] = cmul(v, rt[e]);
+                }
+            if (g + (size_t)PF * gridDim.x < groups) load(d, g + (size_t)PF * gridDim.x);
+            if (!(MKT_ABLATE & 16)) fft_forward<LOGM, LOGR, NBT>(z, psi_f, lds, t, xs.lx);
+            const bool contig = !dev_order && MKT_FFT_CONTIG_STORE && P::NPASS > 1;
+            if (contig) {
+                __syncthreads();
+                exchange_lds<LOGM, LOGR, NBT>(z, lds + ((P::NPASS - 1) & 1) * P::BUF, t, 0, P::lo(0));
+                __syncthreads();      // the next transform's exchanges reuse the buffers
             }
-        if (g + gridDim.x < groups) load(g + gridDim.x);
-        if (!(MKT_ABLATE & 16)) fft_forward<LOGM, LOGR, NBT>(z, psi_f, lds, t, xs.lx);
-        const bool contig = !dev_order && MKT_FFT_CONTIG_STORE && P::NPASS > 1;
-        if (contig) {
-            __syncthreads();
-            exchange_lds<LOGM, LOGR, NBT>(z, lds + ((P::NPASS - 1) & 1) * P::BUF, t, 0, P::lo(0));
-            __syncthreads();      // the next transform's exchanges reuse the buffers
-        }
 #pragma unroll
-        for (int u = 0; u < NBT; u++) {
-            const size_t b = g * NBT + u;
-            if (b >= B) break;
-            cplx *o = out + b * M;
+            for (int u = 0; u < NBT; u++) {
+                const size_t b = g * NBT + u;
+                if (b >= B) break;
+                cplx *o = out + b * M;
 #pragma unroll
-            for (int e = 0; e < R; e++)   // device point order for resident tables; else the reference's TransPoly order
-                o[dev_order ? dev_pos(t * R + e, NT) : (contig ? e * NT + t : t * R + e)] = z[u][e];
+                for (int e = 0; e < R; e++)   // device point order for resident tables; else the reference's TransPoly order
+                    stream_store_c(&o[dev_order ? dev_pos(t * R + e, NT) : (contig ? e * NT + t : t * R + e)], z[u][e]);
+            }
         }
     }
 }
@@ -118,34 +149,47 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_inv_kernel(T
 #pragma unroll
     for (int e = 0; e < R; e++) ri[e] = tw.rootsinv[e * NT + t];
     constexpr bool CONTIG = MKT_FFT_CONTIG_STORE && P::NPASS > 1;
-    cplx zn[R];
-    size_t b = blockIdx.x;
-    if (b < B) {
+#if MKT_FFT_TW_LDS
+    cplx *psi_l = lds + P::LDS_CPLX;          // psiinv[i] == conj(psi[i]) entrywise: one resident table serves both directions
+    for (int i = t; i < M; i += NT) psi_l[i] = tw.psi[i];
+    __syncthreads();
+#endif
+    constexpr int PF = MKT_FFT_PF;
+    cplx zn[PF][R];
+    auto load = [&](int d, size_t b) {
 #pragma unroll
-        for (int e = 0; e < R; e++) zn[e] = in[b * M + (CONTIG ? e * NT + t : t * R + e)];
-    }
-    for (; b < B; b += gridDim.x) {
-        cplx z[R];
+        for (int e = 0; e < R; e++) zn[d][e] = stream_load_c(&in[b * M + (CONTIG ? e * NT + t : t * R + e)]);
+    };
 #pragma unroll
-        for (int e = 0; e < R; e++) z[e] = zn[e];
-        const size_t nb = b + gridDim.x;
-        if (nb < B) {
+    for (int d = 0; d < PF; d++)
+        if (blockIdx.x + (size_t)d * gridDim.x < B) load(d, blockIdx.x + (size_t)d * gridDim.x);
+    for (size_t b0 = blockIdx.x; b0 < B; b0 += (size_t)PF * gridDim.x) {
 #pragma unroll
-            for (int e = 0; e < R; e++) zn[e] = in[nb * M + (CONTIG ? e * NT + t : t * R + e)];
-        }
-        if (CONTIG) {   // contiguous ownership (e*NT + t) -> the inverse transform's first window (4t + e)
-            __syncthreads();
-            exchange_lds<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][R]>(z), lds + (P::NPASS & 1) * P::BUF, t, P::lo(0), 0);
-            __syncthreads();
-        }
-        fft_inverse1<LOGM>(z, tw.psiinv, lds, t, xs);
-        WORD *pp = p + b * N;
+        for (int d = 0; d < PF; d++) {
+            const size_t b = b0 + (size_t)d * gridDim.x;
+            if (b >= B) break;
+            cplx z[R];
 #pragma unroll
-        for (int e = 0; e < R; e++) {
-            const int idx = e * NT + t;
-            const cplx v = cmul(z[e], ri[e]);
-            pp[idx] = native<WORD>(v.re);
-            pp[idx + M] = native<WORD>(-v.im);
+            for (int e = 0; e < R; e++) z[e] = zn[d][e];
+            if (b + (size_t)PF * gridDim.x < B) load(d, b + (size_t)PF * gridDim.x);
+            if (CONTIG) {   // contiguous ownership (e*NT + t) -> the inverse transform's first window (4t + e)
+                __syncthreads();
+                exchange_lds<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][R]>(z), lds + (P::NPASS & 1) * P::BUF, t, P::lo(0), 0);
+                __syncthreads();
+            }
+#if MKT_FFT_TW_LDS
+            fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t, xs.lx);
+#else
+            fft_inverse1<LOGM>(z, tw.psiinv, lds, t, xs);
+#endif
+            WORD *pp = p + b * N;
+#pragma unroll
+            for (int e = 0; e < R; e++) {
+                const int idx = e * NT + t;
+                const cplx v = cmul(z[e], ri[e]);
+                stream_store(&pp[idx], native<WORD>(v.re));
+                stream_store(&pp[idx + M], native<WORD>(-v.im));
+            }
         }
     }
 }
@@ -948,8 +992,9 @@ static hipError_t launch_fwd_one(TwPtrs tw, const void *p, cplx *t, size_t B, in
 
 hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, hipStream_t s) {
     if (B == 0) return hipSuccess;
-    // swept on MI355X (tools/fft_nb.sh): two polynomials per iteration and a larger grid pay up to M = 512
-    int gmax = logM <= 9 ? 10240 : 5120, nbt = logM <= 9 ? 2 : 1;
+    // swept on MI355X (tools/fft_sweep.py): with nontemporal streams many short-lived workgroups (8-16 polynomials each
+    // at a 4 GiB batch) beat few long-lived ones, as a flat copy beats a grid-stride one on this part (tools/membench2.hip)
+    int gmax = 32768, nbt = 1;
     if (const char *e = getenv("MKT_FFT_GRID")) { if (atoi(e) > 0) gmax = atoi(e); }
     if (const char *e = getenv("MKT_FFT_NB")) nbt = atoi(e);
     MKT_DISPATCH_LOGM(logM, {
@@ -973,15 +1018,17 @@ hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, in
 
 hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void *p, size_t B, hipStream_t s) {
     if (B == 0) return hipSuccess;
-    const int grid = (int)(B < 4096 ? B : 4096);
+    size_t gmax = 32768;
+    if (const char *e = getenv("MKT_FFT_IGRID")) { if (atoi(e) > 0) gmax = (size_t)atoi(e); }
+    const int grid = (int)(B < gmax ? B : gmax);
     MKT_DISPATCH_LOGM(logM, {
         using P = Plan<LM, LOGR>;
         if (W == 64) {
-            constexpr size_t LB = P::LDS_BYTES;
+            constexpr size_t LB = P::LDS_BYTES + (MKT_FFT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
             hipError_t e = set_lds(transform_inv_kernel<LM, uint64_t>, LB); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((transform_inv_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), LB, s, tw, t, (uint64_t *)p, B);
         } else {
-            constexpr size_t LB = P::LDS_BYTES;
+            constexpr size_t LB = P::LDS_BYTES + (MKT_FFT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
             hipError_t e = set_lds(transform_inv_kernel<LM, uint32_t>, LB); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((transform_inv_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), LB, s, tw, t, (uint32_t *)p, B);
         }
