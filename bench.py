@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--workload", default="kms2_n1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--inputs", default="mixed", choices=["mixed", "fresh"], help="mixed: every ciphertext involves all k parties (default); fresh: single-party first-level encryptions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="gates in the CPU-baseline sample (0 = auto)")
@@ -81,17 +82,39 @@ def main():
         keys = [mk.PartyKeys(p, seed=1)]
         sch = mk.setup(p, keys=keys[0], device=local)[1]
     rng = np.random.default_rng(2 + rank)
-    bits = rng.integers(0, 2, 2 * B).astype(bool)
-    # a few hundred distinct fresh encryptions, tiled to the batch (values do not affect timing)
-    uniq = min(2 * B, 256)
-    enc = np.empty((uniq, p.lwe_len), dtype=np.uint32)
-    for j in range(uniq):
-        enc[j] = mk.lwe_ith_encrypt(int(bits[j]), j % p.nparty, keys[j % p.nparty], p, seed=10_000 * (rank + 1) + j)
-    idx = np.arange(2 * B) % uniq
-    bits = bits[idx]
-    allc = enc[idx]
-    x = torch.from_numpy(allc[:B].view(np.int32)).to(dev)
-    y = torch.from_numpy(allc[B:].view(np.int32)).to(dev)
+
+    def fresh(nct, seed0):
+        """distinct fresh encryptions of uniform bits, ciphertext j under party j mod k (scheme.jl:379-386)"""
+        b = rng.integers(0, 2, nct).astype(bool)
+        ct = np.empty((nct, p.lwe_len), dtype=np.uint32)
+        for j in range(nct):
+            ct[j] = mk.lwe_ith_encrypt(int(b[j]), j % p.nparty, keys[j % p.nparty], p, seed=seed0 + j)
+        return b, torch.from_numpy(ct.view(np.int32)).to(dev)
+
+    # Inputs.  A fresh multi-key encryption has only its own party's mask block populated, gates between ciphertexts
+    # of one party keep it that way, and the blind rotation skips zero mask words (bootstrapping.jl:413, :261): such
+    # gates do a fraction of the work (KMS k=2: 2/3).  The timed inputs are therefore ciphertexts that involve EVERY
+    # party, as inside any multi-party circuit: each is an untimed NAND fold over k distinct fresh encryptions, one per
+    # party (test/KMS.jl:29-34 folds its inputs the same way).  `--inputs fresh` times single-party first-level gates.
+    seed0 = 10_000_000 * (rank + 1)
+    if args.inputs == "mixed":
+        def folded(s0):
+            b, ct = fresh(p.nparty * B, s0)            # ct[i::k] are the B ciphertexts under party i
+            acc_b, acc = b[0::p.nparty].copy(), ct[0::p.nparty].contiguous()
+            for i in range(1, p.nparty):
+                acc = mk.NAND(acc, ct[i::p.nparty].contiguous(), sch)
+                acc_b = ~(acc_b & b[i::p.nparty])
+            return acc_b, acc
+        bx, x = folded(seed0)
+        by, y = folded(seed0 + 5_000_000)
+        if p.nparty == 1:
+            x, y = x.clone(), y.clone()
+        bits = np.concatenate([bx, by])
+    else:
+        bits, fct = fresh(2 * B, seed0)
+        x, y = fct[:B].clone(), fct[B:].clone()
+    torch.cuda.synchronize()
+    allc = np.concatenate([x.cpu().numpy(), y.cpu().numpy()]).view(np.uint32)
     out = torch.empty_like(x)
     sch.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -119,9 +142,12 @@ def main():
     # correctness of what was timed: decrypt a sample, and (rank 0) compare a sub-batch with the oracle
     res = out.cpu().numpy().view(np.uint32)
     want = ~(bits[:B] & bits[B:])
-    nchk = min(B, 64)
-    got = mk.lwe_decrypt(res[:nchk], keys if p.multikey else keys[0], p)
-    decrypt_ok = bool(np.array_equal(got, want[:nchk]))
+    got = mk.lwe_decrypt(res, keys if p.multikey else keys[0], p)
+    decrypt_errors = int(np.count_nonzero(got != want))
+    # Wrong decryptions, where present, are the parameter set's own noise, not the engine's: the oracle makes the
+    # identical errors (`oracle_bitexact` is the parity gate).  Seen on gates that mix parties: CCS2party a few per
+    # thousand, the synthetic BASELINE shape one per thousand; the flag only guards against gross failure.
+    decrypt_ok = decrypt_errors <= B // 100
 
     line = None
     if rank == 0:
@@ -132,8 +158,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "params": pname, "parties": p.k, "N": p.N, "n": p.n, "ring_bits": p.W,
-                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "op": "NAND", "arith": "F64REF", "sharding": "gates across GPUs, keys replicated"},
-            "decrypt_ok": decrypt_ok,
+                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "op": "NAND", "inputs": args.inputs, "arith": "F64REF", "sharding": "gates across GPUs, keys replicated"},
+            "decrypt_ok": decrypt_ok, "decrypt_errors": decrypt_errors, "decrypt_checked": B,
             "kernels_ms_per_step": {"blindrotate": rot_ms / max(args.steps, 1), "kms_phase2": p2_ms / max(args.steps, 1),
                                     "keyswitch": ks_ms / max(args.steps, 1)},
         }
@@ -142,8 +168,9 @@ def main():
         lg = int(np.log2(M))
         rows = (1 + (p.k - 1) * p.l_lev) if p.scheme in (mk.KMS, mk.KMS_BLOCK) else 1
         lg_ = max(p.l_gsw, 1)
-        per_iter = (2 * lg_ + 2) * (5 * M * lg + 6 * M) + 4 * lg_ * 8 * M + 2 * 6 * M
-        flop = per_iter * p.n * rows * B
+        LB = max(p.blk_len, 1)     # block schemes: one decomposition + 2l+2 transforms per block of LB key bits
+        per_iter = (2 * lg_ + 2) * (5 * M * lg + 6 * M) + LB * (4 * lg_ * 8 * M + 2 * (8 if LB > 1 else 6) * M)
+        flop = per_iter * (p.n // LB) * rows * B
         if rot_ms > 0 and p.scheme != mk.CCS:
             line["blindrotate"] = {"f64_gflops": flop * args.steps / (rot_ms * 1e-3) / 1e9, "peak_gflops_nofma": 39300.0,
                                    "rotations_per_step": rows * B}

@@ -254,10 +254,11 @@ def test_full_batch_properties(require_gpu, p):
     got = mk.lwe_decrypt(out, keys if p.multikey else keys[0], p)
     want = ~(bits[:B] & bits[B:])
     if p is mk.KMS2party_N1024_l2:
-        # BASELINE.json's synthetic shape is not a parameter set of the reference and is noise-marginal (output phase
-        # error std 0.03 against a 0.125 margin, tools/param_noise_sweep.py): a few gates per thousand decrypt wrongly,
-        # in the oracle exactly as on the GPU (the bit-exact comparison below is the parity statement)
-        assert (got == want).mean() > 0.99
+        # BASELINE.json's synthetic shape is not a parameter set of the reference; its noise margin is thinner than the
+        # shipped sets' (output phase error std 0.025 against a 0.125 margin, tools/param_noise_sweep2.py): an isolated
+        # gate may decrypt wrongly, in the oracle exactly as on the GPU (the bit-exact comparison below is the parity
+        # statement)
+        assert (got == want).mean() > 0.995
     else:
         assert np.array_equal(got, want)
     assert np.array_equal(out, sg.gate(0, x, y))                       # deterministic (atomics are integer adds)
