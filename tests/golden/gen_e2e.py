@@ -41,7 +41,30 @@ def run_case(name):
     return h.hexdigest()
 
 
+def run_mixed(name):
+    """multi-key sets on ciphertexts that involve every party: NAND folds over one fresh encryption per party
+    (test/KMS.jl:29-34), then all six gates on two such ciphertexts (fresh same-party pairs, as in run_case, leave
+    the other parties' mask blocks zero and their rotations are all skips)"""
+    p = CASES[name]
+    crs, keys = keygen(p, 41)
+    s = oracle_scheme(p, crs, keys)
+    k = p.nparty
+    bits = np.array([1, 0, 0, 1, 1, 1, 0, 1] * k, dtype=bool)[:4 * k]
+    c = encrypt_bits(p, keys, bits, seed=4200)
+    acc = [c[j * k] for j in range(4)]
+    for i in range(1, k):
+        acc = [s.gate(0, acc[j], c[j * k + i]) for j in range(4)]
+    h = hashlib.sha256()
+    for op in range(6):
+        for j in range(2):
+            h.update(s.gate(op, acc[j], acc[2 + j]).tobytes())
+    return h.hexdigest()
+
+
+MIXED = [name for name, p in CASES.items() if p.multikey]
+
 if __name__ == "__main__":
     out = {name: run_case(name) for name in CASES}
+    out.update({name + "/mixed": run_mixed(name) for name in MIXED})
     json.dump(out, open(os.path.join(HERE, "e2e_hashes.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))

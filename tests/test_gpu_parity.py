@@ -147,7 +147,44 @@ def _stage_check(p, B=6, seed=1):
     z = x.copy()
     sg.bootstrapping_(z)
     assert np.array_equal(z, np.stack([so.bootstrap(x[j]) for j in range(B)]))
+    if p.multikey:
+        _mixed_party_check(p, keys, so, sg, rng)
     sg.close()
+
+
+def _mixed_party_check(p, keys, so, sg, rng, B=3):
+    """Fresh encryptions populate one party's mask block and same-party gates keep it so (the other parties' rotations
+    are all skips, bootstrapping.jl:413 / :261).  Here every ciphertext involves ALL k parties: NAND folds over one
+    fresh encryption per party (as test/KMS.jl:29-34), then every stage and gate on those dense ciphertexts."""
+    k = p.nparty
+    bits = rng.integers(0, 2, 2 * B * k).astype(bool)
+    c = encrypt_bits(p, keys, bits, seed=7700)                      # ciphertext j under party j mod k
+    acc_g, acc_b = c[0::k].copy(), bits[0::k].copy()
+    for i in range(1, k):
+        nxt = c[i::k]
+        ref = np.stack([so.gate(0, acc_g[j], nxt[j]) for j in range(2 * B)])
+        acc_g = sg.gate(0, acc_g, nxt)
+        assert np.array_equal(acc_g, ref), f"fold step {i}"
+        acc_b = ~(acc_b & bits[i::k])
+    assert (acc_g[:, :-1].reshape(2 * B, k, p.n) != 0).any(axis=2).all(), "every party block populated"
+    x, y = acc_g[:B], acc_g[B:]
+    lin = np.stack([O.gate_linear(0, x[j], y[j]) for j in range(B)])
+    at_g, bt_g = sg.modswitch(lin)
+    acc0 = np.stack([so.testvector(bt_g[j]) for j in range(B)])
+    acc_o = np.stack([so.blindrotate(at_g[j], acc0[j]) for j in range(B)])
+    assert np.array_equal(sg.blindrotate_(at_g, acc0.astype(p.ring_dtype).copy()).astype(np.uint64), acc_o), "blindrotate (mixed)"
+    assert np.array_equal(sg.keyswitch(acc_o.astype(p.ring_dtype)), np.stack([so.keyswitch(acc_o[j]) for j in range(B)])), "keyswitch (mixed)"
+    for op in range(6):
+        out_g = sg.gate(op, x, y)
+        assert np.array_equal(out_g, np.stack([so.gate(op, x[j], y[j]) for j in range(B)])), f"gate {op} (mixed)"
+        if p.name not in NOISY:
+            got = mk.lwe_decrypt(out_g, keys, p)
+            assert np.array_equal(got, GATE_FUNCS[op](acc_b[:B], acc_b[B:])), f"decrypt {op} (mixed)"
+
+
+# parameter sets whose own noise makes gates on many-party ciphertexts decrypt wrongly now and then (the oracle
+# produces the identical words; DESIGN.md 5): bit parity is asserted for them, decryption is not
+NOISY = {"CCS16party", "CCS8party", "CCS4party", "KMS8party"}
 
 
 @pytest.mark.parametrize("p", SMALL, ids=lambda p: f"{p.name}-n{p.n}-N{p.N}")
@@ -166,14 +203,21 @@ def test_gate_full_size(require_gpu, p):
     sg = gpu_scheme(p, crs, keys)
     B = 4
     rng = np.random.default_rng(11)
-    bits = rng.integers(0, 2, 2 * B).astype(bool)
+    bits = rng.integers(0, 2, 2 * B + 1).astype(bool)
     c = encrypt_bits(p, keys, bits, seed=900)
+    x, y, bx, by = c[:B], c[B + 1:], bits[:B], bits[B + 1:]           # y_j under party (j + B + 1) mod k: cross-party pairs
     for op in (0, 3):
-        out_g = sg.gate(op, c[:B], c[B:])
-        out_o = so.gate_batch(op, c[:B], c[B:], threads=4)
+        out_g = sg.gate(op, x, y)
+        out_o = so.gate_batch(op, x, y, threads=4)
         assert np.array_equal(out_g, out_o)
         got = mk.lwe_decrypt(out_g, keys if p.multikey else keys[0], p)
-        assert np.array_equal(got, GATE_FUNCS[op](bits[:B], bits[B:]))
+        assert np.array_equal(got, GATE_FUNCS[op](bx, by))
+    # second level: gate outputs (every party block populated) as inputs
+    lvl1 = sg.gate(0, x, y)
+    out2 = sg.gate(0, lvl1[:2], lvl1[2:])
+    assert np.array_equal(out2, so.gate_batch(0, lvl1[:2], lvl1[2:], threads=2))
+    b1 = ~(bx & by)
+    assert np.array_equal(mk.lwe_decrypt(out2, keys if p.multikey else keys[0], p), ~(b1[:2] & b1[2:]))
     sg.close()
 
 

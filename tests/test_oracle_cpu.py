@@ -248,9 +248,11 @@ def test_random_gate_circuit_decrypts(p):
 def test_end_to_end_golden_hashes():
     """regression pin of the oracle's ciphertext bits (fixture written by tests/golden/gen_e2e.py)"""
     gold = json.load(open(os.path.join(GOLD, "e2e_hashes.json")))
-    from golden.gen_e2e import CASES, run_case
+    from golden.gen_e2e import CASES, MIXED, run_case, run_mixed
     for name in CASES:
         assert run_case(name) == gold[name], name
+    for name in MIXED:      # ciphertexts that involve every party (no skipped rotations)
+        assert run_mixed(name) == gold[name + "/mixed"], name
 
 
 # ---------------------------------------------------------------- client keys are what the layouts say
