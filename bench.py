@@ -40,6 +40,25 @@ WORKLOADS = {
 }
 
 
+def effective_cpus():
+    """CPUs this process can really use: affinity mask and cgroup CPU quota (the GPU boxes expose 256 logical CPUs
+    under a 16-CPU quota; more threads than the quota only add contention)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,14 +221,20 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         from helpers import oracle_scheme
         so = oracle_scheme(p, crs, keys)
-        cores = min(os.cpu_count() or 1, 64)
-        sample = min(B, args.cpu_sample or 4 * cores)
+        cores = effective_cpus()                   # host threads this process may actually run on (cgroup quota aware)
+        # pilot round (one gate per thread) sizes the sample to ~10 s of CPU work, capped at the batch
+        t0 = time.perf_counter()
+        so.gate_batch(0, allc[:cores], allc[B:B + cores], threads=cores)
+        pilot = time.perf_counter() - t0
+        sample = args.cpu_sample or cores * max(1, min(int(10.0 / max(pilot, 1e-3)), 64))
+        sample = min(B, sample)
+        cores = min(cores, sample)
         xs, ys = allc[:sample], allc[B:B + sample]
         t0 = time.perf_counter()
         ref = so.gate_batch(0, xs, ys, threads=cores)
         dt = time.perf_counter() - t0
         line["cpu_baseline"] = {"value": sample / dt, "unit": "gates/s", "cores": cores, "kind": "port",
-                                "sample": f"{sample} NAND gates of the same workload, C oracle (F64REF restatement of the reference CPU path), {cores} threads, one gate per thread",
+                                "sample": f"{sample} NAND gates of the same workload, C oracle (F64REF restatement of the reference CPU path), {cores} threads (the host's CPU quota), one gate per thread",
                                 "seconds": dt}
         line["oracle_bitexact"] = bool(np.array_equal(ref, res[:sample]))
 
