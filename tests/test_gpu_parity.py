@@ -414,3 +414,33 @@ def test_fixture_replay_path(require_gpu, tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "replay_fixture.py"), "--make", d])
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "replay_fixture.py"), d], capture_output=True, text=True)
     assert out.returncode == 0 and "True" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("p,B", [(mk.KMS4party, 8192 + 17), (mk.CCS8party, 1024), (mk.Blockparam, 16384), (mk.KMS2partyblock, 2048)],
+                         ids=lambda v: getattr(v, "name", str(v)))
+def test_baseline_config_shares(require_gpu, p, B):
+    """BASELINE.json configs[2..4] at one GPU's share of the batch (65536 / 8 KMS4party gates -- plus a ragged tail that
+    crosses the engine's 8192-gate workspace chunk --, 8192 / 8 CCS8party gates, 16384 block-binary gates): cross-party
+    input pairs, every output decrypts (where the set's own noise allows), sampled gates equal the oracle bit for
+    bit, and the result does not depend on the position of a gate in the batch."""
+    crs, keys = keygen(p, 21)
+    sg = gpu_scheme(p, crs, keys)
+    rng = np.random.default_rng(23)
+    nu = 64 * p.nparty
+    ubits = rng.integers(0, 2, nu).astype(bool)
+    uniq = encrypt_bits(p, keys, ubits, seed=9100)                     # ciphertext j under party j mod k
+    ix, iy = rng.integers(0, nu, B), rng.integers(0, nu, B)            # random pairs: same- and cross-party gates
+    x, y = uniq[ix], uniq[iy]
+    out = sg.gate(0, x, y)
+    want = ~(ubits[ix] & ubits[iy])
+    got = mk.lwe_decrypt(out, keys if p.multikey else keys[0], p)
+    if p.name in NOISY:
+        assert (got == want).mean() > 0.98
+    else:
+        assert np.array_equal(got, want)
+    so = oracle_scheme(p, crs, keys)
+    pick = np.concatenate([[0, B - 1], rng.integers(0, B, 6)])
+    assert np.array_equal(out[pick], so.gate_batch(0, x[pick], y[pick], threads=8))
+    perm = rng.permutation(B)[:512]                                    # same gates at other batch positions
+    assert np.array_equal(sg.gate(0, x[perm], y[perm]), out[perm])
+    sg.close()
