@@ -41,6 +41,11 @@ class Circuit:
         self.nodes.append((_NOT, a, None))
         return len(self.nodes) - 1
 
+    def MUX(self, s, a, b):
+        """s ? a : b.  The reference has no MUX gate (gate.jl exports NAND..NOR, NOT!); this is the composite
+        OR(AND(s, a), AND(NOT s, b)) of its gates: two levels, three bootstraps, the two ANDs in one batch."""
+        return self.OR(self.AND(s, a), self.AND(self.NOT(s), b))
+
     def output(self, w):
         self.outputs.append(w)
         return w

@@ -362,6 +362,20 @@ def XNOR(c1, c2, scheme: Scheme, out=None):
     return scheme.gate(4, c1, c2, out)
 
 
+def MUX(s, c1, c2, scheme: Scheme):
+    """s ? c1 : c2 -- not a reference operator (gate.jl has none): the composite OR(AND(s, c1), AND(NOT s, c2)) of the
+    reference's gates, with the two ANDs evaluated as one batch"""
+    ns = s.clone() if hasattr(s, "clone") else np.array(s, copy=True)
+    NOT_(ns, scheme)
+    if hasattr(s, "clone"):
+        import torch
+        both = scheme.gate(1, torch.cat([s, ns]), torch.cat([c1, c2]))
+    else:
+        both = scheme.gate(1, np.concatenate([np.atleast_2d(s), np.atleast_2d(ns)]), np.concatenate([np.atleast_2d(c1), np.atleast_2d(c2)]))
+    h = both.shape[0] // 2
+    return scheme.gate(2, both[:h], both[h:])      # 1 = AND, 2 = OR (params.py)
+
+
 def NOR(c1, c2, scheme: Scheme, out=None):
     """gate.jl:46-53"""
     return scheme.gate(5, c1, c2, out)

@@ -363,6 +363,13 @@ def test_circuit_on_device(require_gpu):
     got = sum(mk.lwe_decrypt(o.cpu().numpy().view(np.uint32), keys, p).astype(int) << i for i, o in enumerate(outs))
     a = sum(bits[i].astype(int) << i for i in range(4)); b = sum(bits[4 + i].astype(int) << i for i in range(4))
     assert np.array_equal(got, a + b)
+    # MUX (composite of the reference's gates): selector under party 0, data under parties 1 / 0
+    sel, d1, d0 = inputs[0], inputs[1], inputs[2]
+    m = mk.MUX(sel, d1, d0, sg)
+    assert np.array_equal(mk.lwe_decrypt(m.cpu().numpy().view(np.uint32), keys, p), np.where(bits[0], bits[1], bits[2]))
+    cm = CI.Circuit(); s_, a_, b_ = cm.input(), cm.input(), cm.input(); cm.output(cm.MUX(s_, a_, b_))
+    (mo,) = CI.evaluate_on(cm, [sel, d1, d0], sg)
+    assert np.array_equal(mo.cpu().numpy(), m.cpu().numpy())          # same gates, same order -> same words
     sg.close()
 
 

@@ -360,6 +360,12 @@ def test_circuit_levelisation_with_oracle_backend():
     c2 = CI.Circuit(); x = c2.input(); y = c2.input(); c2.output(c2.NOT(c2.NAND(x, c2.NOT(y))))
     o2 = CI.evaluate(c2, inputs[:2], gate_fn, lambda v: (0 - v.astype(np.int64)).astype(np.uint32))
     assert np.array_equal(mk.lwe_decrypt(o2[0], keys[0], p), bits[0] & ~bits[1])
+    # MUX = OR(AND(s, a), AND(NOT s, b)): two levels, the two ANDs in one batched call
+    c3 = CI.Circuit(); s, a3, b3 = c3.input(), c3.input(), c3.input(); c3.output(c3.MUX(s, a3, b3))
+    calls.clear()
+    o3 = CI.evaluate(c3, inputs[:3], gate_fn, lambda v: (0 - v.astype(np.int64)).astype(np.uint32))
+    assert np.array_equal(mk.lwe_decrypt(o3[0], keys[0], p), np.where(bits[0], bits[1], bits[2]))
+    assert calls == [(1, 2 * B), (2, B)]
 
 
 def test_lds_staging_swizzle_is_conflict_free_in_the_bank_model():
