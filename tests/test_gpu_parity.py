@@ -451,3 +451,43 @@ def test_baseline_config_shares(require_gpu, p, B):
     perm = rng.permutation(B)[:512]                                    # same gates at other batch positions
     assert np.array_equal(sg.gate(0, x[perm], y[perm]), out[perm])
     sg.close()
+
+
+def test_two_contexts_two_host_threads(require_gpu):
+    """one context per host thread; contexts on one device are independent.  Two schemes (different
+    parameter sets, own streams) evaluate batches concurrently from two threads (ctypes drops the GIL during the
+    calls); every result equals the single-threaded one.  Also: output aliasing an input (in-place gate)."""
+    import threading
+    import torch
+    ps = [mk.KMS2party.scaled(n=24, N=512), mk.CGGIparam.scaled(n=40, N=1024)]
+    work = []
+    for i, p in enumerate(ps):
+        crs, keys = keygen(p, 50 + i)
+        sg = gpu_scheme(p, crs, keys)
+        bits = np.random.default_rng(60 + i).integers(0, 2, 513).astype(bool)
+        c = encrypt_bits(p, keys, bits, seed=6000 + i)
+        x, y = c[:256], c[257:513]
+        ref = sg.gate(0, x, y)
+        work.append((sg, x, y, ref))
+    results = [None, None]
+
+    def run(i):
+        sg, x, y, _ = work[i]
+        st = torch.cuda.Stream()
+        sg.set_stream(st.cuda_stream)
+        outs = [sg.gate(0, x, y) for _ in range(6)]
+        sg.synchronize()
+        results[i] = outs
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for i in range(2):
+        assert all(np.array_equal(o, work[i][3]) for o in results[i]), f"context {i}"
+    sg, x, y, ref = work[0]
+    xd = torch.from_numpy(x.view(np.int32)).cuda(); yd = torch.from_numpy(y.view(np.int32)).cuda()
+    sg.set_stream(torch.cuda.current_stream().cuda_stream)
+    mk.NAND(xd, yd, sg, out=xd)                                        # out aliases the first input
+    torch.cuda.synchronize()
+    assert np.array_equal(xd.cpu().numpy().view(np.uint32), ref)
+    for w in work:
+        w[0].close()
