@@ -84,6 +84,7 @@ typedef struct {
 } mkt_params;
 
 typedef struct mkt_ctx mkt_ctx;
+typedef struct mkt_client_party mkt_client_party;   /* one party's keys (client section below) */
 
 /* ---- context: replaces the scheme object (scheme.jl:107-116 ...), FFTransformer (fft.jl:18-45)
  *      and getmonomial (scheme.jl:121-146), all built on device `device`. ---- */
@@ -110,7 +111,16 @@ int mkt_load_brk(mkt_ctx *ctx, int party, const void *data, int fmt);
 int mkt_load_ksk(mkt_ctx *ctx, int party, const uint32_t *data);
 int mkt_load_rlk(mkt_ctx *ctx, int party, const void *d, const void *f, int fmt); /* KMS: keygen.jl:103 */
 int mkt_load_pubkey(mkt_ctx *ctx, int party, const void *b, int fmt);             /* CCS/KMS: keygen.jl:67,:100 */
-int mkt_load_crs(mkt_ctx *ctx, const void *a, int fmt);                           /* scheme.jl:409-410 */
+int mkt_load_crs(mkt_ctx *ctx, const void *a, int fmt);
+
+/* ---- key generation on the device: replaces keygen.jl:13-23, :39-51, :71-79, :106-114,
+ *      :143-151 (RGSW / UniEnc bootstrapping key, LEV key-switching key) for party `party`.  Exact integer arithmetic;
+ *      `keys` holds the party's secrets (mkt_client_party_secrets or _keygen); `crs` = the integer CRS
+ *      (mkt_client_crs) for CCS, NULL otherwise.  Equivalent to mkt_load_brk + mkt_load_ksk of the host-generated
+ *      keys of the same seed, word for word. ---- */
+int mkt_keygen_device(mkt_ctx *ctx, int party, const mkt_client_party *keys, const void *crs);
+/* read a party's key-switching key back in the host layout of mkt_load_ksk (tests) */
+int mkt_get_ksk(mkt_ctx *ctx, int party, uint32_t *out_host);                           /* scheme.jl:409-410 */
 
 /* ---- hot path, batched: B independent ciphertexts per call (the reference does one per call) ---- */
 /* gate.jl:1-53: out = bootstrapping!(linear(op, x, y)); x, y, out: [B][k*n+1] */
@@ -149,13 +159,17 @@ int mkt_last_kernel_ms(mkt_ctx *ctx, int which, double *ms);
 /* ---- client side (host only, no GPU): seeded counterparts of the reference's key generation and
  *      encryption, exact integer arithmetic.  setup/party_keygen scheme.jl:151,:190,:227,:273,:324;
  *      keygen.jl; lwe_encrypt scheme.jl:352-386; lwe_decrypt scheme.jl:388-407; CRS scheme.jl:409 ---- */
-typedef struct mkt_client_party mkt_client_party;
 /* crs: [l_uni][N] ring words (MK schemes), filled from `seed` */
 int mkt_client_crs(const mkt_params *params, uint64_t seed, void *crs_out);
 /* one party's secret + evaluation keys; crs may be NULL for SK schemes; sigma_lwe/sigma_ring are the
  * absolute noise standard deviations alpha/beta of params.jl */
 int mkt_client_party_keygen(const mkt_params *params, uint64_t seed, int party, const void *crs,
                             double sigma_lwe, double sigma_ring, mkt_client_party **out);
+/* the same party WITHOUT the two large keys (bootstrapping key, key-switching key: mkt_client_brk / _ksk are empty):
+ * secrets, public key and relinearisation key only -- for mkt_keygen_device, which generates the large keys on the
+ * GPU from the same seeded streams (identical words to mkt_client_party_keygen) */
+int mkt_client_party_secrets(const mkt_params *params, uint64_t seed, int party, const void *crs,
+                             double sigma_lwe, double sigma_ring, mkt_client_party **out);
 int mkt_client_party_destroy(mkt_client_party *p);
 /* sizes in bytes / pointers to the flat key material (layouts above), valid until destroy */
 const uint32_t *mkt_client_lwekey(const mkt_client_party *p);             /* [n] 0/1 */

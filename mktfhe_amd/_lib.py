@@ -42,6 +42,8 @@ SYMBOLS = {
     "mkt_load_rlk": (_i, [_vp, _i, _vp, _vp, _i]),
     "mkt_load_pubkey": (_i, [_vp, _i, _vp, _i]),
     "mkt_load_crs": (_i, [_vp, _vp, _i]),
+    "mkt_keygen_device": (_i, [_vp, _i, _vp, _vp]),
+    "mkt_get_ksk": (_i, [_vp, _i, _vp]),
     "mkt_gate_batch": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _i]),
     "mkt_not_batch": (_i, [_vp, _vp, _sz, _i]),
     "mkt_bootstrap_batch": (_i, [_vp, _vp, _sz, _i]),
@@ -57,6 +59,7 @@ SYMBOLS = {
     "mkt_last_kernel_ms": (_i, [_vp, _i, C.POINTER(_dbl)]),
     "mkt_client_crs": (_i, [_pp, _u64, _vp]),
     "mkt_client_party_keygen": (_i, [_pp, _u64, _i, _vp, _dbl, _dbl, C.POINTER(_vp)]),
+    "mkt_client_party_secrets": (_i, [_pp, _u64, _i, _vp, _dbl, _dbl, C.POINTER(_vp)]),
     "mkt_client_party_destroy": (_i, [_vp]),
     "mkt_client_lwekey": (_vp, [_vp]),
     "mkt_client_brk": (_vp, [_vp, C.POINTER(_sz)]),

@@ -91,16 +91,6 @@ struct RingKey { std::vector<std::vector<int8_t>> z; };  // k polynomials, binar
 
 using namespace mkt;
 
-struct mkt_client_party {
-    mkt_params p;
-    Shape sh;
-    int party;
-    std::vector<uint32_t> lwekey;           // [n]
-    std::vector<std::vector<int8_t>> zring; // SK: k polys; CCS: 1; KMS: [0] = gsw key z', [1] = uni key z
-    std::vector<uint8_t> brk, rlk_d, rlk_f, pub;  // ring words at native width
-    std::vector<uint32_t> ksk;
-};
-
 namespace {
 
 void store_poly(std::vector<uint8_t> &dst, size_t poly_index, const uint64_t *v, int N, int W) {
@@ -158,8 +148,12 @@ int mkt_client_crs(const mkt_params *params, uint64_t seed, void *crs_out) {
     return MKT_OK;
 }
 
-int mkt_client_party_keygen(const mkt_params *params, uint64_t seed, int party, const void *crs,
-                            double sigma_lwe, double sigma_ring, mkt_client_party **out) {
+}  // extern "C"
+
+// heavy = false: secrets and the small keys only (public key, relinearisation key); the bootstrapping and
+// key-switching keys are then generated on the device (mkt_keygen_device) from the same seeded streams
+static int party_keygen_impl(const mkt_params *params, uint64_t seed, int party, const void *crs,
+                             double sigma_lwe, double sigma_ring, bool heavy, mkt_client_party **out) {
     if (!params || !out) return MKT_ERR_ARG;
     std::string why; if (validate_params(*params, why)) return MKT_ERR_ARG;
     const mkt_params &p = *params;
@@ -171,6 +165,7 @@ int mkt_client_party_keygen(const mkt_params *params, uint64_t seed, int party, 
     auto *K = new mkt_client_party();
     K->p = p; K->sh = sh; K->party = party;
     const uint64_t ps = seed * 0x100000001B3ull + (uint64_t)party + 1;
+    K->ps = ps; K->sigma_lwe = sigma_lwe; K->sigma_ring = sigma_ring; K->heavy = heavy;
 
     // ---- secret keys: key.jl:12-19 (binary), sampler.jl:7-21 (block binary), key.jl:52-87 (partial ring key)
     {
@@ -195,7 +190,8 @@ int mkt_client_party_keygen(const mkt_params *params, uint64_t seed, int party, 
     }
 
     // ---- bootstrapping key
-    if (p.scheme != MKT_CCS) {
+    if (!heavy) {
+    } else if (p.scheme != MKT_CCS) {
         // brk[i] = RGSW_z(s_i): keygen.jl:13-15,:39-41,:106-108,:143-145; gsw.jl:174-178; lev.jl:88-102
         const int kr = sh.kr, l = p.l_gsw, rows = (kr + 1) * l, polys = kr + 1;
         K->brk.assign((size_t)n * rows * polys * N * sh.word, 0);
@@ -273,7 +269,7 @@ int mkt_client_party_keygen(const mkt_params *params, uint64_t seed, int party, 
     }
 
     // ---- key-switching key: keygen.jl:17-23,:43-51,:75-79,:110-114,:147-151; lev.jl:31-37; lwe.jl:11-22
-    {
+    if (heavy) {
         const int f = p.f, logD = p.logD, dr = sh.ksk_drows, kk = sh.ksk_kr;
         const int zoff = is_kms(p.scheme) ? 1 : 0;
         const size_t n1 = (size_t)n + 1;
@@ -293,6 +289,18 @@ int mkt_client_party_keygen(const mkt_params *params, uint64_t seed, int party, 
     }
     *out = K;
     return MKT_OK;
+}
+
+extern "C" {
+
+int mkt_client_party_keygen(const mkt_params *params, uint64_t seed, int party, const void *crs,
+                            double sigma_lwe, double sigma_ring, mkt_client_party **out) {
+    return party_keygen_impl(params, seed, party, crs, sigma_lwe, sigma_ring, true, out);
+}
+
+int mkt_client_party_secrets(const mkt_params *params, uint64_t seed, int party, const void *crs,
+                             double sigma_lwe, double sigma_ring, mkt_client_party **out) {
+    return party_keygen_impl(params, seed, party, crs, sigma_lwe, sigma_ring, false, out);
 }
 
 int mkt_client_party_destroy(mkt_client_party *p) { delete p; return MKT_OK; }

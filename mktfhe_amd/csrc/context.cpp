@@ -450,6 +450,56 @@ int mkt_load_crs(mkt_ctx *c, const void *a, int fmt) {
     return r;
 }
 
+// Bootstrapping key and key-switching key of party `party` generated on the device from the party's secrets
+// (keygen.hip: the seeded streams of mkt_client_party_keygen, identical words), pre-transformed in place of an upload.
+int mkt_keygen_device(mkt_ctx *c, int party, const mkt_client_party *K, const void *crs) {
+    if (!c || !K || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    const mkt_params &p = c->p;
+    if (std::memcmp(&K->p, &p, sizeof(mkt_params)) != 0 || K->party != party) return fail(c, MKT_ERR_ARG, "mkt_keygen_device: the party's keys were made for other parameters / another party index");
+    const bool unienc = p.scheme == MKT_CCS;
+    if (unienc && !crs) return fail(c, MKT_ERR_ARG, "mkt_keygen_device: CCS needs the integer CRS");
+    DevGuard dg(c->device);
+    const int N = p.N, nz = (int)K->zring.size();
+    uint32_t *d_lwe = nullptr; int8_t *d_z = nullptr; void *d_crs_int = nullptr, *d_out = nullptr;
+    const size_t brk_polys_total = (size_t)p.n * c->sh.brk_polys;
+    auto cleanup = [&] { (void)hipFree(d_lwe); (void)hipFree(d_z); (void)hipFree(d_crs_int); (void)hipFree(d_out); };
+    hipError_t e = hipMalloc((void **)&d_lwe, (size_t)p.n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_z, (size_t)nz * N);
+    if (e == hipSuccess) e = hipMalloc(&d_out, brk_polys_total * poly_bytes(c));
+    if (e == hipSuccess && unienc) e = hipMalloc(&d_crs_int, (size_t)p.l_uni * poly_bytes(c));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lwe, K->lwekey.data(), (size_t)p.n * 4, hipMemcpyHostToDevice, c->stream);
+    for (int q = 0; q < nz && e == hipSuccess; q++) e = hipMemcpyAsync(d_z + (size_t)q * N, K->zring[q].data(), (size_t)N, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && unienc) e = hipMemcpyAsync(d_crs_int, crs, (size_t)p.l_uni * poly_bytes(c), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { cleanup(); return hipfail(c, e, "device keygen setup"); }
+    mktd::KeygenArgs a{};
+    a.ps = K->ps; a.N = N; a.n = p.n; a.W = p.W; a.f = p.f; a.logD = p.logD;
+    a.sigma_ring = K->sigma_ring; a.sigma_lwe = K->sigma_lwe;
+    a.lwekey = d_lwe; a.zring = d_z; a.crs = d_crs_int; a.out = d_out;
+    if (unienc) { a.kr = 1; a.l = p.l_uni; a.logB = p.logB_uni; a.zoff = 0; }
+    else { a.kr = c->sh.kr; a.l = p.l_gsw; a.logB = p.logB_gsw; a.zoff = 0; }
+    e = mktd::launch_keygen_brk(a, unienc ? 1 : 0, c->stream);
+    if (e == hipSuccess) e = mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->d_brk + (size_t)party * c->brk_party_cplx, brk_polys_total, 1, c->stream);
+    uint32_t *ksk = c->d_ksk + (size_t)party * c->ksk_party_words;
+    if (e == hipSuccess) e = hipMemsetAsync(ksk, 0, c->ksk_party_words * sizeof(uint32_t), c->stream);
+    a.zoff = mkt::is_kms(p.scheme) ? 1 : 0;      // the key switch targets the uni key of the KMS schemes
+    if (e == hipSuccess) e = mktd::launch_keygen_ksk(a, ksk, c->n1p, c->sh.ksk_kr, c->sh.ksk_drows, mkt::is_block(p.scheme) ? 1 : 0, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return hipfail(c, e, "device keygen");
+    c->brk_loaded[party] = 1; c->ksk_loaded[party] = 1;
+    return MKT_OK;
+}
+
+// debug / test read-back of a party's key-switching key in the host layout of mkt_load_ksk
+int mkt_get_ksk(mkt_ctx *c, int party, uint32_t *out_host) {
+    if (!c || !out_host || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    DevGuard dg(c->device);
+    const size_t rows = (size_t)c->sh.ksk_kr * c->p.N * c->sh.ksk_drows * c->p.f, n1 = (size_t)c->p.n + 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(out_host, n1 * 4, c->d_ksk + (size_t)party * c->ksk_party_words, (size_t)c->n1p * 4, n1 * 4, rows, hipMemcpyDeviceToHost));
+    return MKT_OK;
+}
+
 // ---- batched hot path ----
 
 int mkt_gate_batch(mkt_ctx *c, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem) {

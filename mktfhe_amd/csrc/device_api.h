@@ -84,6 +84,22 @@ struct KsArgs {
     int lmss;                 // LMSS flavour of the copy rule (global coefficient index across components)
 };
 
+// Evaluation-key generation on the device (keygen.hip): one party's secrets and the stream seed of client.cpp
+struct KeygenArgs {
+    uint64_t ps;                 // per-party stream seed (client.cpp: seed * 0x100000001B3 + party + 1)
+    int N, n, W;
+    int kr, l, logB;             // RGSW: RLWE length, gadget ; UniEnc: l_uni, logB_uni
+    int zoff;                    // first ring-key polynomial used
+    int f, logD;                 // key-switching gadget
+    double sigma_ring, sigma_lwe;
+    const uint32_t *lwekey;      // [n]
+    const int8_t *zring;         // [nz][N], entries 0/1
+    const void *crs;             // [l][N] ring words (UniEnc only)
+    void *out;                   // bootstrapping key, coefficient form, native word width
+};
+hipError_t launch_keygen_brk(const KeygenArgs &a, int unienc, hipStream_t s);
+hipError_t launch_keygen_ksk(const KeygenArgs &a, uint32_t *ksk, int n1p, int kk, int dr, int is_block, hipStream_t s);
+
 hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, hipStream_t s);
 hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, int to_device, hipStream_t s);
 hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void *p, size_t B, hipStream_t s);

@@ -61,17 +61,23 @@ class PartyKeys:
     """One party's secret and evaluation keys (party_keygen, scheme.jl:227,:273,:324; setup for the
     single-key schemes, scheme.jl:151,:190).  Evaluation keys are in integer (coefficient) form."""
 
-    def __init__(self, params: Params, seed=0, party=0, crs=None):
-        self.params, self.party = params, party
+    def __init__(self, params: Params, seed=0, party=0, crs=None, secrets_only=False):
+        """secrets_only: leave out the two large keys (bootstrapping key, key-switching key); they are then generated
+        on the GPU by Scheme.keygen_device from the same seeded streams (identical words)"""
+        self.params, self.party, self.secrets_only = params, party, secrets_only
         h = C.c_void_p()
-        crs_p = _np_ptr(np.ascontiguousarray(crs, dtype=params.ring_dtype)) if crs is not None else None
-        check(_lib.lib().mkt_client_party_keygen(C.byref(params.c()), seed, party, crs_p,
-                                                 params.alpha, params.beta, C.byref(h)))
+        self._crs = np.ascontiguousarray(crs, dtype=params.ring_dtype) if crs is not None else None
+        crs_p = _np_ptr(self._crs) if crs is not None else None
+        fn = _lib.lib().mkt_client_party_secrets if secrets_only else _lib.lib().mkt_client_party_keygen
+        check(fn(C.byref(params.c()), seed, party, crs_p, params.alpha, params.beta, C.byref(h)))
         self.h = h
 
     def __del__(self):
-        if getattr(self, "h", None):
-            _lib.lib().mkt_client_party_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            try:
+                _lib.lib().mkt_client_party_destroy(self.h)
+            except Exception:       # interpreter shutdown: the library may already be gone
+                pass
             self.h = None
 
     def _buf(self, fn, dtype):
@@ -107,9 +113,9 @@ class PartyKeys:
         return self._buf(_lib.lib().mkt_client_pubkey, self.params.ring_dtype)
 
 
-def party_keygen(a, params: Params, seed=0, party=0):
+def party_keygen(a, params: Params, seed=0, party=0, secrets_only=False):
     """scheme.jl:227/:273/:324 party_keygen(a, params) -> PartyKeys (lwekey + bootstrapping key)"""
-    return PartyKeys(params, seed=seed, party=party, crs=a)
+    return PartyKeys(params, seed=seed, party=party, crs=a, secrets_only=secrets_only)
 
 
 def lwe_encrypt(m, key: PartyKeys, params: Params, seed=0):
@@ -176,6 +182,22 @@ class Scheme:
                                     _np_ptr(np.ascontiguousarray(rlk_f, dtype=kd)), fmt))
         if pubkey is not None:
             self._ck(L.mkt_load_pubkey(self.h, party, _np_ptr(np.ascontiguousarray(pubkey, dtype=kd)), fmt))
+
+    def keygen_device(self, party, keys: PartyKeys):
+        """keygen.jl:13-23 etc. on the GPU: bootstrapping + key-switching key of `party` from its secrets (the small
+        keys -- public key, relinearisation key -- are uploaded from `keys`)"""
+        L = _lib.lib()
+        crs_p = _np_ptr(keys._crs) if (self.params.scheme == CCS and keys._crs is not None) else None
+        self._ck(L.mkt_keygen_device(self.h, party, keys.h, crs_p))
+        self.load_party(party, rlk_d=keys.rlk_d, rlk_f=keys.rlk_f, pubkey=keys.pubkey)
+
+    def get_ksk(self, party):
+        p = self.params
+        D = 1 << p.logD
+        rows = (1 if p.multikey else p.k) * p.N * (D // 2 if p.scheme in (LMSS, KMS_BLOCK) else D - 1) * p.f
+        out = np.empty((rows, p.n + 1), dtype=np.uint32)
+        self._ck(_lib.lib().mkt_get_ksk(self.h, party, _np_ptr(out)))
+        return out
 
     def load_crs(self, a, fmt=FMT_INT_COEFF):
         kd = np.complex128 if fmt == FMT_F64_FFT else self.params.ring_dtype
@@ -310,15 +332,17 @@ def setup(params: Params, keys=None, a=None, device=0, seed=0):
     scheme.jl:244 / :292 / :343 setup(a, btk, params) -> scheme for the multi-key ones
     (keys = list of PartyKeys, a = CRS).  The evaluation keys are uploaded and pre-transformed
     on `device`."""
+    def install(sch, i, kk):      # keys made with secrets_only=True get their large keys generated on the device
+        (sch.keygen_device if kk.secrets_only else sch.load_party)(i, kk)
     if not params.multikey:
         ks = keys if keys is not None else PartyKeys(params, seed=seed, party=0)
         sch = Scheme(params, device=device)
-        sch.load_party(0, ks)
+        install(sch, 0, ks)
         return ks, sch
     sch = Scheme(params, device=device)
     sch.load_crs(a)
     for i, kk in enumerate(keys):
-        sch.load_party(i, kk)
+        install(sch, i, kk)
     return sch
 
 

@@ -491,3 +491,44 @@ def test_two_contexts_two_host_threads(require_gpu):
     assert np.array_equal(xd.cpu().numpy().view(np.uint32), ref)
     for w in work:
         w[0].close()
+
+
+KEYGEN_SETS = [
+    mk.CGGIparam.scaled(n=20, N=256), mk.CGGIparam.scaled(n=16, N=256, k=2), mk.Blockparam.scaled(n=30, N=256, blk_d=10),
+    mk.KMS2party.scaled(n=16, N=256), mk.KMS2partyblock.scaled(n=24, N=256, blk_d=8), mk.CCS2party.scaled(n=12, N=256),
+    mk.KMS4party.scaled(n=10, N=512), mk.CCS4party.scaled(n=6, N=1024), mk.CGGIparam, mk.KMS2party,
+]
+
+
+@pytest.mark.parametrize("p", KEYGEN_SETS, ids=lambda p: f"{p.name}-n{p.n}-N{p.N}")
+def test_device_keygen_matches_host_keygen(require_gpu, p):
+    """the bootstrapping key and the key-switching key generated on the GPU (mkt_keygen_device) are
+    the host generator's words exactly -- same seeded streams, exact integer arithmetic: the key-switching key is
+    compared word for word, the bootstrapping key through its pre-transformed effect (every stage output and gate of
+    a scheme keyed on the device equals the scheme loaded with host keys, hence the oracle)."""
+    seed = 77
+    crs = mk.CRS(p, seed) if p.multikey else None
+    host = [mk.party_keygen(crs, p, seed=seed, party=i) for i in range(p.nparty)]
+    secr = [mk.party_keygen(crs, p, seed=seed, party=i, secrets_only=True) for i in range(p.nparty)]
+    assert all(s.brk is None and s.ksk is None for s in secr)
+    sh = gpu_scheme(p, crs, host)
+    sd = gpu_scheme(p, crs, secr)                                   # setup() generates the large keys on the device
+    for i in range(p.nparty):
+        assert np.array_equal(sd.get_ksk(i), sh.get_ksk(i)), f"ksk party {i}"
+        assert np.array_equal(sh.get_ksk(i).ravel(), host[i].ksk), "read-back layout"
+    B = 5
+    bits = np.random.default_rng(78).integers(0, 2, 2 * B + 1).astype(bool)
+    c = encrypt_bits(p, secr, bits, seed=7800)
+    assert np.array_equal(c, encrypt_bits(p, host, bits, seed=7800))   # same secrets
+    x, y = c[:B], c[B + 1:]
+    lin = np.stack([O.gate_linear(0, x[j], y[j]) for j in range(B)])
+    at, bt = sh.modswitch(lin)
+    acc0 = np.zeros((B, (1 + (p.k)) * p.N), dtype=p.ring_dtype).reshape(B, -1)
+    rng = np.random.default_rng(79)
+    acc0 = rng.integers(0, 2**32, acc0.shape, dtype=np.uint64).astype(p.ring_dtype)     # arbitrary accumulator
+    assert np.array_equal(sd.blindrotate_(at, acc0.copy()), sh.blindrotate_(at, acc0.copy())), "blind rotation (bootstrapping key)"
+    for op in (0, 3):
+        out_d = sd.gate(op, x, y)
+        assert np.array_equal(out_d, sh.gate(op, x, y))
+        assert np.array_equal(mk.lwe_decrypt(out_d, secr if p.multikey else secr[0], p), GATE_FUNCS[op](bits[:B], bits[B + 1:]))
+    sh.close(); sd.close()
