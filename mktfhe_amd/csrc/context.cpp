@@ -169,8 +169,7 @@ int check_ready(mkt_ctx *c, bool need_brk, bool need_ksk) {
 }
 
 int unsupported_scheme(mkt_ctx *c) {
-    if (c->p.scheme == MKT_CGGI && c->p.k > 3) return fail(c, MKT_ERR_UNSUPPORTED, "CGGI is implemented for RLWE length k <= 3");
-    if (c->p.scheme == MKT_LMSS && c->p.k != 1) return fail(c, MKT_ERR_UNSUPPORTED, "LMSS is implemented for RLWE length k = 1");
+    if ((c->p.scheme == MKT_CGGI || c->p.scheme == MKT_LMSS) && c->p.k > 3) return fail(c, MKT_ERR_UNSUPPORTED, "CGGI / LMSS are implemented for RLWE length k <= 3");
     return MKT_OK;
 }
 
@@ -206,7 +205,7 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         mktd::RotArgs a = rot_args(c, lwe, stride, pre);
         a.init_mode = 0; a.out_mode = 0; a.acc_io = acc;
         Timer tm(c, 1);
-        if (p.k > 1) {   // general RLWE length (CGGI only)
+        if (p.k > 1) {   // general RLWE length (CGGI, LMSS)
             HIPCHK(c, mktd::launch_blindrotate_kr(c->logM, p.W, p.k, a, B, c->stream));
             return MKT_OK;
         }

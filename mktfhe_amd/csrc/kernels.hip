@@ -483,12 +483,14 @@ void blindrotate_k1_kernel(const RotArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// CGGI blind rotation with RLWE length KR > 1 (bootstrapping.jl:32-76 with k = KR): the general-k form of the
-// kernel above for the plain single-key scheme; no shipped parameter set uses it (params.jl:1-13 have k = 1),
-// so it is kept simple: one transform at a time, KR+1 accumulators in registers.
+// CGGI / LMSS blind rotation with RLWE length KR > 1 (bootstrapping.jl:32-76, :114-165 with k = KR): the general-k
+// form of the kernel above for the plain single-key schemes; no shipped parameter set uses it (params.jl:1-13 have
+// k = 1), so it is kept simple: one transform at a time, KR+1 accumulators in registers.  BLK (LMSS): the key bits of
+// a block share one decomposition of the accumulator (:131-140) and one inverse transform (:162); the digit transforms
+// are recomputed per key bit here (same values) instead of being held for the whole block.
 // brk layout [n][(KR+1)*l rows][KR+1 polys][M] (device point order), acc [rot][KR+1][N].
 // ------------------------------------------------------------------------------------------------
-template <int LOGM, typename WORD, int KR>
+template <int LOGM, typename WORD, int KR, bool BLK>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(const RotArgs a) {
     using P = Plan<LOGM, LOGR>;
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, NP = KR + 1;
@@ -512,49 +514,81 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(
 #pragma unroll
         for (int e = 0; e < R; e++) { acc[c][e][0] = accg[c * N + e * NT + t]; acc[c][e][1] = accg[c * N + M + e * NT + t]; }
     const int msbit = 32 - a.logN - 1;
-    for (int idx = 0; idx < a.n; idx++) {
-        const uint32_t v0 = at_src[idx];
-        const uint32_t at = a.pre_switched ? v0 : divbits<uint32_t>(v0, msbit);
-        if (at == 0) continue;                                           // :48
-        cplx tacc[NP][R];
+    const int blen = BLK ? a.blk_len : 1;
+    for (int blk = 0; blk < a.n / blen; blk++) {
+        cplx t2[BLK ? NP : 1][R];                                        // :142 tacc2 (LMSS only)
+        if (BLK) {
 #pragma unroll
-        for (int q = 0; q < NP; q++)
+            for (int q = 0; q < NP; q++)
 #pragma unroll
-            for (int e = 0; e < R; e++) { tacc[q][e].re = 0.0; tacc[q][e].im = 0.0; }
-        const cplx *brk = a.brk + (size_t)idx * NP * l * NP * M;
+                for (int e = 0; e < R; e++) { t2[BLK ? q : 0][e].re = 0.0; t2[BLK ? q : 0][e].im = 0.0; }
+        }
+        bool any = false;
+        for (int qb = 0; qb < blen; qb++) {
+            const int idx = blk * blen + qb;
+            const uint32_t v0 = at_src[idx];
+            const uint32_t at = a.pre_switched ? v0 : divbits<uint32_t>(v0, msbit);
+            if (at == 0) continue;                                       // :48 / :145
+            any = true;
+            cplx tacc[NP][R];
 #pragma unroll
-        for (int c = 0; c < NP; c++) {                                   // b digits, then a_0, a_1 ... (:63-68)
-            WORD tp[R][2];
+            for (int q = 0; q < NP; q++)
 #pragma unroll
-            for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(acc[c][e][0]); tp[e][1] = gd.prep(acc[c][e][1]); }
-            for (int j = 0; j < l; j++) {
-                cplx z[R];
+                for (int e = 0; e < R; e++) { tacc[q][e].re = 0.0; tacc[q][e].im = 0.0; }
+            const cplx *brk = a.brk + (size_t)idx * NP * l * NP * M;
 #pragma unroll
-                for (int e = 0; e < R; e++) {
-                    const int d0 = gd.digit(tp[e][0], j), d1 = gd.digit(tp[e][1], j);
-                    cplx v; v.re = (double)d0; v.im = (double)(-d1);
-                    z[e] = cmul(v, a.tw.roots[e * NT + t]);
+            for (int c = 0; c < NP; c++) {                               // b digits, then a_0, a_1 ... (:63-68 / :146-154)
+                WORD tp[R][2];
+#pragma unroll
+                for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(acc[c][e][0]); tp[e][1] = gd.prep(acc[c][e][1]); }
+                for (int j = 0; j < l; j++) {
+                    cplx z[R];
+#pragma unroll
+                    for (int e = 0; e < R; e++) {
+                        const int d0 = gd.digit(tp[e][0], j), d1 = gd.digit(tp[e][1], j);
+                        cplx v; v.re = (double)d0; v.im = (double)(-d1);
+                        z[e] = cmul(v, a.tw.roots[e * NT + t]);
+                    }
+                    fft_forward1<LOGM>(z, psi_l, lds, t, xs);
+                    const cplx *row = brk + (size_t)(c * l + j) * NP * M;
+#pragma unroll
+                    for (int q = 0; q < NP; q++)
+#pragma unroll
+                        for (int e = 0; e < R; e++) tacc[q][e] = cadd(tacc[q][e], cmul(z[e], row[(size_t)q * M + dp[e]]));
                 }
-                fft_forward1<LOGM>(z, psi_l, lds, t, xs);
-                const cplx *row = brk + (size_t)(c * l + j) * NP * M;
+            }
+            const cplx *mono = a.monomial + (size_t)(at - 1) * M;
+            if (BLK) {                                                   // :157 tacc2 += monomial * tacc
 #pragma unroll
                 for (int q = 0; q < NP; q++)
 #pragma unroll
-                    for (int e = 0; e < R; e++) tacc[q][e] = cadd(tacc[q][e], cmul(z[e], row[(size_t)q * M + dp[e]]));
+                    for (int e = 0; e < R; e++) t2[BLK ? q : 0][e] = cadd(t2[BLK ? q : 0][e], cmul(mono[dp[e]], tacc[q][e]));
+            } else {
+#pragma unroll
+                for (int q = 0; q < NP; q++) {                           // :71-73
+                    cplx s[R];
+#pragma unroll
+                    for (int e = 0; e < R; e++) s[e] = cmul(mono[dp[e]], tacc[q][e]);
+                    fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(s), psi_l, lds, t, xs.lx);
+#pragma unroll
+                    for (int e = 0; e < R; e++) {
+                        const cplx v = cmul(s[e], a.tw.rootsinv[e * NT + t]);
+                        acc[q][e][0] = (WORD)(acc[q][e][0] + native<WORD>(v.re));
+                        acc[q][e][1] = (WORD)(acc[q][e][1] + native<WORD>(-v.im));
+                    }
+                }
             }
         }
-        const cplx *mono = a.monomial + (size_t)(at - 1) * M;
+        if (BLK && any) {                                                // :162-163 (an all-zero block adds native(0) = 0)
 #pragma unroll
-        for (int q = 0; q < NP; q++) {                                   // :71-73
-            cplx s[R];
+            for (int q = 0; q < NP; q++) {
+                fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(t2[BLK ? q : 0]), psi_l, lds, t, xs.lx);
 #pragma unroll
-            for (int e = 0; e < R; e++) s[e] = cmul(mono[dp[e]], tacc[q][e]);
-            fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(s), psi_l, lds, t, xs.lx);
-#pragma unroll
-            for (int e = 0; e < R; e++) {
-                const cplx v = cmul(s[e], a.tw.rootsinv[e * NT + t]);
-                acc[q][e][0] = (WORD)(acc[q][e][0] + native<WORD>(v.re));
-                acc[q][e][1] = (WORD)(acc[q][e][1] + native<WORD>(-v.im));
+                for (int e = 0; e < R; e++) {
+                    const cplx v = cmul(t2[BLK ? q : 0][e], a.tw.rootsinv[e * NT + t]);
+                    acc[q][e][0] = (WORD)(acc[q][e][0] + native<WORD>(v.re));
+                    acc[q][e][1] = (WORD)(acc[q][e][1] + native<WORD>(-v.im));
+                }
             }
         }
     }
@@ -1125,22 +1159,27 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
     return hipSuccess;
 }
 
-template <int LM, typename WORD, int KR>
+template <int LM, typename WORD, int KR, bool BLK>
 static hipError_t launch_kr_one(const RotArgs &a, size_t nrot, hipStream_t s) {
     using P = Plan<LM, LOGR>;
     constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
-    hipError_t e = set_lds(blindrotate_kr_kernel<LM, WORD, KR>, LB);
+    hipError_t e = set_lds(blindrotate_kr_kernel<LM, WORD, KR, BLK>, LB);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((blindrotate_kr_kernel<LM, WORD, KR>), dim3((unsigned)nrot), dim3(P::NT), LB, s, a);
+    hipLaunchKernelGGL((blindrotate_kr_kernel<LM, WORD, KR, BLK>), dim3((unsigned)nrot), dim3(P::NT), LB, s, a);
     return hipGetLastError();
+}
+template <int LM, typename WORD>
+static hipError_t launch_kr_word(int kr, const RotArgs &a, size_t nrot, hipStream_t s) {
+    if (a.blk_len > 1) return kr == 2 ? launch_kr_one<LM, WORD, 2, true>(a, nrot, s) : launch_kr_one<LM, WORD, 3, true>(a, nrot, s);
+    return kr == 2 ? launch_kr_one<LM, WORD, 2, false>(a, nrot, s) : launch_kr_one<LM, WORD, 3, false>(a, nrot, s);
 }
 
 hipError_t launch_blindrotate_kr(int logM, int W, int kr, const RotArgs &a, size_t nrot, hipStream_t s) {
     if (!nrot) return hipSuccess;
     if (kr < 2 || kr > 3) return hipErrorInvalidValue;
     MKT_DISPATCH_LOGM(logM, {
-        if (W == 64) return kr == 2 ? launch_kr_one<LM, uint64_t, 2>(a, nrot, s) : launch_kr_one<LM, uint64_t, 3>(a, nrot, s);
-        return kr == 2 ? launch_kr_one<LM, uint32_t, 2>(a, nrot, s) : launch_kr_one<LM, uint32_t, 3>(a, nrot, s);
+        if (W == 64) return launch_kr_word<LM, uint64_t>(kr, a, nrot, s);
+        return launch_kr_word<LM, uint32_t>(kr, a, nrot, s);
     });
     return hipSuccess;
 }

@@ -103,6 +103,9 @@ SMALL = [
     mk.CCS16party.scaled(n=2, N=256),
     mk.CGGIparam.scaled(n=16, N=256, k=2),                  # RLWE length > 1 (TFHEparams_bin.k, scheme.jl:6-20)
     mk.CGGIparam.scaled(n=12, N=512, k=3, l_gsw=2, logB_gsw=10),
+    mk.Blockparam.scaled(n=30, N=256, blk_d=10, k=2),       # LMSS with RLWE length > 1 (TFHEparams_block.k)
+    mk.Blockparam.scaled(n=300, N=128, blk_d=100, k=3),     # n > N: the key switch copies whole components (:179-186)
+    mk.Blockparam.scaled(n=150, N=128, blk_d=50, k=2, blk_len=3),
 ]
 
 
@@ -495,6 +498,7 @@ def test_two_contexts_two_host_threads(require_gpu):
 
 KEYGEN_SETS = [
     mk.CGGIparam.scaled(n=20, N=256), mk.CGGIparam.scaled(n=16, N=256, k=2), mk.Blockparam.scaled(n=30, N=256, blk_d=10),
+    mk.Blockparam.scaled(n=150, N=128, blk_d=50, k=2),
     mk.KMS2party.scaled(n=16, N=256), mk.KMS2partyblock.scaled(n=24, N=256, blk_d=8), mk.CCS2party.scaled(n=12, N=256),
     mk.KMS4party.scaled(n=10, N=512), mk.CCS4party.scaled(n=6, N=1024), mk.CGGIparam, mk.KMS2party,
 ]
