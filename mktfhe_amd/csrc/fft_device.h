@@ -40,15 +40,35 @@ __device__ __forceinline__ cplx cmul_conj(const cplx x, const cplx w) {
 __device__ __forceinline__ cplx cadd(const cplx x, const cplx y) { cplx r; r.re = x.re + y.re; r.im = x.im + y.im; return r; }
 __device__ __forceinline__ cplx csub(const cplx x, const cplx y) { cplx r; r.re = x.re - y.re; r.im = x.im - y.im; return r; }
 
+#ifndef MKT_PERMLANE_SWAP
+#define MKT_PERMLANE_SWAP 1   // gfx950 v_permlane16_swap / v_permlane32_swap for exchanges along lane bits 4 and 5
+#endif
+
+// Schedule of a transform: NPASS passes over 2-bit (LOGR-bit) windows [lo, lo + LOGR) of the point index, from the top
+// window down to [0, LOGR).  When LOGR does not divide LOGM one pass overlaps its predecessor and performs the stages
+// of its fresh bits only.  For 4 points per thread and odd LOGM that single-stage pass sits at window OVL = 4
+// (sequence ... 7, 5, 4, 2, 0): the one-bit exchange in front of it then trades thread bit 4 = lane bit 4, which
+// v_permlane16_swap does in one instruction per dword (at window 0 it is lane bit 0: a DPP move plus three selects).
 template <int LOGM, int LOGR, int NB = 1>
 struct Plan {
     static constexpr int M = 1 << LOGM, R = 1 << LOGR, NT = M / R;
     static constexpr int NPASS = (LOGM + LOGR - 1) / LOGR;
     static_assert(LOGM >= LOGR, "transform smaller than a thread's share");
-    __host__ __device__ static constexpr int lo(int p) { return (LOGM - (p + 1) * LOGR) < 0 ? 0 : (LOGM - (p + 1) * LOGR); }
-    __host__ __device__ static constexpr int nst(int p) { return p < NPASS - 1 ? LOGR : LOGM - (NPASS - 1) * LOGR; }
+    static constexpr int OVL = (MKT_PERMLANE_SWAP && LOGR == 2 && (LOGM & 1) && LOGM >= 7) ? 4 : 0;
+    static constexpr int PA = OVL ? (LOGM - OVL - 1) / LOGR : NPASS - 1;        // index of the single-stage / last pass
+    __host__ __device__ static constexpr int lo(int p) {
+        if (OVL) return p < PA ? LOGM - (p + 1) * LOGR : (p == PA ? OVL : (NPASS - 1 - p) * LOGR);
+        return (LOGM - (p + 1) * LOGR) < 0 ? 0 : (LOGM - (p + 1) * LOGR);
+    }
+    __host__ __device__ static constexpr int nst(int p) {
+        if (OVL) return p == PA ? 1 : LOGR;
+        return p < NPASS - 1 ? LOGR : LOGM - (NPASS - 1) * LOGR;
+    }
     // highest stage bit of pass p
-    __host__ __device__ static constexpr int hib(int p) { return p < NPASS - 1 ? lo(p) + LOGR - 1 : nst(p) - 1; }
+    __host__ __device__ static constexpr int hib(int p) {
+        if (OVL) return p == PA ? OVL : lo(p) + LOGR - 1;
+        return p < NPASS - 1 ? lo(p) + LOGR - 1 : nst(p) - 1;
+    }
     // LDS staging: NB transforms side by side, two buffers (one barrier per exchange)
     static constexpr int BUF = NB * M;
     static constexpr int LDS_CPLX = 2 * BUF;
@@ -114,12 +134,23 @@ __device__ __forceinline__ void swap_pair(cplx &x0, cplx &x1, bool b, const Lane
     // lane with b = 0 gives x1 and receives the partner's x0 into x1; lane with b = 1 gives x0, receives into x0
     int a0[4], a1[4];
     __builtin_memcpy(a0, &x0, 16); __builtin_memcpy(a1, &x1, 16);
+    if constexpr (MKT_PERMLANE_SWAP && (D == 16 || D == 32)) {
+        // gfx950 v_permlane16_swap / v_permlane32_swap: the odd rows (upper half) of the first register trade places
+        // with the even rows (lower half) of the second -- exactly this exchange, one instruction per dword, no selects
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const int snd = b ? a0[w] : a1[w];
-        const int rcv = xor_lane<D>(snd, lx);
-        a0[w] = b ? rcv : a0[w];
-        a1[w] = b ? a1[w] : rcv;
+        for (int w = 0; w < 4; w++) {
+            auto r = D == 16 ? __builtin_amdgcn_permlane16_swap((unsigned)a0[w], (unsigned)a1[w], false, false)
+                             : __builtin_amdgcn_permlane32_swap((unsigned)a0[w], (unsigned)a1[w], false, false);
+            a0[w] = (int)r[0]; a1[w] = (int)r[1];
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int snd = b ? a0[w] : a1[w];
+            const int rcv = xor_lane<D>(snd, lx);
+            a0[w] = b ? rcv : a0[w];
+            a1[w] = b ? a1[w] : rcv;
+        }
     }
     __builtin_memcpy(&x0, a0, 16); __builtin_memcpy(&x1, a1, 16);
 }
@@ -135,10 +166,11 @@ __device__ __forceinline__ void exchange_lane_full(cplx (&z)[NB][4], const LaneX
         swap_pair<(2 << LO)>(z[nb][1], z[nb][3], b1, lx);
     }
 }
-// odd last window, forward direction: slots (b2,b1) with thread bit0 = b0  ->  slots (b1,b0) with thread bit0 = b2
-template <int NB>
+// single-stage window [lo+1, lo+3) -> [lo, lo+2), lo = LB (a lane bit), forward direction:
+// slots (b2,b1) with thread bit LB = b0  ->  slots (b1,b0) with thread bit LB = b2
+template <int NB, int LB>
 __device__ __forceinline__ void exchange_lane_odd_fwd(cplx (&z)[NB][4], const LaneX &lx) {
-    const bool lam = lx.lane & 1;
+    const bool lam = (lx.lane >> LB) & 1;
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         cplx n[4];
@@ -146,7 +178,7 @@ __device__ __forceinline__ void exchange_lane_odd_fwd(cplx (&z)[NB][4], const La
         for (int b1 = 0; b1 < 2; b1++) {
             cplx A = z[nb][b1], Bq = z[nb][2 + b1];                // old slots (b2 = 0, b1), (b2 = 1, b1)
             // keep the one with b2 == lam, trade the other: swap_pair gives/receives exactly that
-            swap_pair<1>(A, Bq, lam, lx);                          // lam = 0: receives into Bq ; lam = 1: receives into A
+            swap_pair<(1 << LB)>(A, Bq, lam, lx);                          // lam = 0: receives into Bq ; lam = 1: receives into A
             // after the swap: lam = 0 holds A = own(0,b1), Bq = partner's (0,b1) ; lam = 1 holds A = partner's (1,b1), Bq = own (1,b1)
             n[2 * b1 + 0] = A;                                     // new slot (b1, b0 = 0): b0 = thread bit of the source
             n[2 * b1 + 1] = Bq;                                    // new slot (b1, b0 = 1)
@@ -156,16 +188,16 @@ __device__ __forceinline__ void exchange_lane_odd_fwd(cplx (&z)[NB][4], const La
     }
 }
 // inverse direction: slots (b1,b0) with thread bit0 = b2  ->  slots (b2,b1) with thread bit0 = b0
-template <int NB>
+template <int NB, int LB>
 __device__ __forceinline__ void exchange_lane_odd_inv(cplx (&z)[NB][4], const LaneX &lx) {
-    const bool lam = lx.lane & 1;
+    const bool lam = (lx.lane >> LB) & 1;
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         cplx n[4];
 #pragma unroll
         for (int b1 = 0; b1 < 2; b1++) {
             cplx A = z[nb][2 * b1], Bq = z[nb][2 * b1 + 1];        // old slots (b1, b0 = 0), (b1, b0 = 1)
-            swap_pair<1>(A, Bq, lam, lx);
+            swap_pair<(1 << LB)>(A, Bq, lam, lx);
             n[b1] = A;                                             // new slot (b2 = 0, b1)
             n[2 + b1] = Bq;                                        // new slot (b2 = 1, b1)
         }
@@ -187,8 +219,8 @@ struct Route {
     __host__ __device__ static constexpr int of(int lo_a, int lo_b) {
         const int lomin = lo_a < lo_b ? lo_a : lo_b, diff = lo_a < lo_b ? lo_b - lo_a : lo_a - lo_b;
         constexpr int MODE = MKT_LANE_EXCHANGE == 4 ? ((LOGM & 1) ? 2 : 1) : MKT_LANE_EXCHANGE;
-        if ((MODE == 1 || (MODE == 3 && lomin == 0)) && LOGR == 2 && diff == 2 && lomin + 2 <= LANEBITS && lomin + 2 <= 5) return 1;
-        if (MODE >= 1 && LOGR == 2 && diff == 1 && lomin == 0 && LANEBITS >= 1) return 2;
+        if ((MODE == 1 || (MODE == 3 && lomin == 0)) && LOGR == 2 && diff == 2 && lomin + 2 <= LANEBITS && lomin + 2 <= (MKT_PERMLANE_SWAP ? 6 : 5)) return 1;
+        if (MODE >= 1 && LOGR == 2 && diff == 1 && lomin == P::OVL && LANEBITS >= lomin + 1) return 2;
         return 0;
     }
     // staging buffer (pass parity) of the first / last LDS exchange of a forward and of an inverse transform, -1 if none
@@ -207,7 +239,7 @@ template <int LOGM, int LOGR, int NB, int LO_FROM, int LO_TO, bool FWD, int PASS
 __device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *lds, int t, const LaneX &lx) {
     constexpr int R = Route<LOGM, LOGR>::of(LO_FROM, LO_TO);
     if constexpr (R == 1) exchange_lane_full<(LO_FROM < LO_TO ? LO_FROM : LO_TO), NB>(z, lx);
-    else if constexpr (R == 2) { if constexpr (FWD) exchange_lane_odd_fwd<NB>(z, lx); else exchange_lane_odd_inv<NB>(z, lx); }
+    else if constexpr (R == 2) { constexpr int LB = Plan<LOGM, LOGR>::OVL; if constexpr (FWD) exchange_lane_odd_fwd<NB, LB>(z, lx); else exchange_lane_odd_inv<NB, LB>(z, lx); }
     else exchange_lds<LOGM, LOGR, NB>(z, lds + (PASS & 1) * Plan<LOGM, LOGR, NB>::BUF, t, LO_FROM, LO_TO);
 }
 

@@ -297,6 +297,9 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 // and the transform-domain accumulator stay in registers for all n CMux steps; LDS only stages the
 // in-transform exchanges.  LB = block length (1 for the plain schemes).
 // ------------------------------------------------------------------------------------------------
+#ifndef MKT_ROT_BT
+#define MKT_ROT_BT 1     // also specialise the gadget base where the length is specialised (l = 2, logB = 16 on the 64-bit ring)
+#endif
 #ifndef MKT_ROT_LT
 #define MKT_ROT_LT 1
 #endif
@@ -311,7 +314,7 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 // builds that stopped at ~186 or chose <= 168 for a third wave LDS cannot host ran up to 25 % slower
 template <int LOGM, int NB> struct RotOcc { static constexpr int MINW = (LOGM >= 10 && NB == 1 && MKT_LOGR == 2) ? 3 : MKT_ROT_MINW; };
 
-template <int LOGM, typename WORD, int LB, int LR, int NB, int LT>
+template <int LOGM, typename WORD, int LB, int LR, int NB, int LT, int BT>
 __global__ __launch_bounds__((Plan<LOGM, LR>::NT)) __attribute__((amdgpu_waves_per_eu(RotOcc<LOGM, NB>::MINW, RotOcc<LOGM, NB>::MINW)))
 void blindrotate_k1_kernel(const RotArgs a) {
     using P = Plan<LOGM, LR, NB>;   // NB transforms at a time share twiddle loads and barriers
@@ -344,7 +347,8 @@ void blindrotate_k1_kernel(const RotArgs a) {
     const int party = a.slot_party[slot], row = a.slot_row[slot];
     const uint32_t *at_src = a.lwe + gate * (size_t)a.lwe_stride + (size_t)party * a.n;
     const cplx *brk = a.brk + (size_t)party * a.brk_party_stride;
-    const Gadget<WORD> gd(a.l, a.logB);
+    // LT, BT > 0: gadget length and base known at compile time -- every digit shift / mask is an immediate
+    const Gadget<WORD> gd(LT ? LT : a.l, (LT && BT) ? BT : a.logB);
     const int l = LT ? LT : a.l;   // LT > 0: gadget length known at compile time, the digit loop unrolls fully
 
     WORD acc[2][R][2];
@@ -1105,13 +1109,13 @@ hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int log
     return hipGetLastError();
 }
 
-template <int LM, typename WORD, int LB, int LR, int NB, int LT>
+template <int LM, typename WORD, int LB, int LR, int NB, int LT, int BT = 0>
 static hipError_t launch_rot_lt(const RotArgs &a, size_t nrot, hipStream_t s) {
     using P = Plan<LM, LR, NB>;
     const size_t lds_bytes = P::LDS_BYTES + (MKT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
-    hipError_t e = set_lds(blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT>, lds_bytes);
+    hipError_t e = set_lds(blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT, BT>, lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT>), dim3((unsigned)nrot), dim3(P::NT), lds_bytes, s, a);
+    hipLaunchKernelGGL((blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT, BT>), dim3((unsigned)nrot), dim3(P::NT), lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -1122,6 +1126,7 @@ static hipError_t launch_rot_one(const RotArgs &a, size_t nrot, hipStream_t s) {
         // gadget length known at compile time (fully unrolled digit loop): measured +8 % at M = 512, l = 2
         // (15.2 -> 14.0 ms, KMS k=2 N=1024) but -4..-7 % at l = 3, so only that case is specialised
         if constexpr (LB == 1 && LM == 9) {
+            if (MKT_ROT_BT && a.l == 2 && a.logB == 16 && sizeof(WORD) == 8) return launch_rot_lt<LM, WORD, LB, LR, NB, 2, 16>(a, nrot, s);
             if (a.l == 2) return launch_rot_lt<LM, WORD, LB, LR, NB, 2>(a, nrot, s);
         }
 #endif
