@@ -218,8 +218,8 @@ struct Route {
     static constexpr int LANEBITS = (LOGM - LOGR) < 6 ? (LOGM - LOGR) : 6;   // thread bits that are lane bits
     __host__ __device__ static constexpr int of(int lo_a, int lo_b) {
         const int lomin = lo_a < lo_b ? lo_a : lo_b, diff = lo_a < lo_b ? lo_b - lo_a : lo_a - lo_b;
-        constexpr int MODE = MKT_LANE_EXCHANGE == 4 ? ((LOGM & 1) ? 2 : 1) : MKT_LANE_EXCHANGE;
-        if ((MODE == 1 || (MODE == 3 && lomin == 0)) && LOGR == 2 && diff == 2 && lomin + 2 <= LANEBITS && lomin + 2 <= (MKT_PERMLANE_SWAP ? 6 : 5)) return 1;
+        constexpr int MODE = MKT_LANE_EXCHANGE == 4 ? ((LOGM & 1) ? 2 : 1) : ((LOGM & 1) && MKT_LANE_EXCHANGE >= 5 ? 2 : MKT_LANE_EXCHANGE);
+        if ((MODE == 1 || (MODE == 3 && lomin == 0) || (MODE == 5 && (lomin == 4 || lomin == 0)) || (MODE == 6 && lomin == 4) || (MODE == 7 && (lomin == 4 || lomin == 2))) && LOGR == 2 && diff == 2 && lomin + 2 <= LANEBITS && lomin + 2 <= (MKT_PERMLANE_SWAP ? 6 : 5)) return 1;
         if (MODE >= 1 && LOGR == 2 && diff == 1 && lomin == P::OVL && LANEBITS >= lomin + 1) return 2;
         return 0;
     }
