@@ -12,8 +12,10 @@
  * image, so the reference cannot be executed here.  The oracle is pinned instead
  * by this repo's own fixtures (tests/golden/): twiddle tables generated with
  * mpmath at 256 bits exactly as fft.jl:31-41 does with BigFloat, exact big-int
- * negacyclic products, decomposition / divbits KATs, and decrypt-correctness of
- * random gate circuits (the reference's own test property).
+ * negacyclic products, decomposition / divbits KATs, decrypt-correctness of
+ * random gate circuits (the reference's own test property), and a second,
+ * independent numpy transcription of the Julia source (tests/ref_numpy.py) whose
+ * CGGI / KMS gate outputs this library equals bit for bit.
  *
  * Conventions
  *   - LWE word is uint32_t everywhere (reference: T = UInt32 in every shipped set).

@@ -255,6 +255,33 @@ def test_end_to_end_golden_hashes():
         assert run_mixed(name) == gold[name + "/mixed"], name
 
 
+# ---------------------------------------------------------------- second, independent restatement (numpy)
+@pytest.mark.parametrize("p", [
+    mk.CGGIparam.scaled(n=10, N=256), mk.CGGIparam.scaled(n=6, N=256, k=2), mk.KMS2party.scaled(n=6, N=256),
+    mk.KMS4party.scaled(n=4, N=256, k=3), mk.KMS2party_N1024_l2.scaled(n=4), mk.CGGIparam, mk.KMS2party.scaled(n=40),
+], ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
+def test_numpy_restatement_equals_the_c_oracle(p):
+    """tests/ref_numpy.py transcribes bootstrapping.jl / fft.jl / gsw.jl a second time (numpy, one array op per
+    reference operation, twiddles from the mpmath fixture); its NAND outputs equal the C oracle's word for word --
+    on single-party and on mixed-party inputs, CGGI (RLWE length 1, 2) and KMS (2, 3 parties), reduced and shipped sizes"""
+    import ref_numpy as RN
+    crs, keys = keygen(p, 9)
+    so = oracle_scheme(p, crs, keys)
+    rs = RN.Scheme(p, crs, keys)
+    bits = np.array([1, 0, 1, 1, 0, 1, 0, 0], dtype=bool)
+    c = encrypt_bits(p, keys, bits, seed=90)
+    full = p.n >= 40
+    pairs = [(0, 3)] if full else [(0, 3), (1, 4), (2, 6)]          # j, j+3: cross-party for k = 2
+    outs = []
+    for j, q in pairs:
+        ref = so.gate(0, c[j], c[q])
+        assert np.array_equal(rs.nand(c[j], c[q]), ref), (j, q)
+        outs.append(ref)
+    if not full:                                                     # second level: inputs that involve every party
+        ref = so.gate(0, outs[0], outs[1])
+        assert np.array_equal(rs.nand(outs[0], outs[1]), ref)
+
+
 # ---------------------------------------------------------------- client keys are what the layouts say
 def test_client_key_layouts():
     p = mk.KMS2party.scaled(n=8, N=64)
