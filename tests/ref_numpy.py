@@ -5,7 +5,8 @@ here (no Julia).  This module transcribes the same Julia source a second time --
 layout (one array per polynomial, one numpy operation per reference operation), written from the .jl files, not from
 the C oracle -- so that `tests/test_oracle_cpu.py::test_numpy_restatement_*` can compare the two bit for bit.  A slip
 in either restatement (operand order, rounding point, index off-by-one) shows up as a mismatch; a shared misreading of
-the Julia source would not.  CGGI (bootstrapping.jl:4-109) and KMS (bootstrapping.jl:369-594) are covered.
+the Julia source would not.  All five schemes are covered: CGGI (bootstrapping.jl:4-109), LMSS (:114-229), CCS
+(:234-364), KMS (:369-594) and KMS_block (:599-695).
 
 numpy's element-wise float64 add / multiply are single IEEE operations (no fused multiply-add), which is the reference's
 arithmetic (Julia Base `*`, `+` on Complex{Float64}; no @fastmath, no muladd on this path).
@@ -143,8 +144,10 @@ class Scheme:
         self.N, self.n, self.k, self.W = p.N, p.n, p.k, p.W
         self.f = FFT(p.N, p.W)
         self.udt = self.f.udt
-        self.kms = p.scheme == mk.KMS
-        assert p.scheme in (mk.CGGI, mk.KMS)
+        self.kms = p.scheme in (mk.KMS, mk.KMS_BLOCK)
+        self.block = p.scheme in (mk.LMSS, mk.KMS_BLOCK)
+        self.ccs = p.scheme == mk.CCS
+        self.multikey = self.kms or self.ccs
         N, T = p.N, self.udt
         # scheme.jl:121-146 getmonomial: entry e (1-based) = fft(X^e - 1) for e < N, fft(-2) at N, fft(-1 - X^(e-N)) above, 0 at 2N
         self.monomial = [None] * (2 * N + 1)
@@ -159,19 +162,25 @@ class Scheme:
         self.parties = []
         for kk in keys:
             d = {}
-            if self.kms:
-                brk = kk.brk.reshape(p.n, 2 * p.l_gsw, 2, N)
+            if self.ccs:                                                          # UniEnc: d[l], then (f[j].b, f[j].a)
+                u = kk.brk.reshape(p.n, 3 * p.l_uni, N)
+                d["uni_d"] = [tr(e[:p.l_uni]) for e in u]
+                d["uni_f"] = [[tr(e[p.l_uni + 2 * j:p.l_uni + 2 * j + 2]) for j in range(p.l_uni)] for e in u]
             else:
-                brk = kk.brk.reshape(p.n, (p.k + 1) * p.l_gsw, p.k + 1, N)
-            d["brk"] = [[tr(row) for row in e] for e in brk]                      # [n][rows][polys] TransPolys
-            D1 = (1 << p.logD) - 1
+                if self.kms:
+                    brk = kk.brk.reshape(p.n, 2 * p.l_gsw, 2, N)
+                else:
+                    brk = kk.brk.reshape(p.n, (p.k + 1) * p.l_gsw, p.k + 1, N)
+                d["brk"] = [[tr(row) for row in e] for e in brk]                  # [n][rows][polys] TransPolys
+            D1 = (1 << p.logD) // 2 if self.block else (1 << p.logD) - 1
             d["ksk"] = kk.ksk.reshape(-1, N, D1, p.f, p.n + 1)                     # [component][coef][digit-1][level][a..., b]
+            if self.multikey:
+                d["pub"] = tr(kk.pubkey.reshape(p.l_uni, N))
             if self.kms:
                 d["rlk_d"] = tr(kk.rlk_d.reshape(p.l_uni, N))
                 d["rlk_f"] = [tr(x) for x in kk.rlk_f.reshape(p.l_uni, 2, N)]
-                d["pub"] = tr(kk.pubkey.reshape(p.l_uni, N))
             self.parties.append(d)
-        if self.kms:
+        if self.multikey:
             self.crs = tr(np.asarray(crs).reshape(p.l_uni, N))
 
     # ---- bootstrapping.jl:4-27
@@ -190,7 +199,19 @@ class Scheme:
             tb -= N
             b = np.where(i1 <= tb, T(0) - eighth, eighth).astype(T)
         acc = [b] + [np.zeros(N, dtype=T) for _ in range(p.k)]
-        acc = self.blindrotate_kms(ta, acc) if self.kms else self.blindrotate_cggi(ta, acc)
+        mk = self.mk
+        if self.kms:
+            acc = self.blindrotate_kms(ta, acc)
+        elif self.ccs:
+            acc = self.blindrotate_ccs(ta, acc)
+        elif p.scheme == mk.LMSS:
+            acc = self.blindrotate_lmss(ta, acc)
+        else:
+            acc = self.blindrotate_cggi(ta, acc)
+        if p.scheme == mk.LMSS:
+            return self.keyswitch_lmss(acc)
+        if p.scheme == mk.KMS_BLOCK:
+            return self.keyswitch_kms_block(acc)
         return self.keyswitch(acc)
 
     # ---- bootstrapping.jl:32-76
@@ -227,6 +248,30 @@ class Scheme:
         for i in range(it):
             b = np.zeros(N, dtype=T); b[0] = T(1) << T(self.W - (i + 1) * p.logB_lev)
             stack.append([b, np.zeros(N, dtype=T)])
+        if self.block:                                                  # bootstrapping.jl:599-659
+            for idx1 in range(p.blk_d):
+                new = []
+                for i in range(it):
+                    tb = [f.fwd(d) for d in decomp_poly(stack[i][0], l, p.logB_gsw, self.W)]
+                    tav = [f.fwd(d) for d in decomp_poly(stack[i][1], l, p.logB_gsw, self.W)]
+                    tacc2 = [C.zeros(N // 2), C.zeros(N // 2)]
+                    for idx2 in range(p.blk_len):
+                        idx = idx1 * p.blk_len + idx2
+                        if ta[idx] == 0:
+                            continue
+                        tacc = [C.zeros(N // 2), C.zeros(N // 2)]
+                        for j in range(l):
+                            for q in range(2):
+                                tacc[q] = tacc[q] + tb[j] * brk[idx][j][q]
+                        for j in range(l):
+                            for q in range(2):
+                                tacc[q] = tacc[q] + tav[j] * brk[idx][l + j][q]
+                        mono = self.monomial[int(ta[idx])]
+                        for q in range(2):
+                            tacc2[q] = tacc2[q] + mono * tacc[q]
+                    new.append([stack[i][q] + f.inv(tacc2[q]) for q in range(2)])
+                stack = new
+            return [[f.fwd(r[0]), f.fwd(r[1])] for r in stack]
         for idx in range(p.n):
             if ta[idx] == 0:
                 continue
@@ -297,13 +342,13 @@ class Scheme:
     def keyswitch(self, acc):
         p, N, n = self.p, self.N, self.n
         bitdiff = self.W - 32
-        nparty = self.k if self.kms else 1
+        nparty = self.k if self.multikey else 1
         res = np.zeros(nparty * n + 1, dtype=np.uint32)
         res[-1] = np.uint32(int(acc[0][0]) >> bitdiff)
         for i in range(p.k):
             a = acc[1 + i]
-            ksk = self.parties[i]["ksk"][0] if self.kms else self.parties[0]["ksk"][i]
-            off = i * n if self.kms else 0
+            ksk = self.parties[i]["ksk"][0] if self.multikey else self.parties[0]["ksk"][i]
+            off = i * n if self.multikey else 0
             for j in range(N):                                          # extracted coefficient j (0-based)
                 w = int(a[0]) >> bitdiff if j == 0 else (-(int(a[N - j]) >> bitdiff)) & 0xFFFFFFFF
                 w &= 0xFFFFFFFF
@@ -312,6 +357,140 @@ class Scheme:
                         row = ksk[j, d - 1, t]
                         res[off:off + n] += row[:n]
                         res[-1] += row[n]
+        return res
+
+    # ---- bootstrapping.jl:114-165
+    def blindrotate_lmss(self, ta, acc):
+        p, f = self.p, self.f
+        l, k = p.l_gsw, p.k
+        brk = self.parties[0]["brk"]
+        for idx1 in range(p.blk_d):
+            tb = [f.fwd(d) for d in decomp_poly(acc[0], l, p.logB_gsw, self.W)]
+            tav = [[f.fwd(d) for d in decomp_poly(acc[1 + i], l, p.logB_gsw, self.W)] for i in range(k)]
+            tacc2 = [C.zeros(self.N // 2) for _ in range(k + 1)]
+            for idx2 in range(p.blk_len):
+                idx = idx1 * p.blk_len + idx2
+                if ta[idx] == 0:
+                    continue
+                tacc = [C.zeros(self.N // 2) for _ in range(k + 1)]
+                for i in range(l):
+                    for q in range(k + 1):
+                        tacc[q] = tacc[q] + tb[i] * brk[idx][i][q]
+                for i in range(k):
+                    for j in range(l):
+                        for q in range(k + 1):
+                            tacc[q] = tacc[q] + tav[i][j] * brk[idx][(1 + i) * l + j][q]
+                mono = self.monomial[int(ta[idx])]
+                for q in range(k + 1):
+                    tacc2[q] = tacc2[q] + mono * tacc[q]                 # muladdto!(tacc2, monomial, tacc)
+            acc = [acc[q] + f.inv(tacc2[q]) for q in range(k + 1)]
+        return acc
+
+    # ---- bootstrapping.jl:234-328
+    def blindrotate_ccs(self, ta, acc):
+        p, f, N, k, n = self.p, self.f, self.N, self.k, self.n
+        M, l, logB = N // 2, p.l_uni, p.logB_uni
+        for idx in range(k):                                            # party; mask polys 0..idx are live
+            P = self.parties[idx]
+            for i in range(n):
+                at = int(ta[idx * n + i])
+                if at == 0:
+                    continue
+                tb = [f.fwd(d) for d in decomp_poly(acc[0], l, logB, self.W)]
+                tav = [[f.fwd(d) for d in decomp_poly(acc[1 + j1], l, logB, self.W)] for j1 in range(idx + 1)]
+                ud, uf = P["uni_d"][i], P["uni_f"][i]
+                tacc = [C.zeros(M) for _ in range(k + 1)]
+                for j in range(l):                                      # u
+                    tacc[0] = tacc[0] + tb[j] * ud[j]
+                for j1 in range(idx + 1):
+                    for j2 in range(l):
+                        tacc[1 + j1] = tacc[1 + j1] + tav[j1][j2] * ud[j2]
+                tv0 = C.zeros(M)                                         # v
+                tv = [C.zeros(M) for _ in range(idx + 1)]
+                for j in range(l):
+                    tv0 = tv0 - tb[j] * self.crs[j]
+                for j1 in range(idx + 1):
+                    for j2 in range(l):
+                        tv[j1] = tv[j1] + tav[j1][j2] * self.parties[j1]["pub"][j2]
+                v0 = f.inv(tv0)
+                v = [f.inv(x) for x in tv]
+                tv0v = [f.fwd(d) for d in decomp_poly(v0, l, logB, self.W)]
+                tvv = [[f.fwd(d) for d in decomp_poly(v[j1], l, logB, self.W)] for j1 in range(idx + 1)]
+                for j in range(l):                                      # w
+                    tacc[0] = tacc[0] + tv0v[j] * uf[j][0]
+                    tacc[1 + idx] = tacc[1 + idx] + tv0v[j] * uf[j][1]
+                for j1 in range(idx + 1):
+                    for j2 in range(l):
+                        tacc[0] = tacc[0] + tvv[j1][j2] * uf[j2][0]
+                        tacc[1 + idx] = tacc[1 + idx] + tvv[j1][j2] * uf[j2][1]
+                mono = self.monomial[at]
+                acc = [acc[q] + f.inv(mono * tacc[q]) for q in range(k + 1)]
+        return acc
+
+    def _balanced_word(self, w):
+        """gsw.jl:42-52 decompto!(avec, a::UInt32, kskpar): signed digits, index 0 = most significant"""
+        l, logB = self.p.f, self.p.logD
+        mask, half = (1 << logB) - 1, 1 << (logB - 1)
+        bit = 32 - l * logB
+        ai = ((w >> bit) + (((w << (32 - bit)) & 0xFFFFFFFF) >> 31)) & 0xFFFFFFFF if bit else w
+        out = [0] * l
+        for i in range(l - 1, 0, -1):
+            d = ai & mask
+            ai >>= logB
+            ai = (ai + (d >> (logB - 1))) & 0xFFFFFFFF
+            out[i] = d - ((d & half) << 1)
+        d = ai & mask
+        out[0] = d - ((d & half) << 1)
+        return out
+
+    def _ks_balanced(self, res, off, ksk, j, w):
+        n = self.n
+        for t, d in enumerate(self._balanced_word(w)):
+            if d > 0:
+                row = ksk[j, d - 1, t]; res[off:off + n] += row[:n]; res[-1] += row[n]
+            elif d != 0:
+                row = ksk[j, -d - 1, t]; res[off:off + n] -= row[:n]; res[-1] -= row[n]
+
+    def _extract(self, a, j, bitdiff):
+        N = self.N
+        return (int(a[0]) >> bitdiff) & 0xFFFFFFFF if j == 0 else (-(int(a[N - j]) >> bitdiff)) & 0xFFFFFFFF
+
+    # ---- bootstrapping.jl:170-229
+    def keyswitch_lmss(self, acc):
+        p, N, n = self.p, self.N, self.n
+        res = np.zeros(n + 1, dtype=np.uint32)
+        res[-1] = np.uint32(int(acc[0][0]) & 0xFFFFFFFF)
+        current = 1                                                     # 1-based, as in the source
+        for i in range(p.k):
+            a, ksk = acc[1 + i], self.parties[0]["ksk"][i]
+            if current + N <= n:
+                for j in range(N):
+                    res[current - 1 + j] = self._extract(a, j, 0)
+                current += N
+            elif current <= n:
+                cnt = n - current + 1                                   # words copied
+                for j in range(cnt):
+                    res[current - 1 + j] = self._extract(a, j, 0)
+                for j in range(cnt, N):
+                    self._ks_balanced(res, 0, ksk, j, self._extract(a, j, 0))
+                current = n + 1
+            else:
+                for j in range(N):
+                    self._ks_balanced(res, 0, ksk, j, self._extract(a, j, 0))
+        return res
+
+    # ---- bootstrapping.jl:664-695
+    def keyswitch_kms_block(self, acc):
+        p, N, n, k = self.p, self.N, self.n, self.k
+        bitdiff = self.W - 32
+        res = np.zeros(k * n + 1, dtype=np.uint32)
+        res[-1] = np.uint32((int(acc[0][0]) >> bitdiff) & 0xFFFFFFFF)
+        for i in range(k):
+            a, ksk = acc[1 + i], self.parties[i]["ksk"][0]
+            for j in range(n):
+                res[i * n + j] = self._extract(a, j, bitdiff)
+            for j in range(n, N):
+                self._ks_balanced(res, i * n, ksk, j, self._extract(a, j, bitdiff))
         return res
 
     # ---- gate.jl:1-8

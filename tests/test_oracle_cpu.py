@@ -259,11 +259,15 @@ def test_end_to_end_golden_hashes():
 @pytest.mark.parametrize("p", [
     mk.CGGIparam.scaled(n=10, N=256), mk.CGGIparam.scaled(n=6, N=256, k=2), mk.KMS2party.scaled(n=6, N=256),
     mk.KMS4party.scaled(n=4, N=256, k=3), mk.KMS2party_N1024_l2.scaled(n=4), mk.CGGIparam, mk.KMS2party.scaled(n=40),
+    mk.Blockparam.scaled(n=12, N=256, blk_d=4), mk.Blockparam.scaled(n=30, N=256, blk_d=10, k=2),
+    mk.Blockparam.scaled(n=300, N=256, blk_d=100, k=2),                 # n > N: the LMSS key switch copies a whole component
+    mk.CCS2party.scaled(n=6, N=256), mk.CCS4party.scaled(n=3, N=256, k=3),
+    mk.KMS2partyblock.scaled(n=12, N=256, blk_d=4), mk.KMS4partyblock.scaled(n=6, N=256, blk_d=2, k=3),
 ], ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
 def test_numpy_restatement_equals_the_c_oracle(p):
     """tests/ref_numpy.py transcribes bootstrapping.jl / fft.jl / gsw.jl a second time (numpy, one array op per
     reference operation, twiddles from the mpmath fixture); its NAND outputs equal the C oracle's word for word --
-    on single-party and on mixed-party inputs, CGGI (RLWE length 1, 2) and KMS (2, 3 parties), reduced and shipped sizes"""
+    on single-party and on mixed-party inputs, all five schemes (RLWE length 1-2, 2-3 parties), reduced and shipped sizes"""
     import ref_numpy as RN
     crs, keys = keygen(p, 9)
     so = oracle_scheme(p, crs, keys)
@@ -271,7 +275,7 @@ def test_numpy_restatement_equals_the_c_oracle(p):
     bits = np.array([1, 0, 1, 1, 0, 1, 0, 0], dtype=bool)
     c = encrypt_bits(p, keys, bits, seed=90)
     full = p.n >= 40
-    pairs = [(0, 3)] if full else [(0, 3), (1, 4), (2, 6)]          # j, j+3: cross-party for k = 2
+    pairs = [(0, 3)] if full else [(0, 3), (1, 4), (2, 6)]          # j, j+3: cross-party for k = 2, 3
     outs = []
     for j, q in pairs:
         ref = so.gate(0, c[j], c[q])
