@@ -312,7 +312,10 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 // Occupancy the register allocator is told to hit EXACTLY (amdgpu_waves_per_eu(min, max)): 3 waves/SIMD pays at
 // M >= 1024 with single transforms; elsewhere LDS admits 2 and the allocator should then use all 256 VGPRs --
 // builds that stopped at ~186 or chose <= 168 for a third wave LDS cannot host ran up to 25 % slower
-template <int LOGM, int NB> struct RotOcc { static constexpr int MINW = (LOGM >= 10 && NB == 1 && MKT_LOGR == 2) ? 3 : MKT_ROT_MINW; };
+#ifndef MKT_ROT_OCC9
+#define MKT_ROT_OCC9 MKT_ROT_MINW   // waves/SIMD asked for at M = 512 with single transforms (3 was measured slower)
+#endif
+template <int LOGM, int NB> struct RotOcc { static constexpr int MINW = (LOGM >= 10 && NB == 1 && MKT_LOGR == 2) ? 3 : ((LOGM == 9 && NB == 1) ? MKT_ROT_OCC9 : MKT_ROT_MINW); };
 
 template <int LOGM, typename WORD, int LB, int LR, int NB, int LT, int BT>
 __global__ __launch_bounds__((Plan<LOGM, LR>::NT)) __attribute__((amdgpu_waves_per_eu(RotOcc<LOGM, NB>::MINW, RotOcc<LOGM, NB>::MINW)))
