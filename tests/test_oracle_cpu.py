@@ -411,5 +411,7 @@ def test_lds_staging_swizzle_is_conflict_free_in_the_bank_model():
         assert sorted(swz(i) for i in range(M)) == list(range(M))          # a permutation of the staging slots
         rd, ird, wr, iwr = S.evaluate(LOGM, swz)
         assert (rd, wr) == (ird, iwr), LOGM
+        rd, ird, wr, iwr = S.evaluate(LOGM, swz, S.schedule(LOGM))         # the shipped window sequence (odd LOGM: ..5,4,2,0)
+        assert (rd, wr) == (ird, iwr), ("shipped schedule", LOGM)
         rd0, _, wr0, _ = S.evaluate(LOGM, lambda i: i)
         assert rd0 > ird and wr0 > iwr                                     # the identity layout does conflict

@@ -38,15 +38,30 @@ def cost(pos, groups, ncols):
     return tot
 
 
-def evaluate(LOGM, swz):
-    """-> (read cycles, ideal read, write cycles, ideal write) summed over all exchanges of fwd+inv"""
+def schedule(LOGM):
+    """window sequence of the shipped schedule (fft_device.h Plan): for 4 points per thread and odd LOGM >= 7 the
+    single-stage window sits at 4 (... 7, 5, 4, 2, 0) and its one-bit exchange is done in the wave (permlane swap)"""
+    npass = (LOGM + LOGR - 1) // LOGR
+    if LOGR == 2 and (LOGM & 1) and LOGM >= 7:
+        pa = (LOGM - 5) // 2
+        return [LOGM - 2 * (p + 1) for p in range(pa)] + [4, 2, 0]
+    return [lo_of(LOGM, p) for p in range(npass)]
+
+
+def evaluate(LOGM, swz, los=None):
+    """-> (read cycles, ideal read, write cycles, ideal write) summed over all LDS exchanges of fwd+inv
+    (`los`: window sequence, default the textbook top-down one; one-bit exchanges of `schedule()` are in-wave)"""
     M = 1 << LOGM
     NT = M >> LOGR
-    npass = (LOGM + LOGR - 1) // LOGR
-    los = [lo_of(LOGM, p) for p in range(npass)]
+    inwave_odd = los is not None
+    if los is None:
+        los = [lo_of(LOGM, p) for p in range((LOGM + LOGR - 1) // LOGR)]
+    npass = len(los)
     rd = wr = ird = iwr = 0
     pairs = [(los[p], los[p + 1]) for p in range(npass - 1)] + [(los[p], los[p - 1]) for p in range(npass - 1, 0, -1)]
     for lo_w, lo_r in pairs:
+        if inwave_odd and abs(lo_w - lo_r) == 1:
+            continue
         for wave in range(max(NT // 64, 1)):
             lanes = range(wave * 64, min(wave * 64 + 64, NT))
             for e in range(1 << LOGR):
