@@ -114,14 +114,17 @@ def main():
     p = getattr(mk, pname)
     B = args.batch
 
+    # The large evaluation keys are generated on the GPU (mkt_keygen_device: the same words as the host generator);
+    # only the rank that runs the CPU baseline also needs them on the host, for the oracle.
+    need_host_keys = rank == 0 and not args.no_cpu_baseline
     # ---- synthetic inputs: seeded keys (seed 1), encryptions of uniform bits (seed 2) ----
     if p.multikey:
         crs = mk.CRS(p, 1)
-        keys = [mk.party_keygen(crs, p, seed=1, party=i) for i in range(p.k)]
+        keys = [mk.party_keygen(crs, p, seed=1, party=i, secrets_only=not need_host_keys) for i in range(p.k)]
         sch = mk.setup(p, keys=keys, a=crs, device=local)
     else:
         crs = None
-        keys = [mk.PartyKeys(p, seed=1)]
+        keys = [mk.PartyKeys(p, seed=1, secrets_only=not need_host_keys)]
         sch = mk.setup(p, keys=keys[0], device=local)[1]
     rng = np.random.default_rng(2 + rank)
 
