@@ -309,6 +309,23 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 #ifndef MKT_ROT_MINW
 #define MKT_ROT_MINW 2
 #endif
+// Key rows, monomial rows and the twist tables are read through buffer descriptors: SGPR base + 32-bit per-lane
+// offset + SGPR row offset, so a load costs no address arithmetic on the VALU (flat loads needed a 64-bit add each:
+// ~100 of the ~2000 VALU instructions of a CMux).
+#ifndef MKT_ROT_BUFLOAD
+#define MKT_ROT_BUFLOAD 1
+#endif
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void *p, size_t bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0,
+                                             (int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
+}
+__device__ __forceinline__ cplx table_load(__amdgpu_buffer_rsrc_t rs, unsigned voff_bytes, unsigned soff_bytes) {
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff_bytes, (int)soff_bytes, 0);
+    cplx r; __builtin_memcpy(&r, &v, 16); return r;
+}
+
 // Occupancy the register allocator is told to hit EXACTLY (amdgpu_waves_per_eu(min, max)): 3 waves/SIMD pays at
 // M >= 1024 with single transforms; elsewhere LDS admits 2 and the allocator should then use all 256 VGPRs --
 // builds that stopped at ~186 or chose <= 168 for a third wave LDS cannot host ran up to 25 % slower
@@ -347,9 +364,16 @@ void blindrotate_k1_kernel(const RotArgs a) {
     const size_t gate = blockIdx.x % (size_t)a.ngates;
     const int slot = (int)(blockIdx.x / (size_t)a.ngates);
     const size_t rot = gate * (size_t)a.rows_per_gate + slot;
-    const int party = a.slot_party[slot], row = a.slot_row[slot];
+    const int party = __builtin_amdgcn_readfirstlane(a.slot_party[slot]), row = __builtin_amdgcn_readfirstlane(a.slot_row[slot]);
     const uint32_t *at_src = a.lwe + gate * (size_t)a.lwe_stride + (size_t)party * a.n;
     const cplx *brk = a.brk + (size_t)party * a.brk_party_stride;
+    const __amdgpu_buffer_rsrc_t rs_brk = table_rsrc(brk, (size_t)a.brk_party_stride * sizeof(cplx));
+    const __amdgpu_buffer_rsrc_t rs_mono = table_rsrc(a.monomial, (size_t)2 * N * M * sizeof(cplx));
+    const __amdgpu_buffer_rsrc_t rs_roots = table_rsrc(a.tw.roots, (size_t)M * sizeof(cplx));
+    const __amdgpu_buffer_rsrc_t rs_rinv = table_rsrc(a.tw.rootsinv, (size_t)M * sizeof(cplx));
+    unsigned vo_dev[R], vo_nat[R];            // per-lane byte offsets: device point order (tables), e*NT + t (twists)
+#pragma unroll
+    for (int e = 0; e < R; e++) { vo_dev[e] = (unsigned)dev_pos(t * R + e, NT) * 16u; vo_nat[e] = (unsigned)(e * NT + t) * 16u; }
     // LT, BT > 0: gadget length and base known at compile time -- every digit shift / mask is an immediate
     const Gadget<WORD> gd(LT ? LT : a.l, (LT && BT) ? BT : a.logB);
     const int l = LT ? LT : a.l;   // LT > 0: gadget length known at compile time, the digit loop unrolls fully
@@ -377,7 +401,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
         for (int q = 0; q < LB; q++) {
             const uint32_t v = at_src[blk * LB + q];
-            ats[q] = a.pre_switched ? v : divbits<uint32_t>(v, msbit);   // bootstrapping.jl:8
+            ats[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.pre_switched ? v : divbits<uint32_t>(v, msbit)));   // bootstrapping.jl:8 (wave-uniform)
             any |= ats[q] != 0;
         }
         if (!any) continue;                                              // :48 / :145 / :413 / :638
@@ -405,7 +429,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
                     int d0, d1;
                     if (MKT_ABLATE & 32) { d0 = (int)(w0 & 7) - 4 + j; d1 = (int)(w1 & 7) - 3; } else { d0 = gd.digit(gd.prep(w0), j); d1 = gd.digit(gd.prep(w1), j); }
                     cplx v; v.re = (double)d0; v.im = (double)(-d1);
-                    z[h2][e] = cmul(v, a.tw.roots[e * NT + t]);
+                    z[h2][e] = cmul(v, MKT_ROT_BUFLOAD ? table_load(rs_roots, vo_nat[e], 0) : a.tw.roots[e * NT + t]);
                 }
             }
             fft_forward<LOGM, LR, NB>(z, MKT_PSI_F, lds, t, xs.lx);  // :54-59 fftto!
@@ -415,10 +439,11 @@ void blindrotate_k1_kernel(const RotArgs a) {
                 for (int q = 0; q < LB; q++) {
                     if (LB > 1 && ats[q] == 0) continue;
                     const cplx *krow = brk + (((size_t)(blk * LB + q) * 2 * l + (size_t)(g0 + h2)) * 2) * M;
+                    const unsigned so_row = (unsigned)((((size_t)(blk * LB + q) * 2 * l + (size_t)(g0 + h2)) * 2) * M * sizeof(cplx));
 #pragma unroll
                     for (int e = 0; e < R; e++) {                        // :63-68 muladdto!(tacc, digit, row)
                         cplx kb, ka;
-                        if (MKT_ABLATE & 1) { kb.re = 1.5; kb.im = (double)t; ka.re = 2.5; ka.im = (double)e; } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
+                        if (MKT_ABLATE & 1) { kb.re = 1.5; kb.im = (double)t; ka.re = 2.5; ka.im = (double)e; } else if (MKT_ROT_BUFLOAD) { kb = table_load(rs_brk, vo_dev[e], so_row); ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
                         tacc[q][0][e] = cadd(tacc[q][0][e], cmul(z[h2][e], kb));
                         tacc[q][1][e] = cadd(tacc[q][1][e], cmul(z[h2][e], ka));
                         if (RotOcc<LOGM, NB>::MINW >= 3) __builtin_amdgcn_sched_barrier(0);   // keep the key-row live ranges short at 3 waves/SIMD
@@ -432,7 +457,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int e = 0; e < R; e++) { cplx mv; if (MKT_ABLATE & 1) { mv.re = 0.5; mv.im = (double)e; } else mv = mono[dev_pos(t * R + e, NT)]; t2[c][e] = cmul(mv, tacc[0][c][e]); }
+                for (int e = 0; e < R; e++) { cplx mv; if (MKT_ABLATE & 1) { mv.re = 0.5; mv.im = (double)e; } else mv = MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[0] - 1) * M * sizeof(cplx))) : mono[dev_pos(t * R + e, NT)]; t2[c][e] = cmul(mv, tacc[0][c][e]); }
         } else {                                                         // :157 / :648 tacc2 += monomial * tacc
 #pragma unroll
             for (int c = 0; c < 2; c++)
@@ -445,7 +470,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; c++)
 #pragma unroll
-                    for (int e = 0; e < R; e++) t2[c][e] = cadd(t2[c][e], cmul(mono[dev_pos(t * R + e, NT)], tacc[q][c][e]));
+                    for (int e = 0; e < R; e++) t2[c][e] = cadd(t2[c][e], cmul(MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[q] - 1) * M * sizeof(cplx))) : mono[dev_pos(t * R + e, NT)], tacc[q][c][e]));
             }
         }
         if (NB == 2) {
@@ -456,7 +481,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < R; e++) {
-            const cplx ri = a.tw.rootsinv[e * NT + t];
+            const cplx ri = MKT_ROT_BUFLOAD ? table_load(rs_rinv, vo_nat[e], 0) : a.tw.rootsinv[e * NT + t];
 #pragma unroll
             for (int c = 0; c < 2; c++) {                                // fft.jl:76-80 untwist + native; :73 add!
                 const cplx v = cmul(t2[c][e], ri);
