@@ -297,6 +297,9 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 // and the transform-domain accumulator stay in registers for all n CMux steps; LDS only stages the
 // in-transform exchanges.  LB = block length (1 for the plain schemes).
 // ------------------------------------------------------------------------------------------------
+#ifndef MKT_ROT_LT3
+#define MKT_ROT_LT3 1     // specialise the shipped l = 3 shapes too (CGGIparam, Blockparam, KMS2party, KMS2partyblock)
+#endif
 #ifndef MKT_ROT_BT
 #define MKT_ROT_BT 1     // also specialise the gadget base where the length is specialised (l = 2, logB = 16 on the 64-bit ring)
 #endif
@@ -1152,10 +1155,19 @@ static hipError_t launch_rot_one(const RotArgs &a, size_t nrot, hipStream_t s) {
     if constexpr (LM < LR) { return hipErrorInvalidValue; } else {
 #if MKT_ROT_LT
         // gadget length known at compile time (fully unrolled digit loop): measured +8 % at M = 512, l = 2
-        // (15.2 -> 14.0 ms, KMS k=2 N=1024) but -4..-7 % at l = 3, so only that case is specialised
+        // (15.2 -> 14.0 ms, KMS k=2 N=1024)
         if constexpr (LB == 1 && LM == 9) {
             if (MKT_ROT_BT && a.l == 2 && a.logB == 16 && sizeof(WORD) == 8) return launch_rot_lt<LM, WORD, LB, LR, NB, 2, 16>(a, nrot, s);
             if (a.l == 2) return launch_rot_lt<LM, WORD, LB, LR, NB, 2>(a, nrot, s);
+        }
+        // the shipped l = 3 shapes: CGGIparam / Blockparam (logB 9, 32-bit ring, N = 1024) and KMS2party / KMS2partyblock
+        // (logB 12, 64-bit ring, N = 2048): +5..7 % once the gadget base is a constant too (the early l = 3 unrolling
+        // without it had been slower)
+        if constexpr ((LB == 1 || LB == 3) && LM == 9 && sizeof(WORD) == 4) {
+            if (MKT_ROT_LT3 && a.l == 3 && a.logB == 9) return launch_rot_lt<LM, WORD, LB, LR, NB, 3, 9>(a, nrot, s);
+        }
+        if constexpr ((LB == 1 || LB == 3) && LM == 10 && sizeof(WORD) == 8) {
+            if (MKT_ROT_LT3 && a.l == 3 && a.logB == 12) return launch_rot_lt<LM, WORD, LB, LR, NB, 3, 12>(a, nrot, s);
         }
 #endif
         return launch_rot_lt<LM, WORD, LB, LR, NB, 0>(a, nrot, s);
