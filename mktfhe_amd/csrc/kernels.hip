@@ -297,6 +297,9 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 // and the transform-domain accumulator stay in registers for all n CMux steps; LDS only stages the
 // in-transform exchanges.  LB = block length (1 for the plain schemes).
 // ------------------------------------------------------------------------------------------------
+#ifndef MKT_ROT_LT5
+#define MKT_ROT_LT5 1     // ... and the l = 4, 5, 6 shapes of the larger KMS sets (params.jl:55-125)
+#endif
 #ifndef MKT_ROT_LT3
 #define MKT_ROT_LT3 1     // specialise the shipped l = 3 shapes too (CGGIparam, Blockparam, KMS2party, KMS2partyblock)
 #endif
@@ -1168,6 +1171,9 @@ static hipError_t launch_rot_one(const RotArgs &a, size_t nrot, hipStream_t s) {
         }
         if constexpr ((LB == 1 || LB == 3) && LM == 10 && sizeof(WORD) == 8) {
             if (MKT_ROT_LT3 && a.l == 3 && a.logB == 12) return launch_rot_lt<LM, WORD, LB, LR, NB, 3, 12>(a, nrot, s);
+            if (MKT_ROT_LT5 && a.l == 5 && a.logB == 8) return launch_rot_lt<LM, WORD, LB, LR, NB, 5, 8>(a, nrot, s);    // KMS4party, KMS16party (+7 %)
+            if (MKT_ROT_LT5 && a.l == 4 && a.logB == 9) return launch_rot_lt<LM, WORD, LB, LR, NB, 4, 9>(a, nrot, s);    // KMS8party
+            if (MKT_ROT_LT5 && a.l == 6 && a.logB == 7) return launch_rot_lt<LM, WORD, LB, LR, NB, 6, 7>(a, nrot, s);    // KMS32party
         }
 #endif
         return launch_rot_lt<LM, WORD, LB, LR, NB, 0>(a, nrot, s);
