@@ -40,6 +40,9 @@ __device__ __forceinline__ cplx cmul_conj(const cplx x, const cplx w) {
 __device__ __forceinline__ cplx cadd(const cplx x, const cplx y) { cplx r; r.re = x.re + y.re; r.im = x.im + y.im; return r; }
 __device__ __forceinline__ cplx csub(const cplx x, const cplx y) { cplx r; r.re = x.re - y.re; r.im = x.im - y.im; return r; }
 
+#ifndef MKT_DPP_PAIR
+#define MKT_DPP_PAIR 1        // pairwise lane exchanges along lane bits 0..3 as two DPP reads (see swap_pair)
+#endif
 #ifndef MKT_PERMLANE_SWAP
 #define MKT_PERMLANE_SWAP 1   // gfx950 v_permlane16_swap / v_permlane32_swap for exchanges along lane bits 4 and 5
 #endif
@@ -142,6 +145,33 @@ __device__ __forceinline__ void swap_pair(cplx &x0, cplx &x1, bool b, const Lane
             auto r = D == 16 ? __builtin_amdgcn_permlane16_swap((unsigned)a0[w], (unsigned)a1[w], false, false)
                              : __builtin_amdgcn_permlane32_swap((unsigned)a0[w], (unsigned)a1[w], false, false);
             a0[w] = (int)r[0]; a1[w] = (int)r[1];
+        }
+    } else if constexpr (MKT_DPP_PAIR && (D == 1 || D == 2 || D == 4 || D == 8)) {
+        // Two DPP reads instead of one read and three selects: r0 = the partner's x0 as the b = 0 lanes see it, r1 = the
+        // partner's x1 as the b = 1 lanes see it; each is consumed only in the lanes for which its lane pattern is the
+        // right one, so lane ^ 4 needs no choice between row_ror:4 and row_ror:12 (dst[i] = src[(i - n) mod 16]:
+        // row_ror:12 serves the lanes with bit 2 clear, row_ror:4 those with it set).  The compiler folds each DPP
+        // move into the v_cndmask that consumes it where it can.
+        constexpr int CA = D == 1 ? 0xB1 : D == 2 ? 0x4E : D == 4 ? 0x12C : 0x128;   // seen by the b = 0 lanes
+        constexpr int CB = D == 1 ? 0xB1 : D == 2 ? 0x4E : D == 4 ? 0x124 : 0x128;   // seen by the b = 1 lanes
+        if constexpr (D >= 4) {
+            // lane bits 2 and 3 select whole banks of 4 lanes: the DPP bank mask does the merge, no select at all
+            constexpr int BM0 = D == 4 ? 0x5 : 0x3, BM1 = D == 4 ? 0xA : 0xC;       // banks holding the b = 0 / b = 1 lanes
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int n1 = __builtin_amdgcn_update_dpp(a1[w], a0[w], CA, 0xf, BM0, false);
+                const int n0 = __builtin_amdgcn_update_dpp(a0[w], a1[w], CB, 0xf, BM1, false);
+                a1[w] = n1; a0[w] = n0;
+            }
+        } else {
+            const bool nb = !b;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int r0 = dpp_mov<CA>(a0[w]);
+                const int r1 = dpp_mov<CB>(a1[w]);
+                a1[w] = b ? a1[w] : r0;
+                a0[w] = nb ? a0[w] : r1;
+            }
         }
     } else {
 #pragma unroll
