@@ -237,8 +237,10 @@ __device__ __forceinline__ void exchange_lane_odd_inv(cplx (&z)[NB][4], const La
 }
 
 #ifndef MKT_LANE_EXCHANGE
-#define MKT_LANE_EXCHANGE 4   // 0: every exchange through LDS; 1: in-wave wherever legal; 2: only the odd last window;
-                              // 3: 2 + quad-local (d = 1, 2); 4 (default, measured): 2 for odd log2 M, 1 for even
+#define MKT_LANE_EXCHANGE 4   // 0: every exchange through LDS; 1: in-wave wherever legal; 2: only the single-stage window;
+                              // 3: 2 + quad-local (d = 1, 2); 5-7: route mixes for tuning; 8: single-stage window + the
+                              // transposes along lane bits 2-5 (bank-masked DPP / permlane swaps), quad-local ones via LDS;
+                              // 4 (default, measured): 8 for odd log2 M, 1 for even
 #endif
 
 // which route the exchange between two windows of the schedule takes (compile time): 0 LDS, 1 in-wave 4x4, 2 odd window
@@ -248,8 +250,8 @@ struct Route {
     static constexpr int LANEBITS = (LOGM - LOGR) < 6 ? (LOGM - LOGR) : 6;   // thread bits that are lane bits
     __host__ __device__ static constexpr int of(int lo_a, int lo_b) {
         const int lomin = lo_a < lo_b ? lo_a : lo_b, diff = lo_a < lo_b ? lo_b - lo_a : lo_a - lo_b;
-        constexpr int MODE = MKT_LANE_EXCHANGE == 4 ? ((LOGM & 1) ? 2 : 1) : ((LOGM & 1) && MKT_LANE_EXCHANGE >= 5 ? 2 : MKT_LANE_EXCHANGE);
-        if ((MODE == 1 || (MODE == 3 && lomin == 0) || (MODE == 5 && (lomin == 4 || lomin == 0)) || (MODE == 6 && lomin == 4) || (MODE == 7 && (lomin == 4 || lomin == 2))) && LOGR == 2 && diff == 2 && lomin + 2 <= LANEBITS && lomin + 2 <= (MKT_PERMLANE_SWAP ? 6 : 5)) return 1;
+        constexpr int MODE = MKT_LANE_EXCHANGE == 4 ? ((LOGM & 1) ? 8 : 1) : ((LOGM & 1) && MKT_LANE_EXCHANGE >= 5 && MKT_LANE_EXCHANGE <= 7 ? 2 : MKT_LANE_EXCHANGE);
+        if ((MODE == 1 || (MODE == 3 && lomin == 0) || (MODE == 5 && (lomin == 4 || lomin == 0)) || (MODE == 6 && lomin == 4) || (MODE == 7 && (lomin == 4 || lomin == 2)) || (MODE == 8 && (lomin == 4 || lomin == 2))) && LOGR == 2 && diff == 2 && lomin + 2 <= LANEBITS && lomin + 2 <= (MKT_PERMLANE_SWAP ? 6 : 5)) return 1;
         if (MODE >= 1 && LOGR == 2 && diff == 1 && lomin == P::OVL && LANEBITS >= lomin + 1) return 2;
         return 0;
     }
