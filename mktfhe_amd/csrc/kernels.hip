@@ -297,6 +297,9 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 // and the transform-domain accumulator stay in registers for all n CMux steps; LDS only stages the
 // in-transform exchanges.  LB = block length (1 for the plain schemes).
 // ------------------------------------------------------------------------------------------------
+#ifndef MKT_KS_WAVES
+#define MKT_KS_WAVES 4
+#endif
 #ifndef MKT_ROT_LT5
 #define MKT_ROT_LT5 1     // ... and the l = 4, 5, 6 shapes of the larger KMS sets (params.jl:55-125)
 #endif
@@ -936,15 +939,26 @@ __global__ void ks_init_kernel(const KsArgs a, size_t B) {
 // the gather is bound by L2 / Infinity-Cache bandwidth.  Partial sums over slabs meet in u32 atomics; wrap-around
 // addition is order independent, so the result is deterministic.
 constexpr int KS_LANES = 64, KS_CHUNK_WORDS = 4 * KS_LANES, KS_STAGES = 2;
+#ifndef MKT_KS_BATCH
+#define MKT_KS_BATCH 8
+#endif
+constexpr int KS_BATCH = (MKT_KS_BATCH);
 
-template <typename WORD, int G>
-__global__ __launch_bounds__(KS_LANES) void keyswitch_mg_kernel(const KsArgs a, int B, int ngroups, int jslab) {
+// WAVES > 1: the waves of a workgroup (each with its own G ciphertexts) share one staged table -- every row is fetched
+// from L2 / Infinity Cache once per WAVES*G ciphertexts; one barrier per stage (the two stage buffers alternate, and
+// a wave reaches the next barrier only after its reads of the previous stage).
+// BAL: balanced (signed) digits of the block schemes -- a template flag so the unbalanced path carries none of the
+// sign handling on the scalar unit (one per CU, and the busiest unit of this kernel)
+template <typename WORD, int G, int WAVES, bool BAL>
+__global__ __launch_bounds__(KS_LANES * WAVES) void keyswitch_mg_kernel(const KsArgs a, int B, int ngroups, int jslab) {
     // digit table: [stage][1 + drows (+ drows negated rows for balanced digits)][lane]
     uint4 *tabp = reinterpret_cast<uint4 *>(mkt_smem);
-    const int trows = 1 + a.drows * (a.balanced ? 2 : 1);
+    const int trows = 1 + a.drows * (BAL ? 2 : 1);
 #define tab(s, r, l) tabp[((s) * trows + (r)) * KS_LANES + (l)]
-    const int lane = threadIdx.x;
-    const int gg = (int)(blockIdx.x % (unsigned)ngroups), slab = (int)(blockIdx.x / (unsigned)ngroups);
+    const int lane = threadIdx.x & (KS_LANES - 1);
+    const int wv = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / KS_LANES)) : 0;   // wave-uniform, and known to be
+    const int gblocks = (ngroups + WAVES - 1) / WAVES;
+    const int gg = (int)(blockIdx.x % (unsigned)gblocks) * WAVES + wv, slab = (int)(blockIdx.x / (unsigned)gblocks);
     const int N = a.N, n = a.n, n1p = a.n1p, f = a.f, logD = a.logD;
     const int q0 = (int)blockIdx.z * KS_CHUNK_WORDS + 4 * lane;
     const bool active = q0 < n1p;
@@ -960,13 +974,15 @@ __global__ __launch_bounds__(KS_LANES) void keyswitch_mg_kernel(const KsArgs a, 
     uint4 sum[G];
 #pragma unroll
     for (int g = 0; g < G; g++) sum[g] = make_uint4(0, 0, 0, 0);
+    if (wv == 0) {
 #pragma unroll
-    for (int s = 0; s < KS_STAGES; s++) tab(s, 0, lane) = make_uint4(0, 0, 0, 0);   // digit 0 adds nothing
+        for (int s = 0; s < KS_STAGES; s++) tab(s, 0, lane) = make_uint4(0, 0, 0, 0);   // digit 0 adds nothing
+    }
 
     for (int c = c_begin; c < c_end; c++) {
         const uint32_t *ksk = a.mk ? a.ksk + (size_t)c * a.ksk_party_stride : a.ksk + (size_t)c * comp_words;
         int jstart = 0;
-        if (a.balanced) {
+        if (BAL) {
             if (a.lmss) { const long cur = (long)c * N; jstart = cur >= n ? 0 : (cur + N <= n ? N : (int)(n - cur)); }
             else jstart = n;
         }
@@ -980,24 +996,34 @@ __global__ __launch_bounds__(KS_LANES) void keyswitch_mg_kernel(const KsArgs a, 
                 const int gi = g_base + g < B ? g_base + g : B - 1;
                 const WORD *ac = reinterpret_cast<const WORD *>(a.acc) + ((size_t)gi * (1 + a.kacc) + 1 + c) * N;
                 const uint32_t w = extract_word<WORD>(ac, j, N);
-                tt[g] = a.balanced ? gb.prep(w) : divbits<uint32_t>(w, 32 - f * logD);   // gsw.jl:42-52 / :34-40
+                tt[g] = BAL ? gb.prep(w) : divbits<uint32_t>(w, 32 - f * logD);   // gsw.jl:42-52 / :34-40
             }
             const uint32_t *rowj = ksk + (size_t)j * drows * f * n1p + q0;
             for (int td = 0; td < f; td++) {
                 const int st = td & (KS_STAGES - 1);
                 const int shift = logD * (f - 1 - td);
-                for (int d = 1; d <= drows; d++) {
+                for (int d = 1 + wv; d <= drows; d += WAVES) {              // the waves share the row fetches
                     uint4 r = make_uint4(0, 0, 0, 0);
                     if (active) r = *reinterpret_cast<const uint4 *>(rowj + ((size_t)(d - 1) * f + td) * n1p);
                     tab(st, d, lane) = r;
-                    if (a.balanced) tab(st, drows + d, lane) = make_uint4(0u - r.x, 0u - r.y, 0u - r.z, 0u - r.w);
+                    if (BAL) tab(st, drows + d, lane) = make_uint4(0u - r.x, 0u - r.y, 0u - r.z, 0u - r.w);
                 }
+                if (WAVES > 1) __syncthreads();
+                // KS_BATCH table reads are issued back to back before their sums: one LDS latency per batch instead of
+                // one per ciphertext
 #pragma unroll
-                for (int g = 0; g < G; g++) {
-                    int idx = (int)((tt[g] >> shift) & Dm);
-                    if (a.balanced) { idx -= half; if (idx < 0) idx = drows - idx; }   // -1 -> drows+1, -2 -> drows+2
-                    const uint4 v = tab(st, idx, lane);
-                    sum[g].x += v.x; sum[g].y += v.y; sum[g].z += v.z; sum[g].w += v.w;
+                for (int g0 = 0; g0 < G; g0 += KS_BATCH) {
+                    uint4 v[KS_BATCH];
+#pragma unroll
+                    for (int u = 0; u < KS_BATCH; u++) {
+                        int idx = (int)((tt[g0 + u] >> shift) & Dm);
+                        if (BAL) { idx -= half; if (idx < 0) idx = drows - idx; }   // -1 -> drows+1, -2 -> drows+2
+                        v[u] = tab(st, idx, lane);
+                    }
+#pragma unroll
+                    for (int u = 0; u < KS_BATCH; u++) {
+                        sum[g0 + u].x += v[u].x; sum[g0 + u].y += v[u].y; sum[g0 + u].z += v[u].z; sum[g0 + u].w += v[u].w;
+                    }
                 }
             }
         }
@@ -1279,11 +1305,24 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     if (slabs > a.N / 8) slabs = a.N / 8;
     const int jslab = (a.N + slabs - 1) / slabs;
     slabs = (a.N + jslab - 1) / jslab;
-    const dim3 grid((unsigned)(ngroups * slabs), (unsigned)parties, (unsigned)((a.n1p + KS_CHUNK_WORDS - 1) / KS_CHUNK_WORDS));
+    int waves = MKT_KS_WAVES;
+    if (const char *e = getenv("MKT_KS_WAVES")) waves = atoi(e);
+    if (waves != 2 && waves != 4) waves = 1;
+    if (G != 32) waves = 1;
+    const int gblocks = (ngroups + waves - 1) / waves;
+    if (waves > 1) {   // same number of waves in flight as the single-wave launch
+        slabs = (target_blocks + ngroups * parties - 1) / (ngroups * parties);
+        if (slabs < 1) slabs = 1;
+        if (slabs > a.N / 8) slabs = a.N / 8;
+    }
+    const dim3 grid((unsigned)(gblocks * slabs), (unsigned)parties, (unsigned)((a.n1p + KS_CHUNK_WORDS - 1) / KS_CHUNK_WORDS));
     const size_t ks_lds = (size_t)KS_STAGES * (1 + a.drows * (a.balanced ? 2 : 1)) * KS_LANES * sizeof(uint4);
     if (ks_lds > 64 * 1024) return hipErrorInvalidValue;   // logD <= 5
     const size_t total = B * (size_t)(parties * a.n + 1);
-#define MKT_KS_LAUNCH(WT, GV) hipLaunchKernelGGL((keyswitch_mg_kernel<WT, GV>), grid, dim3(KS_LANES), ks_lds, s, a, (int)B, ngroups, jslab)
+#define MKT_KS_LAUNCH_B(WT, GV, BV) do { if (GV == 32 && waves == 4) hipLaunchKernelGGL((keyswitch_mg_kernel<WT, 32, 4, BV>), grid, dim3(KS_LANES * 4), ks_lds, s, a, (int)B, ngroups, jslab); \
+        else if (GV == 32 && waves == 2) hipLaunchKernelGGL((keyswitch_mg_kernel<WT, 32, 2, BV>), grid, dim3(KS_LANES * 2), ks_lds, s, a, (int)B, ngroups, jslab); \
+        else hipLaunchKernelGGL((keyswitch_mg_kernel<WT, GV, 1, BV>), grid, dim3(KS_LANES), ks_lds, s, a, (int)B, ngroups, jslab); } while (0)
+#define MKT_KS_LAUNCH(WT, GV) do { if (a.balanced) MKT_KS_LAUNCH_B(WT, GV, true); else MKT_KS_LAUNCH_B(WT, GV, false); } while (0)
     if (W == 64) {
         hipLaunchKernelGGL(ks_init_kernel<uint64_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
         if (G == 8) MKT_KS_LAUNCH(uint64_t, 8); else if (G == 32) MKT_KS_LAUNCH(uint64_t, 32); else MKT_KS_LAUNCH(uint64_t, 16);
@@ -1291,6 +1330,7 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
         hipLaunchKernelGGL(ks_init_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
         if (G == 8) MKT_KS_LAUNCH(uint32_t, 8); else if (G == 32) MKT_KS_LAUNCH(uint32_t, 32); else MKT_KS_LAUNCH(uint32_t, 16);
     }
+#undef MKT_KS_LAUNCH_B
 #undef MKT_KS_LAUNCH
     return hipGetLastError();
 }
