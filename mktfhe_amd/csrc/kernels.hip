@@ -1309,6 +1309,7 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     if (const char *e = getenv("MKT_KS_WAVES")) waves = atoi(e);
     if (waves != 2 && waves != 4) waves = 1;
     if (G != 32) waves = 1;
+    if (a.balanced && a.mk && !getenv("MKT_KS_WAVES")) waves = 1;   // KMS_block: measured 2.7 ms alone vs 4.0 ms shared (KMS2partyblock)
     const int gblocks = (ngroups + waves - 1) / waves;
     if (waves > 1) {   // same number of waves in flight as the single-wave launch
         slabs = (target_blocks + ngroups * parties - 1) / (ngroups * parties);
