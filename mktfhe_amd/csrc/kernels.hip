@@ -1211,7 +1211,7 @@ static hipError_t launch_rot_one(const RotArgs &a, size_t nrot, hipStream_t s) {
 template <int LM, typename WORD>
 static hipError_t launch_rot_lb(const RotArgs &a, size_t nrot, hipStream_t s) {
     int variant = a.variant;
-    if (variant == 0) variant = (LM <= 9 || a.blk_len > 1) ? 22 : 21;   // pairs of transforms up to M = 512 and for the block schemes, single transforms above (measured)
+    if (variant == 0) variant = (LM <= 10 || a.blk_len > 1) ? 22 : 21;   // pairs of transforms up to M = 1024 (re-measured with the specialised kernels: +4 % at M = 1024) and for the block schemes; single transforms above (LDS)
     if ((2 * a.l) % (variant % 10) != 0) variant = (variant / 10) * 10 + 1;
     switch (a.blk_len) {
     case 1:
