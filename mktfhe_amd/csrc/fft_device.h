@@ -240,17 +240,17 @@ __device__ __forceinline__ void exchange_lane_odd_inv(cplx (&z)[NB][4], const La
 #define MKT_LANE_EXCHANGE 4   // 0: every exchange through LDS; 1: in-wave wherever legal; 2: only the single-stage window;
                               // 3: 2 + quad-local (d = 1, 2); 5-7: route mixes for tuning; 8: single-stage window + the
                               // transposes along lane bits 2-5 (bank-masked DPP / permlane swaps), quad-local ones via LDS;
-                              // 4 (default, measured): 8 for odd log2 M, 1 for even
+                              // 4 (default, measured): 8 at every size (with paired transforms also at M = 1024: +3 % over 1)
 #endif
 
 // which route the exchange between two windows of the schedule takes (compile time): 0 LDS, 1 in-wave 4x4, 2 odd window
-template <int LOGM, int LOGR>
+template <int LOGM, int LOGR, int MO = -1>      // MO >= 0: exchange-route mode of this kernel (else MKT_LANE_EXCHANGE)
 struct Route {
     using P = Plan<LOGM, LOGR>;
     static constexpr int LANEBITS = (LOGM - LOGR) < 6 ? (LOGM - LOGR) : 6;   // thread bits that are lane bits
     __host__ __device__ static constexpr int of(int lo_a, int lo_b) {
         const int lomin = lo_a < lo_b ? lo_a : lo_b, diff = lo_a < lo_b ? lo_b - lo_a : lo_a - lo_b;
-        constexpr int MODE = MKT_LANE_EXCHANGE == 4 ? ((LOGM & 1) ? 8 : 1) : ((LOGM & 1) && MKT_LANE_EXCHANGE >= 5 && MKT_LANE_EXCHANGE <= 7 ? 2 : MKT_LANE_EXCHANGE);
+        constexpr int MODE = MO >= 0 ? MO : MKT_LANE_EXCHANGE == 4 ? 8 : ((LOGM & 1) && MKT_LANE_EXCHANGE >= 5 && MKT_LANE_EXCHANGE <= 7 ? 2 : MKT_LANE_EXCHANGE);
         if ((MODE == 1 || (MODE == 3 && lomin == 0) || (MODE == 5 && (lomin == 4 || lomin == 0)) || (MODE == 6 && lomin == 4) || (MODE == 7 && (lomin == 4 || lomin == 2)) || (MODE == 8 && (lomin == 4 || lomin == 2))) && LOGR == 2 && diff == 2 && lomin + 2 <= LANEBITS && lomin + 2 <= (MKT_PERMLANE_SWAP ? 6 : 5)) return 1;
         if (MODE >= 1 && LOGR == 2 && diff == 1 && lomin == P::OVL && LANEBITS >= lomin + 1) return 2;
         return 0;
@@ -267,9 +267,9 @@ struct Route {
 
 // one exchange between the windows lo_from / lo_to of the schedule, by the cheapest legal route; PASS = the pass
 // whose output is exchanged (selects the staging buffer)
-template <int LOGM, int LOGR, int NB, int LO_FROM, int LO_TO, bool FWD, int PASS>
+template <int LOGM, int LOGR, int NB, int LO_FROM, int LO_TO, bool FWD, int PASS, int MO = -1>
 __device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *lds, int t, const LaneX &lx) {
-    constexpr int R = Route<LOGM, LOGR>::of(LO_FROM, LO_TO);
+    constexpr int R = Route<LOGM, LOGR, MO>::of(LO_FROM, LO_TO);
     if constexpr (R == 1) exchange_lane_full<(LO_FROM < LO_TO ? LO_FROM : LO_TO), NB>(z, lx);
     else if constexpr (R == 2) { constexpr int LB = Plan<LOGM, LOGR>::OVL; if constexpr (FWD) exchange_lane_odd_fwd<NB, LB>(z, lx); else exchange_lane_odd_inv<NB, LB>(z, lx); }
     else exchange_lds<LOGM, LOGR, NB>(z, lds + (PASS & 1) * Plan<LOGM, LOGR, NB>::BUF, t, LO_FROM, LO_TO);
@@ -279,7 +279,7 @@ __device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *lds, in
 //   u = a[j+k] * Psi[m + (j >> (b+1))];  a[j], a[j+k] = a[j] + u, a[j] - u
 // In: slot e = point e*NT + t.  Out: slot e = point t*R + e.  NB independent transforms share the
 // twiddle loads and the barriers.
-template <int LOGM, int LOGR, int NB, int PASS = 0>
+template <int LOGM, int LOGR, int NB, int PASS = 0, int MO = -1>
 __device__ __forceinline__ void fft_forward_pass(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t, const LaneX &lx) {
     using P = Plan<LOGM, LOGR, NB>;
     constexpr int p = PASS, lo = P::lo(p);
@@ -303,21 +303,21 @@ __device__ __forceinline__ void fft_forward_pass(cplx (&z)[NB][1 << LOGR], const
         }
     }
     if constexpr (p < P::NPASS - 1) {
-        exchange<LOGM, LOGR, NB, P::lo(p), P::lo(p + 1), true, PASS>(z, lds, t, lx);
-        fft_forward_pass<LOGM, LOGR, NB, PASS + 1>(z, psi, lds, t, lx);
+        exchange<LOGM, LOGR, NB, P::lo(p), P::lo(p + 1), true, PASS, MO>(z, lds, t, lx);
+        fft_forward_pass<LOGM, LOGR, NB, PASS + 1, MO>(z, psi, lds, t, lx);
     }
 }
-template <int LOGM, int LOGR, int NB>
+template <int LOGM, int LOGR, int NB, int MO = -1>
 __device__ __forceinline__ void fft_forward(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t, const LaneX &lx) {
-    if (Route<LOGM, LOGR>::guard_fwd) __syncthreads();
-    fft_forward_pass<LOGM, LOGR, NB, 0>(z, psi, lds, t, lx);
+    if (Route<LOGM, LOGR, MO>::guard_fwd) __syncthreads();
+    fft_forward_pass<LOGM, LOGR, NB, 0, MO>(z, psi, lds, t, lx);
 }
 
 // fft.jl:159-209: t, u = a[j], a[j+k];  a[j] = t + u;  a[j+k] = (t - u) * Psiinv[m + (j >> (b+1))]
 // In: slot e = point t*R + e.  Out: slot e = point e*NT + t.
 // CONJ: `psiinv` points at the FORWARD table Psi and the butterflies multiply by its conjugate (Psiinv == conj(Psi)
 // entry for entry, fft.jl:33-34), so one table -- e.g. a copy resident in LDS -- serves both directions.
-template <int LOGM, int LOGR, int NB, bool CONJ, int PASS>
+template <int LOGM, int LOGR, int NB, bool CONJ, int PASS, int MO = -1>
 __device__ __forceinline__ void fft_inverse_pass(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t, const LaneX &lx) {
     using P = Plan<LOGM, LOGR, NB>;
     constexpr int p = PASS, lo = P::lo(p);
@@ -341,14 +341,14 @@ __device__ __forceinline__ void fft_inverse_pass(cplx (&z)[NB][1 << LOGR], const
         }
     }
     if constexpr (p > 0) {
-        exchange<LOGM, LOGR, NB, P::lo(p), P::lo(p - 1), false, PASS>(z, lds, t, lx);
-        fft_inverse_pass<LOGM, LOGR, NB, CONJ, PASS - 1>(z, psiinv, lds, t, lx);
+        exchange<LOGM, LOGR, NB, P::lo(p), P::lo(p - 1), false, PASS, MO>(z, lds, t, lx);
+        fft_inverse_pass<LOGM, LOGR, NB, CONJ, PASS - 1, MO>(z, psiinv, lds, t, lx);
     }
 }
-template <int LOGM, int LOGR, int NB, bool CONJ = false>
+template <int LOGM, int LOGR, int NB, bool CONJ = false, int MO = -1>
 __device__ __forceinline__ void fft_inverse(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t, const LaneX &lx) {
-    if (Route<LOGM, LOGR>::guard_inv) __syncthreads();
-    fft_inverse_pass<LOGM, LOGR, NB, CONJ, Plan<LOGM, LOGR, NB>::NPASS - 1>(z, psiinv, lds, t, lx);
+    if (Route<LOGM, LOGR, MO>::guard_inv) __syncthreads();
+    fft_inverse_pass<LOGM, LOGR, NB, CONJ, Plan<LOGM, LOGR, NB>::NPASS - 1, MO>(z, psiinv, lds, t, lx);
 }
 
 // Device point order of the resident TransPolys (keys, monomial table, phase-1 output): where the
