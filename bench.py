@@ -120,11 +120,11 @@ def main():
     # ---- synthetic inputs: seeded keys (seed 1), encryptions of uniform bits (seed 2) ----
     if p.multikey:
         crs = mk.CRS(p, 1)
-        keys = [mk.party_keygen(crs, p, seed=1, party=i, secrets_only=not need_host_keys) for i in range(p.k)]
+        keys = [mk.party_keygen(crs, p, deterministic_seed=1, party=i, secrets_only=not need_host_keys) for i in range(p.k)]
         sch = mk.setup(p, keys=keys, a=crs, device=local)
     else:
         crs = None
-        keys = [mk.PartyKeys(p, seed=1, secrets_only=not need_host_keys)]
+        keys = [mk.PartyKeys(p, deterministic_seed=1, secrets_only=not need_host_keys)]
         sch = mk.setup(p, keys=keys[0], device=local)[1]
     rng = np.random.default_rng(2 + rank)
 
@@ -133,7 +133,7 @@ def main():
         b = rng.integers(0, 2, nct).astype(bool)
         ct = np.empty((nct, p.lwe_len), dtype=np.uint32)
         for j in range(nct):
-            ct[j] = mk.lwe_ith_encrypt(int(b[j]), j % p.nparty, keys[j % p.nparty], p, seed=seed0 + j)
+            ct[j] = mk.lwe_ith_encrypt(int(b[j]), j % p.nparty, keys[j % p.nparty], p, deterministic_seed=seed0 + j)
         return b, torch.from_numpy(ct.view(np.int32)).to(dev)
 
     # Inputs.  A fresh multi-key encryption has only its own party's mask block populated, gates between ciphertexts

@@ -19,9 +19,12 @@ int main(int argc, char **argv) {
     mkt_ctx *ctx = NULL;
 
     uint64_t *crs = malloc(sizeof(uint64_t) * (size_t)p.l_uni * p.N);
-    CK(mkt_client_crs(&p, 1, crs));
+    /* pinned seeds so the example is reproducible -- a real client passes NULL (fresh OS entropy per call) */
+    uint8_t seed[32];
+    CK(mkt_client_test_seed(1, seed));
+    CK(mkt_client_crs(&p, seed, crs));
     mkt_client_party *party[2];
-    for (int i = 0; i < 2; i++) CK(mkt_client_party_keygen(&p, 1, i, crs, alpha, beta, &party[i]));
+    for (int i = 0; i < 2; i++) CK(mkt_client_party_keygen(&p, seed, i, crs, alpha, beta, &party[i]));
 
     CK(mkt_ctx_create(&p, MKT_ARITH_F64REF, 0, &ctx));
     CK(mkt_load_crs(ctx, crs, MKT_FMT_INT_COEFF));
@@ -37,8 +40,8 @@ int main(int argc, char **argv) {
     int bx[8], by[8], bad = 0;
     for (int j = 0; j < B; j++) {
         bx[j] = j & 1; by[j] = (j >> 1) & 1;
-        CK(mkt_client_lwe_encrypt(&p, party[0], 0, bx[j], alpha, 100 + j, x + (size_t)j * len));   /* party 0's bit */
-        CK(mkt_client_lwe_encrypt(&p, party[1], 1, by[j], alpha, 200 + j, y + (size_t)j * len));   /* party 1's bit */
+        CK(mkt_client_lwe_encrypt(&p, party[0], 0, bx[j], alpha, NULL, x + (size_t)j * len));   /* party 0's bit, fresh randomness */
+        CK(mkt_client_lwe_encrypt(&p, party[1], 1, by[j], alpha, NULL, y + (size_t)j * len));   /* party 1's bit */
     }
     CK(mkt_gate_batch(ctx, MKT_NAND, x, y, z, B, MKT_MEM_HOST));
     for (int j = 0; j < B; j++) {

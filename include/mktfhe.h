@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MKT_ABI_VERSION 1
+#define MKT_ABI_VERSION 2
 
 typedef enum {
     MKT_OK = 0,
@@ -117,7 +117,11 @@ int mkt_load_crs(mkt_ctx *ctx, const void *a, int fmt);
  *      :143-151 (RGSW / UniEnc bootstrapping key, LEV key-switching key) for party `party`.  Exact integer arithmetic;
  *      `keys` holds the party's secrets (mkt_client_party_secrets or _keygen); `crs` = the integer CRS
  *      (mkt_client_crs) for CCS, NULL otherwise.  Equivalent to mkt_load_brk + mkt_load_ksk of the host-generated
- *      keys of the same seed, word for word. ---- */
+ *      keys of the same seed, word for word.
+ *      TRUST: this call hands party `party`'s SECRET keys to the GPU of this context.  It is a party-local operation:
+ *      a party runs it on its own machine / GPU and ships the resulting evaluation keys (key blob) to the evaluator.
+ *      An evaluator context that runs it for every party holds all k secrets -- acceptable only in tests and
+ *      benchmarks.  The secret buffers are zeroed on the device before they are freed. ---- */
 int mkt_keygen_device(mkt_ctx *ctx, int party, const mkt_client_party *keys, const void *crs);
 /* read a party's key-switching key back in the host layout of mkt_load_ksk (tests) */
 int mkt_get_ksk(mkt_ctx *ctx, int party, uint32_t *out_host);                           /* scheme.jl:409-410 */
@@ -156,21 +160,29 @@ int mkt_get_monomial(mkt_ctx *ctx, int e, double *out_host);
 int mkt_enable_timing(mkt_ctx *ctx, int on);
 int mkt_last_kernel_ms(mkt_ctx *ctx, int which, double *ms);
 
-/* ---- client side (host only, no GPU): seeded counterparts of the reference's key generation and
- *      encryption, exact integer arithmetic.  setup/party_keygen scheme.jl:151,:190,:227,:273,:324;
- *      keygen.jl; lwe_encrypt scheme.jl:352-386; lwe_decrypt scheme.jl:388-407; CRS scheme.jl:409 ---- */
-/* crs: [l_uni][N] ring words (MK schemes), filled from `seed` */
-int mkt_client_crs(const mkt_params *params, uint64_t seed, void *crs_out);
+/* ---- client side (host only, no GPU): counterparts of the reference's key generation and encryption,
+ *      exact integer arithmetic.  setup/party_keygen scheme.jl:151,:190,:227,:273,:324; keygen.jl;
+ *      lwe_encrypt scheme.jl:352-386; lwe_decrypt scheme.jl:388-407; CRS scheme.jl:409
+ *
+ *      RANDOMNESS.  Every `seed` below is a 256-bit value (32 bytes) keying ChaCha20 streams, or NULL.
+ *      NULL -- what a caller should pass -- draws a fresh seed from the OS (getrandom) for that call, as the
+ *      reference draws fresh ChaCha20 entropy per call (sampler.jl:1-34).  A pinned seed makes keys and
+ *      ciphertexts reproducible and therefore PUBLIC: pinned seeds (mkt_client_test_seed) are for tests and
+ *      benchmarks only. ---- */
+int mkt_client_random_seed(uint8_t out[32]);            /* 32 bytes of OS entropy */
+int mkt_client_test_seed(uint64_t n, uint8_t out[32]);  /* TESTS / BENCHMARKS ONLY: deterministic expansion of n */
+/* crs: [l_uni][N] ring words (MK schemes) */
+int mkt_client_crs(const mkt_params *params, const uint8_t *seed, void *crs_out);
 /* one party's secret + evaluation keys; crs may be NULL for SK schemes; sigma_lwe/sigma_ring are the
  * absolute noise standard deviations alpha/beta of params.jl */
-int mkt_client_party_keygen(const mkt_params *params, uint64_t seed, int party, const void *crs,
+int mkt_client_party_keygen(const mkt_params *params, const uint8_t *seed, int party, const void *crs,
                             double sigma_lwe, double sigma_ring, mkt_client_party **out);
 /* the same party WITHOUT the two large keys (bootstrapping key, key-switching key: mkt_client_brk / _ksk are empty):
  * secrets, public key and relinearisation key only -- for mkt_keygen_device, which generates the large keys on the
- * GPU from the same seeded streams (identical words to mkt_client_party_keygen) */
-int mkt_client_party_secrets(const mkt_params *params, uint64_t seed, int party, const void *crs,
+ * GPU from the same streams (identical words to mkt_client_party_keygen with the same seed) */
+int mkt_client_party_secrets(const mkt_params *params, const uint8_t *seed, int party, const void *crs,
                              double sigma_lwe, double sigma_ring, mkt_client_party **out);
-int mkt_client_party_destroy(mkt_client_party *p);
+int mkt_client_party_destroy(mkt_client_party *p);   /* wipes the secrets */
 /* sizes in bytes / pointers to the flat key material (layouts above), valid until destroy */
 const uint32_t *mkt_client_lwekey(const mkt_client_party *p);             /* [n] 0/1 */
 const void *mkt_client_brk(const mkt_client_party *p, size_t *bytes);     /* INT_COEFF */
@@ -180,7 +192,7 @@ const void *mkt_client_rlk_f(const mkt_client_party *p, size_t *bytes);
 const void *mkt_client_pubkey(const mkt_client_party *p, size_t *bytes);
 /* lwe_encrypt (SK: party = 0) / lwe_ith_encrypt (MK): out [k*n+1] */
 int mkt_client_lwe_encrypt(const mkt_params *params, const mkt_client_party *p, int party, int bit,
-                           double sigma_lwe, uint64_t seed, uint32_t *out);
+                           double sigma_lwe, const uint8_t *seed, uint32_t *out);
 /* lwe_decrypt: keys = nparties pointers; returns 0/1, <0 on error */
 int mkt_client_lwe_decrypt(const mkt_params *params, const mkt_client_party *const *keys, int nparties,
                            const uint32_t *lwe);

@@ -57,9 +57,11 @@ SYMBOLS = {
     "mkt_get_monomial": (_i, [_vp, _i, _vp]),
     "mkt_enable_timing": (_i, [_vp, _i]),
     "mkt_last_kernel_ms": (_i, [_vp, _i, C.POINTER(_dbl)]),
-    "mkt_client_crs": (_i, [_pp, _u64, _vp]),
-    "mkt_client_party_keygen": (_i, [_pp, _u64, _i, _vp, _dbl, _dbl, C.POINTER(_vp)]),
-    "mkt_client_party_secrets": (_i, [_pp, _u64, _i, _vp, _dbl, _dbl, C.POINTER(_vp)]),
+    "mkt_client_random_seed": (_i, [_vp]),
+    "mkt_client_test_seed": (_i, [_u64, _vp]),
+    "mkt_client_crs": (_i, [_pp, _vp, _vp]),
+    "mkt_client_party_keygen": (_i, [_pp, _vp, _i, _vp, _dbl, _dbl, C.POINTER(_vp)]),
+    "mkt_client_party_secrets": (_i, [_pp, _vp, _i, _vp, _dbl, _dbl, C.POINTER(_vp)]),
     "mkt_client_party_destroy": (_i, [_vp]),
     "mkt_client_lwekey": (_vp, [_vp]),
     "mkt_client_brk": (_vp, [_vp, C.POINTER(_sz)]),
@@ -67,7 +69,7 @@ SYMBOLS = {
     "mkt_client_rlk_d": (_vp, [_vp, C.POINTER(_sz)]),
     "mkt_client_rlk_f": (_vp, [_vp, C.POINTER(_sz)]),
     "mkt_client_pubkey": (_vp, [_vp, C.POINTER(_sz)]),
-    "mkt_client_lwe_encrypt": (_i, [_pp, _vp, _i, _i, _dbl, _u64, _vp]),
+    "mkt_client_lwe_encrypt": (_i, [_pp, _vp, _i, _i, _dbl, _vp, _vp]),
     "mkt_client_lwe_decrypt": (_i, [_pp, C.POINTER(_vp), _i, _vp]),
 }
 

@@ -1,16 +1,20 @@
-// Client side of the boundary (host only, no GPU): seeded key generation, encryption, decryption.
+// Client side of the boundary (host only, no GPU): key generation, encryption, decryption.
 // Counterpart of the reference's setup / party_keygen / lwe_encrypt / lwe_ith_encrypt / lwe_decrypt /
 // CRS (src/tfhe/scheme.jl:151-410, src/tfhe/keygen.jl, src/ciphertext/{lwe,lev,gsw,unienc,key}.jl).
-// Differences by design: randomness is a seeded xoshiro256** (the reference draws fresh ChaCha20
-// entropy per call, sampler.jl:1-34) and the RLWE products are exact integer arithmetic mod 2^W (the
-// reference approximates them with a Float64x2 FFT, params.jl:1).  Keys leave in integer (coefficient)
+// Randomness: ChaCha20 streams keyed by a 256-bit seed (rng_chacha.h); a NULL seed draws fresh entropy from
+// the OS for that call, as the reference does per call (ChaCha20Stream, sampler.jl:1-34) -- pinned seeds are
+// for tests and benchmarks only.  Difference by design: the RLWE products are exact integer arithmetic
+// mod 2^W (the reference approximates them with a Float64x2 FFT, params.jl:1).  Keys leave in integer (coefficient)
 // form; the device pre-transforms them (mkt_load_* with MKT_FMT_INT_COEFF).
 #include <cmath>
 #include <cstring>
 #include <functional>
 #include <thread>
 
+#include <sys/random.h>
+
 #include "host_internal.h"
+#include "rng_chacha.h"
 
 namespace mkt {
 
@@ -36,36 +40,23 @@ int validate_params(const mkt_params &p, std::string &why) {
 
 namespace {
 
-struct Rng {  // xoshiro256** seeded through splitmix64 from a (seed, stream...) tuple
-    uint64_t s[4];
-    static uint64_t splitmix(uint64_t &x) {
-        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
+using mktrng::Rng;
+
+// 256-bit seed -> key words; NULL = fresh OS entropy (getrandom), never a fixed default
+int seed_to_key(const uint8_t *seed, uint32_t key[8]) {
+    uint8_t tmp[32];
+    if (!seed) {
+        size_t got = 0;
+        while (got < sizeof tmp) {
+            ssize_t r = getrandom(tmp + got, sizeof tmp - got, 0);
+            if (r <= 0) return MKT_ERR_STATE;
+            got += (size_t)r;
+        }
+        seed = tmp;
     }
-    Rng(uint64_t seed, uint64_t a, uint64_t b = 0, uint64_t c = 0) {
-        uint64_t x = seed;
-        x = splitmix(x) ^ (a * 0xD6E8FEB86659FD93ull); x = splitmix(x) ^ (b * 0xA0761D6478BD642Full);
-        x = splitmix(x) ^ (c * 0xE7037ED1A0B428DBull);
-        for (int i = 0; i < 4; i++) s[i] = splitmix(x);
-    }
-    static uint64_t rotl(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
-    uint64_t next() {
-        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
-        return r;
-    }
-    double uniform() { return (double)(next() >> 11) * 0x1p-53; }
-    // unit-variance approximately normal deviate: centred sum of 16 uniforms (pure IEEE add/mul,
-    // hence identical on every machine; the reference uses randn, sampler.jl:24-28)
-    double gauss() {
-        double acc = 0.0;
-        for (int i = 0; i < 16; i++) acc += uniform();
-        return (acc - 8.0) * 0.8660254037844386;
-    }
-    uint64_t noise(double sigma) { return (uint64_t)(int64_t)std::nearbyint(sigma * gauss()); }  // round(signed(T), sigma*randn)
-};
+    std::memcpy(key, seed, 32);
+    return MKT_OK;
+}
 
 inline uint64_t wmask(int W) { return W == 64 ? ~0ull : ((1ull << W) - 1); }
 
@@ -134,12 +125,38 @@ int mkt_make_twiddles(int N, int which, double *out_host) {
     return MKT_OK;
 }
 
-int mkt_client_crs(const mkt_params *params, uint64_t seed, void *crs_out) {
+// a fresh 256-bit seed from the OS (what a NULL seed argument uses internally)
+int mkt_client_random_seed(uint8_t out[32]) {
+    if (!out) return MKT_ERR_ARG;
+    uint32_t key[8];
+    if (seed_to_key(nullptr, key)) return MKT_ERR_STATE;
+    std::memcpy(out, key, 32);
+    return MKT_OK;
+}
+
+// TESTS AND BENCHMARKS ONLY: expands a small integer into a 256-bit seed so that keys and ciphertexts are
+// reproducible.  Anything encrypted under such a seed is public.
+int mkt_client_test_seed(uint64_t n, uint8_t out[32]) {
+    if (!out) return MKT_ERR_ARG;
+    uint64_t x = n ^ 0x6D6B746668655F74ull;
+    for (int i = 0; i < 4; i++) {   // splitmix64
+        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        std::memcpy(out + 8 * i, &z, 8);
+    }
+    return MKT_OK;
+}
+
+int mkt_client_crs(const mkt_params *params, const uint8_t *seed, void *crs_out) {
     if (!params || !crs_out) return MKT_ERR_ARG;
     std::string why; if (validate_params(*params, why)) return MKT_ERR_ARG;
     const mkt_params &p = *params;
     if (!is_mk(p.scheme)) return MKT_ERR_ARG;
-    Rng rng(seed, 0xC125);
+    uint32_t key[8];
+    if (seed_to_key(seed, key)) return MKT_ERR_STATE;
+    Rng rng(key, 0, 0xC125);
     uint64_t m = wmask(p.W);
     for (size_t i = 0; i < (size_t)p.l_uni * p.N; i++) {   // scheme.jl:409-410
         uint64_t v = rng.next() & m;
@@ -152,7 +169,7 @@ int mkt_client_crs(const mkt_params *params, uint64_t seed, void *crs_out) {
 
 // heavy = false: secrets and the small keys only (public key, relinearisation key); the bootstrapping and
 // key-switching keys are then generated on the device (mkt_keygen_device) from the same seeded streams
-static int party_keygen_impl(const mkt_params *params, uint64_t seed, int party, const void *crs,
+static int party_keygen_impl(const mkt_params *params, const uint8_t *seed, int party, const void *crs,
                              double sigma_lwe, double sigma_ring, bool heavy, mkt_client_party **out) {
     if (!params || !out) return MKT_ERR_ARG;
     std::string why; if (validate_params(*params, why)) return MKT_ERR_ARG;
@@ -164,12 +181,13 @@ static int party_keygen_impl(const mkt_params *params, uint64_t seed, int party,
     const uint64_t wm = wmask(W);
     auto *K = new mkt_client_party();
     K->p = p; K->sh = sh; K->party = party;
-    const uint64_t ps = seed * 0x100000001B3ull + (uint64_t)party + 1;
-    K->ps = ps; K->sigma_lwe = sigma_lwe; K->sigma_ring = sigma_ring; K->heavy = heavy;
+    if (seed_to_key(seed, K->key)) { delete K; return MKT_ERR_STATE; }
+    const uint32_t *ps = K->key; const uint32_t pa = (uint32_t)party;   // stream key, party index (in the nonce)
+    K->sigma_lwe = sigma_lwe; K->sigma_ring = sigma_ring; K->heavy = heavy;
 
     // ---- secret keys: key.jl:12-19 (binary), sampler.jl:7-21 (block binary), key.jl:52-87 (partial ring key)
     {
-        Rng r(ps, 1);
+        Rng r(ps, pa, 1);
         K->lwekey.assign(n, 0);
         if (is_block(p.scheme)) {
             for (int i = 0; i < p.blk_d; i++) {
@@ -198,7 +216,7 @@ static int party_keygen_impl(const mkt_params *params, uint64_t seed, int party,
         parallel_for(n, [&](int i) {
             std::vector<uint64_t> buf((size_t)polys * N);
             for (int c = 0; c <= kr; c++) for (int j = 0; j < l; j++) {
-                Rng r(ps, 2, (uint64_t)i, (uint64_t)(c * l + j));
+                Rng r(ps, pa, 2, (uint32_t)i, (uint32_t)(c * l + j));
                 rlwe_sample(r, K->zring, 0, kr, sigma_ring, N, W, buf.data());
                 uint64_t g = 1ull << (W - (j + 1) * p.logB_gsw);
                 buf[(size_t)c * N] = (buf[(size_t)c * N] + (uint64_t)K->lwekey[i] * g) & wm;  // c = 0: b[0]; c >= 1: a_{c-1}[0]
@@ -211,7 +229,7 @@ static int party_keygen_impl(const mkt_params *params, uint64_t seed, int party,
         const int l = p.l_uni;
         K->brk.assign((size_t)n * 3 * l * N * sh.word, 0);
         parallel_for(n, [&](int i) {
-            Rng r(ps, 2, (uint64_t)i);
+            Rng r(ps, pa, 2, (uint32_t)i);
             std::vector<int8_t> rt(N);
             for (int q = 0; q < N; q++) rt[q] = (int8_t)((int)(r.next() % 3) - 1);      // ternary r
             std::vector<uint64_t> a(N), d(N), rl((size_t)2 * N);
@@ -238,7 +256,7 @@ static int party_keygen_impl(const mkt_params *params, uint64_t seed, int party,
         const int zi = is_kms(p.scheme) ? 1 : 0;   // uni key
         K->pub.assign((size_t)l * N * sh.word, 0);
         std::vector<uint64_t> a(N), b(N);
-        Rng r(ps, 3);
+        Rng r(ps, pa, 3);
         for (int j = 0; j < l; j++) {
             load_poly(crs, j, a.data(), N, W);
             std::fill(b.begin(), b.end(), 0);
@@ -249,7 +267,7 @@ static int party_keygen_impl(const mkt_params *params, uint64_t seed, int party,
         if (is_kms(p.scheme)) {
             K->rlk_d.assign((size_t)l * N * sh.word, 0);
             K->rlk_f.assign((size_t)l * 2 * N * sh.word, 0);
-            Rng r2(ps, 4);
+            Rng r2(ps, pa, 4);
             std::vector<int8_t> rt(N);
             for (int q = 0; q < N; q++) rt[q] = (int8_t)((int)(r2.next() % 3) - 1);
             std::vector<uint64_t> d(N), rl((size_t)2 * N);
@@ -277,7 +295,7 @@ static int party_keygen_impl(const mkt_params *params, uint64_t seed, int party,
         parallel_for(kk * N, [&](int cj) {
             int c = cj / N, j = cj % N;
             if (is_block(p.scheme) && (long)c * N + j < n) return;       // keygen.jl:46,:147: only beyond the embedded LWE key
-            Rng r(ps, 5, (uint64_t)cj);
+            Rng r(ps, pa, 5, (uint32_t)cj);
             for (int d = 0; d < dr; d++) for (int t = 0; t < f; t++) {
                 uint32_t *row = K->ksk.data() + ((((size_t)c * N + j) * dr + d) * f + t) * n1;
                 uint32_t msg = (uint32_t)((uint32_t)K->zring[zoff + c][j] * (uint32_t)(d + 1)) << (32 - (t + 1) * logD);
@@ -293,17 +311,25 @@ static int party_keygen_impl(const mkt_params *params, uint64_t seed, int party,
 
 extern "C" {
 
-int mkt_client_party_keygen(const mkt_params *params, uint64_t seed, int party, const void *crs,
+int mkt_client_party_keygen(const mkt_params *params, const uint8_t *seed, int party, const void *crs,
                             double sigma_lwe, double sigma_ring, mkt_client_party **out) {
     return party_keygen_impl(params, seed, party, crs, sigma_lwe, sigma_ring, true, out);
 }
 
-int mkt_client_party_secrets(const mkt_params *params, uint64_t seed, int party, const void *crs,
+int mkt_client_party_secrets(const mkt_params *params, const uint8_t *seed, int party, const void *crs,
                              double sigma_lwe, double sigma_ring, mkt_client_party **out) {
     return party_keygen_impl(params, seed, party, crs, sigma_lwe, sigma_ring, false, out);
 }
 
-int mkt_client_party_destroy(mkt_client_party *p) { delete p; return MKT_OK; }
+int mkt_client_party_destroy(mkt_client_party *p) {
+    if (!p) return MKT_OK;
+    // wipe the secrets before the memory goes back to the allocator
+    explicit_bzero(p->key, sizeof p->key);
+    if (!p->lwekey.empty()) explicit_bzero(p->lwekey.data(), p->lwekey.size() * sizeof(uint32_t));
+    for (auto &z : p->zring) if (!z.empty()) explicit_bzero(z.data(), z.size());
+    delete p;
+    return MKT_OK;
+}
 const uint32_t *mkt_client_lwekey(const mkt_client_party *p) { return p ? p->lwekey.data() : nullptr; }
 const void *mkt_client_brk(const mkt_client_party *p, size_t *bytes) { if (bytes) *bytes = p->brk.size(); return p->brk.data(); }
 const uint32_t *mkt_client_ksk(const mkt_client_party *p, size_t *bytes) { if (bytes) *bytes = p->ksk.size() * 4; return p->ksk.data(); }
@@ -313,13 +339,15 @@ const void *mkt_client_pubkey(const mkt_client_party *p, size_t *bytes) { if (by
 
 // scheme.jl:352-386 lwe_encrypt / lwe_ith_encrypt: b = e - <a,s> + (2m-1)*2^29, mask in the party's block
 int mkt_client_lwe_encrypt(const mkt_params *params, const mkt_client_party *K, int party, int bit,
-                           double sigma_lwe, uint64_t seed, uint32_t *out) {
+                           double sigma_lwe, const uint8_t *seed, uint32_t *out) {
     if (!params || !K || !out) return MKT_ERR_ARG;
     const mkt_params &p = *params;
     Shape sh = shape_of(p);
     if (party < 0 || party >= sh.nparty) return MKT_ERR_ARG;
     std::memset(out, 0, sizeof(uint32_t) * (size_t)sh.lwe_len);
-    Rng r(seed, 7, (uint64_t)party);
+    uint32_t key[8];
+    if (seed_to_key(seed, key)) return MKT_ERR_STATE;
+    Rng r(key, (uint32_t)party, 7);
     uint32_t *a = out + (size_t)party * p.n;
     uint32_t dot = 0;
     uint32_t e = (uint32_t)r.noise(sigma_lwe);

@@ -461,7 +461,13 @@ int mkt_keygen_device(mkt_ctx *c, int party, const mkt_client_party *K, const vo
     const int N = p.N, nz = (int)K->zring.size();
     uint32_t *d_lwe = nullptr; int8_t *d_z = nullptr; void *d_crs_int = nullptr, *d_out = nullptr;
     const size_t brk_polys_total = (size_t)p.n * c->sh.brk_polys;
-    auto cleanup = [&] { (void)hipFree(d_lwe); (void)hipFree(d_z); (void)hipFree(d_crs_int); (void)hipFree(d_out); };
+    // the secrets are wiped on the device before their buffers are released
+    auto cleanup = [&] {
+        if (d_lwe) (void)hipMemsetAsync(d_lwe, 0, (size_t)p.n * 4, c->stream);
+        if (d_z) (void)hipMemsetAsync(d_z, 0, (size_t)nz * N, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(d_lwe); (void)hipFree(d_z); (void)hipFree(d_crs_int); (void)hipFree(d_out);
+    };
     hipError_t e = hipMalloc((void **)&d_lwe, (size_t)p.n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d_z, (size_t)nz * N);
     if (e == hipSuccess) e = hipMalloc(&d_out, brk_polys_total * poly_bytes(c));
@@ -471,7 +477,7 @@ int mkt_keygen_device(mkt_ctx *c, int party, const mkt_client_party *K, const vo
     if (e == hipSuccess && unienc) e = hipMemcpyAsync(d_crs_int, crs, (size_t)p.l_uni * poly_bytes(c), hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { cleanup(); return hipfail(c, e, "device keygen setup"); }
     mktd::KeygenArgs a{};
-    a.ps = K->ps; a.N = N; a.n = p.n; a.W = p.W; a.f = p.f; a.logD = p.logD;
+    std::memcpy(a.key, K->key, sizeof a.key); a.party = K->party; a.N = N; a.n = p.n; a.W = p.W; a.f = p.f; a.logD = p.logD;
     a.sigma_ring = K->sigma_ring; a.sigma_lwe = K->sigma_lwe;
     a.lwekey = d_lwe; a.zring = d_z; a.crs = d_crs_int; a.out = d_out;
     if (unienc) { a.kr = 1; a.l = p.l_uni; a.logB = p.logB_uni; a.zoff = 0; }

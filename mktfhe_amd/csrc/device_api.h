@@ -84,9 +84,10 @@ struct KsArgs {
     int lmss;                 // LMSS flavour of the copy rule (global coefficient index across components)
 };
 
-// Evaluation-key generation on the device (keygen.hip): one party's secrets and the stream seed of client.cpp
+// Evaluation-key generation on the device (keygen.hip): one party's secrets and the stream key of client.cpp
 struct KeygenArgs {
-    uint64_t ps;                 // per-party stream seed (client.cpp: seed * 0x100000001B3 + party + 1)
+    uint32_t key[8];             // the party's 256-bit ChaCha20 stream key (rng_chacha.h)
+    int party;                   // party index (carried in the stream nonce)
     int N, n, W;
     int kr, l, logB;             // RGSW: RLWE length, gadget ; UniEnc: l_uni, logB_uni
     int zoff;                    // first ring-key polynomial used

@@ -20,10 +20,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef MKT_ABLATE
-#define MKT_ABLATE 0   // timing-only experiments: 1 no key loads, 2 no twiddle loads, 4 no LDS exchange, 8 no barrier
-#endif
-
 namespace mktd {
 
 struct __attribute__((aligned(16))) cplx { double re, im; };
@@ -99,12 +95,11 @@ __device__ __forceinline__ int lds_pos(int idx) {
 template <int LOGM, int LOGR, int NB>
 __device__ __forceinline__ void exchange_lds(cplx (&z)[NB][1 << LOGR], cplx *buf, int t, int lo_from, int lo_to) {
     constexpr int R = 1 << LOGR, M = 1 << LOGM;
-    if (MKT_ABLATE & 4) return;
 #pragma unroll
     for (int b = 0; b < NB; b++)
 #pragma unroll
         for (int e = 0; e < R; e++) buf[b * M + lds_pos<LOGR>(pt_index<LOGR>(t, e, lo_from))] = z[b][e];
-    if (!(MKT_ABLATE & 8)) __syncthreads();
+    __syncthreads();
 #pragma unroll
     for (int b = 0; b < NB; b++)
 #pragma unroll
@@ -289,7 +284,7 @@ __device__ __forceinline__ void fft_forward_pass(cplx (&z)[NB][1 << LOGR], const
         const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
 #pragma unroll
         for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) {
-            cplx w; if (MKT_ABLATE & 2) { w.re = 0.5 + twbase; w.im = 0.25 * g; } else w = psi[twbase + g];
+            const cplx w = psi[twbase + g];
 #pragma unroll
             for (int q = 0; q < (1 << sb); q++) {
                 const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
@@ -327,7 +322,7 @@ __device__ __forceinline__ void fft_inverse_pass(cplx (&z)[NB][1 << LOGR], const
         const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
 #pragma unroll
         for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) {
-            cplx w; if (MKT_ABLATE & 2) { w.re = 0.5 + twbase; w.im = 0.25 * g; } else w = psiinv[twbase + g];
+            const cplx w = psiinv[twbase + g];
 #pragma unroll
             for (int q = 0; q < (1 << sb); q++) {
                 const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);

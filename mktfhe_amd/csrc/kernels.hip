@@ -8,6 +8,17 @@
 
 #pragma clang fp contract(off)
 
+// The file is compiled once per translation unit MKT_TU (Makefile) so the template instantiations build in parallel:
+//   0 transforms, small kernels, key switch, dispatchers      3 / 5 blind rotation of the block schemes (LMSS, KMS_block), 32- / 64-bit ring
+//   1 blind rotation, 32-bit ring, plain schemes              4 general-k rotation, KMS phase 2, CCS
+//   2 blind rotation, 64-bit ring, plain schemes
+// MKT_TU undefined = everything in one unit.
+#ifdef MKT_TU
+#define MKT_IN_TU(n) (MKT_TU == (n))
+#else
+#define MKT_IN_TU(n) 1
+#endif
+
 namespace mktd {
 
 constexpr int LOGR = MKT_LOGR;  // points per thread (4 by default)
@@ -27,6 +38,7 @@ __device__ __forceinline__ void fft_inverse1(cplx (&z)[1 << LOGR], const cplx *_
     fft_inverse<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][1 << LOGR]>(z), psiinv, lds, t, xs.lx);
 }
 
+#if MKT_IN_TU(0)
 // ------------------------------------------------------------------------------------------------
 // batched transforms (fft.jl:57-63 / :74-81): HBM -> HBM, one polynomial per workgroup pass
 // ------------------------------------------------------------------------------------------------
@@ -117,7 +129,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
                     z[u][e] = cmul(v, rt[e]);
                 }
             if (g + (size_t)PF * gridDim.x < groups) load(d, g + (size_t)PF * gridDim.x);
-            if (!(MKT_ABLATE & 16)) fft_forward<LOGM, LOGR, NBT>(z, psi_f, lds, t, xs.lx);
+            fft_forward<LOGM, LOGR, NBT>(z, psi_f, lds, t, xs.lx);
             const bool contig = !dev_order && MKT_FFT_CONTIG_STORE && P::NPASS > 1;
             if (contig) {
                 __syncthreads();
@@ -265,6 +277,8 @@ __global__ void testvector_kernel(const uint32_t *__restrict__ lin, int lwe_stri
     for (int i = threadIdx.x; i < kacc * N; i += blockDim.x) a[N + i] = 0;
 }
 
+#endif  // TU 0
+
 // ------------------------------------------------------------------------------------------------
 // digit -> transform helper: z[e] = (d(c_idx) - i*d(c_{idx+M})) * roots[idx]   (fft.jl:57-63)
 // ------------------------------------------------------------------------------------------------
@@ -291,15 +305,13 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
     }
 }
 
+#if MKT_IN_TU(1) || MKT_IN_TU(2) || MKT_IN_TU(3) || MKT_IN_TU(5)
 // ------------------------------------------------------------------------------------------------
 // Blind rotation, RLWE length 1.  bootstrapping.jl:32-76 (CGGI), :114-165 (LMSS), :389-443 and
 // :599-659 (KMS / KMS_block phase 1).  One workgroup per rotation; the accumulator (2 polynomials)
 // and the transform-domain accumulator stay in registers for all n CMux steps; LDS only stages the
 // in-transform exchanges.  LB = block length (1 for the plain schemes).
 // ------------------------------------------------------------------------------------------------
-#ifndef MKT_KS_WAVES
-#define MKT_KS_WAVES 4
-#endif
 #ifndef MKT_ROT_LT5
 #define MKT_ROT_LT5 1     // ... and the l = 4, 5, 6 shapes of the larger KMS sets (params.jl:55-125)
 #endif
@@ -439,7 +451,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
                 for (int e = 0; e < R; e++) {                            // :50-51 decompto!, fft.jl:57-63 twist
                     const WORD w0 = isa ? acc[1][e][0] : acc[0][e][0], w1 = isa ? acc[1][e][1] : acc[0][e][1];
                     int d0, d1;
-                    if (MKT_ABLATE & 32) { d0 = (int)(w0 & 7) - 4 + j; d1 = (int)(w1 & 7) - 3; } else { d0 = gd.digit(gd.prep(w0), j); d1 = gd.digit(gd.prep(w1), j); }
+                    d0 = gd.digit(gd.prep(w0), j); d1 = gd.digit(gd.prep(w1), j);
                     cplx v; v.re = (double)d0; v.im = (double)(-d1);
                     z[h2][e] = cmul(v, MKT_ROT_BUFLOAD ? table_load(rs_roots, vo_nat[e], 0) : a.tw.roots[e * NT + t]);
                 }
@@ -455,7 +467,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
                     for (int e = 0; e < R; e++) {                        // :63-68 muladdto!(tacc, digit, row)
                         cplx kb, ka;
-                        if (MKT_ABLATE & 1) { kb.re = 1.5; kb.im = (double)t; ka.re = 2.5; ka.im = (double)e; } else if (MKT_ROT_BUFLOAD) { kb = table_load(rs_brk, vo_dev[e], so_row); ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
+                        if (MKT_ROT_BUFLOAD) { kb = table_load(rs_brk, vo_dev[e], so_row); ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
                         tacc[q][0][e] = cadd(tacc[q][0][e], cmul(z[h2][e], kb));
                         tacc[q][1][e] = cadd(tacc[q][1][e], cmul(z[h2][e], ka));
                         if (RotOcc<LOGM, NB>::MINW >= 3) __builtin_amdgcn_sched_barrier(0);   // keep the key-row live ranges short at 3 waves/SIMD
@@ -469,7 +481,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int e = 0; e < R; e++) { cplx mv; if (MKT_ABLATE & 1) { mv.re = 0.5; mv.im = (double)e; } else mv = MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[0] - 1) * M * sizeof(cplx))) : mono[dev_pos(t * R + e, NT)]; t2[c][e] = cmul(mv, tacc[0][c][e]); }
+                for (int e = 0; e < R; e++) { cplx mv; mv = MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[0] - 1) * M * sizeof(cplx))) : mono[dev_pos(t * R + e, NT)]; t2[c][e] = cmul(mv, tacc[0][c][e]); }
         } else {                                                         // :157 / :648 tacc2 += monomial * tacc
 #pragma unroll
             for (int c = 0; c < 2; c++)
@@ -526,6 +538,9 @@ void blindrotate_k1_kernel(const RotArgs a) {
     }
 }
 
+#endif  // TU 1-3, 5
+
+#if MKT_IN_TU(4)
 // ------------------------------------------------------------------------------------------------
 // CGGI / LMSS blind rotation with RLWE length KR > 1 (bootstrapping.jl:32-76, :114-165 with k = KR): the general-k
 // form of the kernel above for the plain single-key schemes; no shipped parameter set uses it (params.jl:1-13 have
@@ -900,6 +915,9 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
     }
 }
 
+#endif  // TU 4
+
+#if MKT_IN_TU(0)
 // ------------------------------------------------------------------------------------------------
 // Sample extract + LWE key switch.  bootstrapping.jl:81-109 (CGGI), :170-229 (LMSS), :333-364 (CCS),
 // :564-594 (KMS), :664-695 (KMS_block).  Gather-accumulate of pre-multiplied LWE rows; u32 wrap adds
@@ -941,6 +959,9 @@ __global__ void ks_init_kernel(const KsArgs a, size_t B) {
 // reads another lane's data, so there are no barriers).  3 row loads per (j,t) instead of 0.75*G is what matters:
 // the gather is bound by L2 / Infinity-Cache bandwidth.  Partial sums over slabs meet in u32 atomics; wrap-around
 // addition is order independent, so the result is deterministic.
+#ifndef MKT_KS_WAVES
+#define MKT_KS_WAVES 4
+#endif
 constexpr int KS_LANES = 64, KS_CHUNK_WORDS = 4 * KS_LANES, KS_STAGES = 2;
 #ifndef MKT_KS_BATCH
 #define MKT_KS_BATCH 8
@@ -948,8 +969,9 @@ constexpr int KS_LANES = 64, KS_CHUNK_WORDS = 4 * KS_LANES, KS_STAGES = 2;
 constexpr int KS_BATCH = (MKT_KS_BATCH);
 
 // WAVES > 1: the waves of a workgroup (each with its own G ciphertexts) share one staged table -- every row is fetched
-// from L2 / Infinity Cache once per WAVES*G ciphertexts; one barrier per stage (the two stage buffers alternate, and
-// a wave reaches the next barrier only after its reads of the previous stage).
+// from L2 / Infinity Cache once per WAVES*G ciphertexts; one barrier per stage.  The two stage buffers alternate on a
+// counter that runs over the whole (c, j, td) loop, so the buffer a wave overwrites is always the one whose readers
+// have passed the barrier in between (a per-j parity would reuse stage 0 back to back when f is odd).
 // BAL: balanced (signed) digits of the block schemes -- a template flag so the unbalanced path carries none of the
 // sign handling on the scalar unit (one per CU, and the busiest unit of this kernel)
 template <typename WORD, int G, int WAVES, bool BAL>
@@ -982,6 +1004,7 @@ __global__ __launch_bounds__(KS_LANES * WAVES) void keyswitch_mg_kernel(const Ks
         for (int s = 0; s < KS_STAGES; s++) tab(s, 0, lane) = make_uint4(0, 0, 0, 0);   // digit 0 adds nothing
     }
 
+    int it = 0;   // stage counter over the WHOLE (c, j, td) loop: consecutive stagings always alternate buffers, also for odd f
     for (int c = c_begin; c < c_end; c++) {
         const uint32_t *ksk = a.mk ? a.ksk + (size_t)c * a.ksk_party_stride : a.ksk + (size_t)c * comp_words;
         int jstart = 0;
@@ -1003,7 +1026,7 @@ __global__ __launch_bounds__(KS_LANES * WAVES) void keyswitch_mg_kernel(const Ks
             }
             const uint32_t *rowj = ksk + (size_t)j * drows * f * n1p + q0;
             for (int td = 0; td < f; td++) {
-                const int st = td & (KS_STAGES - 1);
+                const int st = (it++) & (KS_STAGES - 1);
                 const int shift = logD * (f - 1 - td);
                 for (int d = 1 + wv; d <= drows; d += WAVES) {              // the waves share the row fetches
                     uint4 r = make_uint4(0, 0, 0, 0);
@@ -1048,6 +1071,8 @@ __global__ __launch_bounds__(KS_LANES * WAVES) void keyswitch_mg_kernel(const Ks
     }
 }
 
+#endif  // TU 0
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -1064,7 +1089,9 @@ static hipError_t set_lds(K kern, size_t bytes) {
     return hipSuccess;
 }
 
+#if MKT_IN_TU(0)
 bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
+#endif
 
 #define MKT_DISPATCH_LOGM(logM, ...)                 \
     switch (logM) {                                  \
@@ -1079,6 +1106,7 @@ bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
     default: return hipErrorInvalidValue;            \
     }
 
+#if MKT_IN_TU(0)
 template <int LM, typename WORD, int NBT>
 static hipError_t launch_fwd_one(TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, int gmax, hipStream_t s) {
     using P = Plan<LM, LOGR, NBT>;
@@ -1172,6 +1200,9 @@ hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int log
     return hipGetLastError();
 }
 
+#endif  // TU 0
+
+#if MKT_IN_TU(1) || MKT_IN_TU(2) || MKT_IN_TU(3) || MKT_IN_TU(5)
 template <int LM, typename WORD, int LB, int LR, int NB, int LT, int BT = 0>
 static hipError_t launch_rot_lt(const RotArgs &a, size_t nrot, hipStream_t s) {
     using P = Plan<LM, LR, NB>;
@@ -1211,34 +1242,70 @@ static hipError_t launch_rot_one(const RotArgs &a, size_t nrot, hipStream_t s) {
 
 // variant = 10*LR + NB for the plain schemes (tuning knob).  Only LR == LOGR variants are built: the device
 // point order of the key tables is tied to the points-per-thread of the schedule.
-template <int LM, typename WORD>
-static hipError_t launch_rot_lb(const RotArgs &a, size_t nrot, hipStream_t s) {
+static inline int rot_variant(const RotArgs &a, int LM) {
     int variant = a.variant;
     if (variant == 0) variant = (LM <= 10 || a.blk_len > 1) ? 22 : 21;   // pairs of transforms up to M = 1024 (re-measured with the specialised kernels: +4 % at M = 1024) and for the block schemes; single transforms above (LDS)
     if ((2 * a.l) % (variant % 10) != 0) variant = (variant / 10) * 10 + 1;
+    return variant;
+}
+template <int LM, typename WORD>
+static hipError_t launch_rot_plain(const RotArgs &a, size_t nrot, hipStream_t s) {
+    switch (rot_variant(a, LM)) {
+    case 21: return launch_rot_one<LM, WORD, 1, LOGR, 1>(a, nrot, s);
+    case 22: return launch_rot_one<LM, WORD, 1, LOGR, 2>(a, nrot, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+template <int LM, typename WORD>
+static hipError_t launch_rot_blk(const RotArgs &a, size_t nrot, hipStream_t s) {
+    const int variant = rot_variant(a, LM);
     switch (a.blk_len) {
-    case 1:
-        switch (variant) {
-        case 21: return launch_rot_one<LM, WORD, 1, LOGR, 1>(a, nrot, s);
-        case 22: return launch_rot_one<LM, WORD, 1, LOGR, 2>(a, nrot, s);
-        default: return hipErrorInvalidValue;
-        }
     case 2: return variant % 10 == 1 ? launch_rot_one<LM, WORD, 2, LOGR, 1>(a, nrot, s) : launch_rot_one<LM, WORD, 2, LOGR, 2>(a, nrot, s);
     case 3: return variant % 10 == 1 ? launch_rot_one<LM, WORD, 3, LOGR, 1>(a, nrot, s) : launch_rot_one<LM, WORD, 3, LOGR, 2>(a, nrot, s);
     case 4: return variant % 10 == 1 ? launch_rot_one<LM, WORD, 4, LOGR, 1>(a, nrot, s) : launch_rot_one<LM, WORD, 4, LOGR, 2>(a, nrot, s);
     default: return hipErrorInvalidValue;
     }
 }
+#endif  // TU 1-3, 5
 
-hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s) {
-    if (!nrot) return hipSuccess;
-    MKT_DISPATCH_LOGM(logM, {
-        if (W == 64) return launch_rot_lb<LM, uint64_t>(a, nrot, s);
-        return launch_rot_lb<LM, uint32_t>(a, nrot, s);
-    });
+#if MKT_IN_TU(1)
+hipError_t launch_rot_plain_u32(int logM, const RotArgs &a, size_t nrot, hipStream_t s) {
+    MKT_DISPATCH_LOGM(logM, { return launch_rot_plain<LM, uint32_t>(a, nrot, s); });
     return hipSuccess;
 }
+#endif
+#if MKT_IN_TU(2)
+hipError_t launch_rot_plain_u64(int logM, const RotArgs &a, size_t nrot, hipStream_t s) {
+    MKT_DISPATCH_LOGM(logM, { return launch_rot_plain<LM, uint64_t>(a, nrot, s); });
+    return hipSuccess;
+}
+#endif
+#if MKT_IN_TU(3)
+hipError_t launch_rot_block_u32(int logM, const RotArgs &a, size_t nrot, hipStream_t s) {
+    MKT_DISPATCH_LOGM(logM, { return launch_rot_blk<LM, uint32_t>(a, nrot, s); });
+    return hipSuccess;
+}
+#endif
+#if MKT_IN_TU(5)
+hipError_t launch_rot_block_u64(int logM, const RotArgs &a, size_t nrot, hipStream_t s) {
+    MKT_DISPATCH_LOGM(logM, { return launch_rot_blk<LM, uint64_t>(a, nrot, s); });
+    return hipSuccess;
+}
+#endif
 
+#if MKT_IN_TU(0)
+hipError_t launch_rot_plain_u32(int logM, const RotArgs &a, size_t nrot, hipStream_t s);
+hipError_t launch_rot_plain_u64(int logM, const RotArgs &a, size_t nrot, hipStream_t s);
+hipError_t launch_rot_block_u32(int logM, const RotArgs &a, size_t nrot, hipStream_t s);
+hipError_t launch_rot_block_u64(int logM, const RotArgs &a, size_t nrot, hipStream_t s);
+hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s) {
+    if (!nrot) return hipSuccess;
+    if (a.blk_len > 1) return W == 64 ? launch_rot_block_u64(logM, a, nrot, s) : launch_rot_block_u32(logM, a, nrot, s);
+    return W == 64 ? launch_rot_plain_u64(logM, a, nrot, s) : launch_rot_plain_u32(logM, a, nrot, s);
+}
+#endif  // TU 0
+
+#if MKT_IN_TU(4)
 template <int LM, typename WORD, int KR, bool BLK>
 static hipError_t launch_kr_one(const RotArgs &a, size_t nrot, hipStream_t s) {
     using P = Plan<LM, LOGR>;
@@ -1295,6 +1362,9 @@ hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, h
     return hipGetLastError();
 }
 
+#endif  // TU 4
+
+#if MKT_IN_TU(0)
 hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
     int G = 32, target_blocks = 1024;   // swept on MI355X (tools/ks_sweep.sh): 1.6 ms vs 4.7 ms single-gate at KMS k=2 N=1024
@@ -1338,5 +1408,6 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
 #undef MKT_KS_LAUNCH
     return hipGetLastError();
 }
+#endif  // TU 0
 
 }  // namespace mktd

@@ -5,51 +5,47 @@
 // those of mkt_client_party_keygen (client.cpp), so the generated words are identical to the host path's; the
 // bootstrapping key is left in coefficient form for the caller to pre-transform (context.cpp).
 //
-// Randomness is a sequential xoshiro256** stream per sample (one lane draws, the workgroup multiplies): the draw is
-// ~35 N generator steps per RLWE sample, the exact negacyclic product with the binary key N^2/2 word additions spread
-// over the workgroup; thousands of samples run side by side, so a whole party key takes milliseconds.
+// Randomness: the ChaCha20 streams of client.cpp (rng_chacha.h).  The streams are counter-based, so the workgroup
+// fills a whole polynomial in parallel -- lane t generates keystream blocks t, t + 256, ... (8 uniform draws or
+// 4 Gaussian deviates each) -- and still produces exactly the words the sequential host loop draws; the exact
+// negacyclic product with the binary key is N^2/2 word additions spread over the workgroup.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "device_api.h"
+#include "rng_chacha.h"
 
 #pragma clang fp contract(off)
 
 namespace mktd {
 namespace {
 
-struct DRng {  // client.cpp Rng, operation for operation
-    uint64_t s[4];
-    __device__ static uint64_t splitmix(uint64_t &x) {
-        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
+using mktrng::Rng;
+constexpr int KG_THREADS = 256;
+
+// dst[q] = draw number (first + q) of the stream & wm, q < N  (N a multiple of 8, first a multiple of 8)
+__device__ __forceinline__ void fill_uniform(const Rng &proto, uint64_t first, uint64_t *dst, int N, uint64_t wm) {
+    for (int b = threadIdx.x; b < N / 8; b += KG_THREADS) {
+        uint32_t w[16];
+        mktrng::chacha20_block(proto.key, (uint32_t)(first / 8) + (uint32_t)b, proto.nonce, w);
+#pragma unroll
+        for (int i = 0; i < 8; i++) dst[8 * b + i] = ((uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32)) & wm;
     }
-    __device__ DRng(uint64_t seed, uint64_t a, uint64_t b = 0, uint64_t c = 0) {
-        uint64_t x = seed;
-        x = splitmix(x) ^ (a * 0xD6E8FEB86659FD93ull); x = splitmix(x) ^ (b * 0xA0761D6478BD642Full);
-        x = splitmix(x) ^ (c * 0xE7037ED1A0B428DBull);
-        for (int i = 0; i < 4; i++) s[i] = splitmix(x);
+}
+// dst[q] = noise(sigma) from draws first + 2q, first + 2q + 1  (Rng::noise order)
+__device__ __forceinline__ void fill_noise(const Rng &proto, uint64_t first, uint64_t *dst, int N, double sigma) {
+    for (int b = threadIdx.x; b < N / 4; b += KG_THREADS) {
+        uint32_t w[16];
+        mktrng::chacha20_block(proto.key, (uint32_t)(first / 8) + (uint32_t)b, proto.nonce, w);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t r1 = (uint64_t)w[4 * i] | ((uint64_t)w[4 * i + 1] << 32), r2 = (uint64_t)w[4 * i + 2] | ((uint64_t)w[4 * i + 3] << 32);
+            dst[4 * b + i] = (uint64_t)(int64_t)rint(sigma * mktrng::box_muller(r1, r2));
+        }
     }
-    __device__ static uint64_t rotl(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
-    __device__ uint64_t next() {
-        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
-        return r;
-    }
-    __device__ double uniform() { return (double)(next() >> 11) * 0x1p-53; }
-    __device__ double gauss() {
-        double acc = 0.0;
-        for (int i = 0; i < 16; i++) acc += uniform();
-        return (acc - 8.0) * 0.8660254037844386;
-    }
-    __device__ uint64_t noise(double sigma) { return (uint64_t)(int64_t)rint(sigma * gauss()); }
-};
+}
 
 template <typename WORD> __device__ __forceinline__ uint64_t wmask_of() { return sizeof(WORD) == 8 ? ~0ull : 0xFFFFFFFFull; }
-
-constexpr int KG_THREADS = 256;
 
 // acc[r] (+)= sum_i s_i * a[(m - i) mod N] with the negacyclic sign, m = t + r * KG_THREADS; s in {-1, 0, 1};
 // client.cpp mul_small_acc (out[i + j] -/+= a[j]) restated per output coefficient.  `negate` flips the sign.
@@ -83,18 +79,18 @@ __global__ __launch_bounds__(KG_THREADS) void keygen_rgsw_kernel(KeygenArgs a) {
     const int rows = (a.kr + 1) * a.l, polys = a.kr + 1;
     const int sample = blockIdx.x, i = sample / rows, cj = sample % rows, c = cj / a.l, j = cj % a.l;
     WORD *out = reinterpret_cast<WORD *>(a.out) + (size_t)sample * polys * N;
-    DRng rng(a.ps, 2, (uint64_t)i, (uint64_t)cj);
+    const Rng rng(a.key, (uint32_t)a.party, 2, (uint32_t)i, (uint32_t)cj);
     uint64_t acc[MAXR];
 #pragma unroll
     for (int r = 0; r < MAXR; r++) acc[r] = 0;
     for (int cc = 0; cc < a.kr; cc++) {
-        if (t == 0) for (int q = 0; q < N; q++) al[q] = rng.next() & wm;
+        fill_uniform(rng, (uint64_t)cc * N, al, N, wm);
         __syncthreads();
         for (int q = t; q < N; q += KG_THREADS) out[(size_t)(1 + cc) * N + q] = (WORD)al[q];
         mul_small_acc_dev<MAXR>(al, a.zring + (size_t)(a.zoff + cc) * N, acc, N, true);
         __syncthreads();
     }
-    if (t == 0) for (int q = 0; q < N; q++) al[q] = rng.noise(a.sigma_ring);
+    fill_noise(rng, (uint64_t)a.kr * N, al, N, a.sigma_ring);
     __syncthreads();
     const uint64_t g = (uint64_t)1 << (a.W - (j + 1) * a.logB);
 #pragma unroll
@@ -118,8 +114,12 @@ __global__ __launch_bounds__(KG_THREADS) void keygen_unienc_kernel(KeygenArgs a)
     const uint64_t wm = wmask_of<WORD>();
     WORD *out = reinterpret_cast<WORD *>(a.out) + (size_t)i * 3 * l * N;
     const WORD *crs = reinterpret_cast<const WORD *>(a.crs);
-    DRng rng(a.ps, 2, (uint64_t)i);
-    if (t == 0) for (int q = 0; q < N; q++) rt[q] = (int8_t)((int)(rng.next() % 3) - 1);
+    const Rng rng(a.key, (uint32_t)a.party, 2, (uint32_t)i);
+    // stream layout of the host loop: draws [0, N) ternary r; per j at base = N + 5 N j: noise of d (2 draws each),
+    // base + 2N: mask of f[j], base + 3N: noise of f[j]
+    fill_uniform(rng, 0, al, N, ~0ull);
+    __syncthreads();
+    for (int q = t; q < N; q += KG_THREADS) rt[q] = (int8_t)((int)(al[q] % 3) - 1);
     __syncthreads();
     for (int j = 0; j < l; j++) {
         const uint64_t g = (uint64_t)1 << (a.W - (j + 1) * a.logB);
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(KG_THREADS) void keygen_unienc_kernel(KeygenArgs a)
         __syncthreads();
         mul_small_acc_dev<MAXR>(al, rt, acc, N, false);                         // crs[j] * r
         __syncthreads();
-        if (t == 0) for (int q = 0; q < N; q++) al[q] = rng.noise(a.sigma_ring);
+        const uint64_t base = (uint64_t)N + (uint64_t)5 * N * j;
+        fill_noise(rng, base, al, N, a.sigma_ring);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < MAXR; r++) {
@@ -144,12 +145,12 @@ __global__ __launch_bounds__(KG_THREADS) void keygen_unienc_kernel(KeygenArgs a)
         __syncthreads();
         // f.stack[j] = RLWE_z(g_j * r): a uniform, b = -a z + e + g r
         WORD *fb = out + (size_t)(l + 2 * j) * N, *fa = fb + N;
-        if (t == 0) for (int q = 0; q < N; q++) al[q] = rng.next() & wm;
+        fill_uniform(rng, base + (uint64_t)2 * N, al, N, wm);
         __syncthreads();
         for (int q = t; q < N; q += KG_THREADS) fa[q] = (WORD)al[q];
         mul_small_acc_dev<MAXR>(al, a.zring + (size_t)a.zoff * N, acc, N, true);
         __syncthreads();
-        if (t == 0) for (int q = 0; q < N; q++) al[q] = rng.noise(a.sigma_ring);
+        fill_noise(rng, base + (uint64_t)3 * N, al, N, a.sigma_ring);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < MAXR; r++) {
@@ -168,7 +169,7 @@ __global__ void keygen_ksk_kernel(KeygenArgs a, uint32_t *ksk, int n1p, int kk, 
     if (cj >= kk * a.N) return;
     const int c = cj / a.N, j = cj % a.N, n = a.n;
     if (is_block && (long)c * a.N + j < n) return;                    // keygen.jl:46, :147
-    DRng rng(a.ps, 5, (uint64_t)cj);
+    Rng rng(a.key, (uint32_t)a.party, 5, (uint32_t)cj);
     const uint32_t zj = (uint32_t)a.zring[(size_t)(a.zoff + c) * a.N + j];
     for (int d = 0; d < dr; d++)
         for (int t = 0; t < a.f; t++) {

@@ -50,10 +50,28 @@ def _arg(x, dtype, writable=False):
 # ------------------------------------------------------------------------------------------------
 # client side: CRS, party_keygen / setup keys, encrypt, decrypt  (CPU, exact integer arithmetic)
 # ------------------------------------------------------------------------------------------------
-def CRS(params: Params, seed=0):
-    """scheme.jl:409-410 CRS(params): l_uni uniform ring polynomials -> (l_uni, N) ring words"""
+def _seed_arg(deterministic_seed):
+    """-> (pointer or None, keepalive).  None (the default everywhere) = the library draws a fresh 256-bit seed from the
+    OS for this call, like the reference's per-call ChaCha20 entropy (sampler.jl:1-34).  An int (tests / benchmarks
+    ONLY: the result is reproducible, hence public) is expanded by mkt_client_test_seed; 32 bytes are used as they are."""
+    if deterministic_seed is None:
+        return None, None
+    buf = (C.c_uint8 * 32)()
+    if isinstance(deterministic_seed, (bytes, bytearray)):
+        if len(deterministic_seed) != 32:
+            raise ValueError("a seed is 32 bytes")
+        buf[:] = deterministic_seed
+    else:
+        check(_lib.lib().mkt_client_test_seed(int(deterministic_seed) & (2**64 - 1), buf))
+    return C.cast(buf, C.c_void_p), buf
+
+
+def CRS(params: Params, deterministic_seed=None):
+    """scheme.jl:409-410 CRS(params): l_uni uniform ring polynomials -> (l_uni, N) ring words.
+    Fresh OS randomness unless `deterministic_seed` (tests / benchmarks only) pins it."""
     out = np.empty((params.l_uni, params.N), dtype=params.ring_dtype)
-    check(_lib.lib().mkt_client_crs(C.byref(params.c()), seed, _np_ptr(out)))
+    sp, _keep = _seed_arg(deterministic_seed)
+    check(_lib.lib().mkt_client_crs(C.byref(params.c()), sp, _np_ptr(out)))
     return out
 
 
@@ -61,15 +79,19 @@ class PartyKeys:
     """One party's secret and evaluation keys (party_keygen, scheme.jl:227,:273,:324; setup for the
     single-key schemes, scheme.jl:151,:190).  Evaluation keys are in integer (coefficient) form."""
 
-    def __init__(self, params: Params, seed=0, party=0, crs=None, secrets_only=False):
-        """secrets_only: leave out the two large keys (bootstrapping key, key-switching key); they are then generated
-        on the GPU by Scheme.keygen_device from the same seeded streams (identical words)"""
+    def __init__(self, params: Params, party=0, crs=None, secrets_only=False, deterministic_seed=None):
+        """Keys are drawn from fresh OS randomness; `deterministic_seed` (an int, or 32 bytes) pins the streams for
+        tests and benchmarks ONLY -- such keys are reproducible by anyone.
+        secrets_only: leave out the two large keys (bootstrapping key, key-switching key); they are then generated
+        on the GPU by Scheme.keygen_device from the same streams (identical words).  That hands this party's secrets
+        to that GPU: a party-local step (own machine), not something an evaluator does for every party."""
         self.params, self.party, self.secrets_only = params, party, secrets_only
         h = C.c_void_p()
         self._crs = np.ascontiguousarray(crs, dtype=params.ring_dtype) if crs is not None else None
         crs_p = _np_ptr(self._crs) if crs is not None else None
         fn = _lib.lib().mkt_client_party_secrets if secrets_only else _lib.lib().mkt_client_party_keygen
-        check(fn(C.byref(params.c()), seed, party, crs_p, params.alpha, params.beta, C.byref(h)))
+        sp, _keep = _seed_arg(deterministic_seed)
+        check(fn(C.byref(params.c()), sp, party, crs_p, params.alpha, params.beta, C.byref(h)))
         self.h = h
 
     def __del__(self):
@@ -113,20 +135,23 @@ class PartyKeys:
         return self._buf(_lib.lib().mkt_client_pubkey, self.params.ring_dtype)
 
 
-def party_keygen(a, params: Params, seed=0, party=0, secrets_only=False):
-    """scheme.jl:227/:273/:324 party_keygen(a, params) -> PartyKeys (lwekey + bootstrapping key)"""
-    return PartyKeys(params, seed=seed, party=party, crs=a, secrets_only=secrets_only)
+def party_keygen(a, params: Params, party=0, secrets_only=False, deterministic_seed=None):
+    """scheme.jl:227/:273/:324 party_keygen(a, params) -> PartyKeys (lwekey + bootstrapping key); fresh randomness
+    per call unless `deterministic_seed` (tests / benchmarks only) is given"""
+    return PartyKeys(params, party=party, crs=a, secrets_only=secrets_only, deterministic_seed=deterministic_seed)
 
 
-def lwe_encrypt(m, key: PartyKeys, params: Params, seed=0):
-    """scheme.jl:352-368 lwe_encrypt(m, key, params) (single-key schemes)"""
-    return lwe_ith_encrypt(m, 0, key, params, seed)
+def lwe_encrypt(m, key: PartyKeys, params: Params, deterministic_seed=None):
+    """scheme.jl:352-368 lwe_encrypt(m, key, params) (single-key schemes); fresh mask and noise per call"""
+    return lwe_ith_encrypt(m, 0, key, params, deterministic_seed)
 
 
-def lwe_ith_encrypt(m, i, key: PartyKeys, params: Params, seed=0):
-    """scheme.jl:370-386 lwe_ith_encrypt(m, i, key, params); i is the 0-based party index"""
+def lwe_ith_encrypt(m, i, key: PartyKeys, params: Params, deterministic_seed=None):
+    """scheme.jl:370-386 lwe_ith_encrypt(m, i, key, params); i is the 0-based party index.  Mask and noise come from
+    fresh OS randomness on every call; `deterministic_seed` (tests / benchmarks only) pins them"""
     out = np.empty(params.lwe_len, dtype=np.uint32)
-    check(_lib.lib().mkt_client_lwe_encrypt(C.byref(params.c()), key.h, i, int(bool(m)), params.alpha, seed, _np_ptr(out)))
+    sp, _keep = _seed_arg(deterministic_seed)
+    check(_lib.lib().mkt_client_lwe_encrypt(C.byref(params.c()), key.h, i, int(bool(m)), params.alpha, sp, _np_ptr(out)))
     return out
 
 
@@ -327,7 +352,7 @@ class Scheme:
         return out
 
 
-def setup(params: Params, keys=None, a=None, device=0, seed=0):
+def setup(params: Params, keys=None, a=None, device=0, deterministic_seed=None):
     """scheme.jl:151 / :190 setup(params) -> (keys, scheme) for the single-key schemes, and
     scheme.jl:244 / :292 / :343 setup(a, btk, params) -> scheme for the multi-key ones
     (keys = list of PartyKeys, a = CRS).  The evaluation keys are uploaded and pre-transformed
@@ -335,7 +360,7 @@ def setup(params: Params, keys=None, a=None, device=0, seed=0):
     def install(sch, i, kk):      # keys made with secrets_only=True get their large keys generated on the device
         (sch.keygen_device if kk.secrets_only else sch.load_party)(i, kk)
     if not params.multikey:
-        ks = keys if keys is not None else PartyKeys(params, seed=seed, party=0)
+        ks = keys if keys is not None else PartyKeys(params, party=0, deterministic_seed=deterministic_seed)
         sch = Scheme(params, device=device)
         install(sch, 0, ks)
         return ks, sch

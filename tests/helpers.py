@@ -21,8 +21,8 @@ def keygen(p: mk.Params, seed=1):
     """-> (crs or None, [PartyKeys])"""
     if p.multikey:
         a = mk.CRS(p, seed)
-        return a, [mk.party_keygen(a, p, seed=seed, party=i) for i in range(p.k)]
-    return None, [mk.PartyKeys(p, seed=seed, party=0)]
+        return a, [mk.party_keygen(a, p, deterministic_seed=seed, party=i) for i in range(p.k)]
+    return None, [mk.PartyKeys(p, deterministic_seed=seed, party=0)]
 
 
 def oracle_scheme(p: mk.Params, crs, keys):
@@ -50,7 +50,7 @@ def encrypt_bits(p: mk.Params, keys, bits, seed=100):
     out = np.empty((len(bits), p.lwe_len), dtype=np.uint32)
     for j, b in enumerate(bits):
         i = j % p.nparty
-        out[j] = mk.lwe_ith_encrypt(int(b), i, keys[i], p, seed=seed + j)
+        out[j] = mk.lwe_ith_encrypt(int(b), i, keys[i], p, deterministic_seed=seed + j)
     return out
 
 

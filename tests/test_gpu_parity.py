@@ -359,7 +359,7 @@ def test_circuit_on_device(require_gpu):
     B = 64
     rng = np.random.default_rng(15)
     bits = rng.integers(0, 2, (8, B)).astype(bool)
-    pool = {(i, v): mk.lwe_ith_encrypt(v, i % 2, keys[i % 2], p, seed=1500 + 2 * i + v) for i in range(8) for v in (0, 1)}
+    pool = {(i, v): mk.lwe_ith_encrypt(v, i % 2, keys[i % 2], p, deterministic_seed=1500 + 2 * i + v) for i in range(8) for v in (0, 1)}
     inputs = [torch.from_numpy(np.stack([pool[(i, int(bits[i, j]))] for j in range(B)]).view(np.int32)).cuda() for i in range(8)]
     outs = CI.evaluate_on(circ, inputs, sg)
     torch.cuda.synchronize()
@@ -512,8 +512,8 @@ def test_device_keygen_matches_host_keygen(require_gpu, p):
     a scheme keyed on the device equals the scheme loaded with host keys, hence the oracle)."""
     seed = 77
     crs = mk.CRS(p, seed) if p.multikey else None
-    host = [mk.party_keygen(crs, p, seed=seed, party=i) for i in range(p.nparty)]
-    secr = [mk.party_keygen(crs, p, seed=seed, party=i, secrets_only=True) for i in range(p.nparty)]
+    host = [mk.party_keygen(crs, p, deterministic_seed=seed, party=i) for i in range(p.nparty)]
+    secr = [mk.party_keygen(crs, p, deterministic_seed=seed, party=i, secrets_only=True) for i in range(p.nparty)]
     assert all(s.brk is None and s.ksk is None for s in secr)
     sh = gpu_scheme(p, crs, host)
     sd = gpu_scheme(p, crs, secr)                                   # setup() generates the large keys on the device

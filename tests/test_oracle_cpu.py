@@ -305,7 +305,7 @@ def test_client_key_layouts():
     brk = k0.brk.reshape(n, 2 * p.l_gsw, 2, N)
     assert brk.dtype == np.uint64 and k0.rlk_d.size == p.l_uni * N and k0.rlk_f.size == 2 * p.l_uni * N and k0.pubkey.size == p.l_uni * N
     # seeded: same seed -> same keys, different party -> different keys
-    again = mk.party_keygen(crs, p, seed=31, party=0)
+    again = mk.party_keygen(crs, p, deterministic_seed=31, party=0)
     assert np.array_equal(again.brk, k0.brk) and not np.array_equal(keys[1].brk, k0.brk)
 
 
@@ -319,7 +319,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/mktfhe.h but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert _lib.lib().mkt_abi_version() == 1
+    assert _lib.lib().mkt_abi_version() == 2
 
 
 def test_no_cpu_fallback_and_argument_errors():
@@ -374,7 +374,7 @@ def test_circuit_levelisation_with_oracle_backend():
     B = 4
     rng = np.random.default_rng(72)
     bits = rng.integers(0, 2, (6, B)).astype(bool)
-    inputs = [np.stack([mk.lwe_encrypt(int(bits[i, j]), keys[0], p, seed=7200 + 10 * i + j) for j in range(B)]) for i in range(6)]
+    inputs = [np.stack([mk.lwe_encrypt(int(bits[i, j]), keys[0], p, deterministic_seed=7200 + 10 * i + j) for j in range(B)]) for i in range(6)]
     calls = []
     def gate_fn(op, x, y):
         calls.append((op, x.shape[0]))

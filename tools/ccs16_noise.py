@@ -7,7 +7,7 @@ sg = gpu_scheme(p, crs, keys)
 B = 16
 rng = np.random.default_rng(5)
 bits = rng.integers(0, 2, (p.k, B)).astype(bool)
-cts = [np.stack([mk.lwe_ith_encrypt(int(bits[i, j]), i, keys[i], p, seed=1000 * i + j) for j in range(B)]) for i in range(p.k)]
+cts = [np.stack([mk.lwe_ith_encrypt(int(bits[i, j]), i, keys[i], p, deterministic_seed=1000 * i + j) for j in range(B)]) for i in range(p.k)]
 def phase_err(c, m):
     ph = c[:, -1].astype(np.int64)
     for i, kk in enumerate(keys):

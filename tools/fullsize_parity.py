@@ -15,7 +15,7 @@ for name in names:
     B = 4
     rng = np.random.default_rng(5)
     bits = rng.integers(0, 2, (p.k, B)).astype(bool)
-    cts = [np.stack([mk.lwe_ith_encrypt(int(bits[i, j]), i, keys[i], p, seed=1000 * i + j) for j in range(B)]) for i in range(p.k)]
+    cts = [np.stack([mk.lwe_ith_encrypt(int(bits[i, j]), i, keys[i], p, deterministic_seed=1000 * i + j) for j in range(B)]) for i in range(p.k)]
     res_g, mres, ok, t_gpu, t_ora = cts[0], bits[0].copy(), True, 0.0, 0.0
     for i in range(1, p.k):
         op = int(rng.integers(0, 6))

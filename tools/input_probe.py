@@ -6,12 +6,12 @@ import numpy as np, torch
 import mktfhe_amd as mk
 B = 1024
 for p in (mk.KMS2party_N1024_l2, mk.KMS2party):
-    crs = mk.CRS(p, 1); keys = [mk.party_keygen(crs, p, seed=1, party=i) for i in range(p.k)]
+    crs = mk.CRS(p, 1); keys = [mk.party_keygen(crs, p, deterministic_seed=1, party=i) for i in range(p.k)]
     sch = mk.setup(p, keys=keys, a=crs, device=0)
     rng = np.random.default_rng(5)
     def fresh(n, s0):
         b = rng.integers(0, 2, n).astype(bool); ct = np.empty((n, p.lwe_len), dtype=np.uint32)
-        for j in range(n): ct[j] = mk.lwe_ith_encrypt(int(b[j]), j % p.k, keys[j % p.k], p, seed=s0 + j)
+        for j in range(n): ct[j] = mk.lwe_ith_encrypt(int(b[j]), j % p.k, keys[j % p.k], p, deterministic_seed=s0 + j)
         return torch.from_numpy(ct.view(np.int32)).cuda()
     f = fresh(4 * B, 1000)
     sets = {

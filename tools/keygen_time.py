@@ -5,8 +5,8 @@ import numpy as np, torch
 import mktfhe_amd as mk
 for p in (mk.CGGIparam, mk.KMS2party, mk.KMS4party, mk.CCS8party, mk.KMS16party):
     crs = mk.CRS(p, 1) if p.multikey else None
-    t0 = time.perf_counter(); kh = mk.party_keygen(crs, p, seed=1, party=0); th = time.perf_counter() - t0
-    t0 = time.perf_counter(); ks = mk.party_keygen(crs, p, seed=1, party=0, secrets_only=True); ts = time.perf_counter() - t0
+    t0 = time.perf_counter(); kh = mk.party_keygen(crs, p, deterministic_seed=1, party=0); th = time.perf_counter() - t0
+    t0 = time.perf_counter(); ks = mk.party_keygen(crs, p, deterministic_seed=1, party=0, secrets_only=True); ts = time.perf_counter() - t0
     sch = mk.Scheme(p, device=0)
     if p.multikey: sch.load_crs(crs)
     t0 = time.perf_counter(); sch.load_party(0, kh); sch.synchronize(); tu = time.perf_counter() - t0

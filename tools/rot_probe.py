@@ -19,10 +19,10 @@ cases = [
 ]
 for name, p in cases:
     if p.multikey:
-        crs = mk.CRS(p, 1); keys = [mk.party_keygen(crs, p, seed=1, party=i) for i in range(p.k)]
+        crs = mk.CRS(p, 1); keys = [mk.party_keygen(crs, p, deterministic_seed=1, party=i) for i in range(p.k)]
         sch = mk.setup(p, keys=keys, a=crs, device=0)
     else:
-        keys = mk.PartyKeys(p, seed=1); sch = mk.setup(p, keys=keys, device=0)[1]
+        keys = mk.PartyKeys(p, deterministic_seed=1); sch = mk.setup(p, keys=keys, device=0)[1]
     rng = np.random.default_rng(5)
     x = torch.from_numpy(rng.integers(0, 2**32, (B, p.lwe_len), dtype=np.uint64).astype(np.uint32).view(np.int32)).cuda()
     y = torch.from_numpy(rng.integers(0, 2**32, (B, p.lwe_len), dtype=np.uint64).astype(np.uint32).view(np.int32)).cuda()
