@@ -123,6 +123,10 @@ int mkt_load_crs(mkt_ctx *ctx, const void *a, int fmt);
  *      An evaluator context that runs it for every party holds all k secrets -- acceptable only in tests and
  *      benchmarks.  The secret buffers are zeroed on the device before they are freed. ---- */
 int mkt_keygen_device(mkt_ctx *ctx, int party, const mkt_client_party *keys, const void *crs);
+/* the same, and the keys are also copied to the host: brk_out in the MKT_FMT_INT_COEFF layout of mkt_load_brk, ksk_out
+ * in the layout of mkt_load_ksk -- what a party ships to the evaluator after generating its keys on its own GPU */
+int mkt_keygen_device_export(mkt_ctx *ctx, int party, const mkt_client_party *keys, const void *crs,
+                             void *brk_out, uint32_t *ksk_out);
 /* read a party's key-switching key back in the host layout of mkt_load_ksk (tests) */
 int mkt_get_ksk(mkt_ctx *ctx, int party, uint32_t *out_host);                           /* scheme.jl:409-410 */
 
@@ -185,6 +189,8 @@ int mkt_client_party_secrets(const mkt_params *params, const uint8_t *seed, int 
 int mkt_client_party_destroy(mkt_client_party *p);   /* wipes the secrets */
 /* sizes in bytes / pointers to the flat key material (layouts above), valid until destroy */
 const uint32_t *mkt_client_lwekey(const mkt_client_party *p);             /* [n] 0/1 */
+/* ring secret polynomial idx, N entries 0/1 (SK schemes: idx < k; CCS: 0; KMS: 0 = gsw key, 1 = uni key); key.jl */
+const int8_t *mkt_client_ringkey(const mkt_client_party *p, int idx, size_t *bytes);
 const void *mkt_client_brk(const mkt_client_party *p, size_t *bytes);     /* INT_COEFF */
 const uint32_t *mkt_client_ksk(const mkt_client_party *p, size_t *bytes);
 const void *mkt_client_rlk_d(const mkt_client_party *p, size_t *bytes);

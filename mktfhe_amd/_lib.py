@@ -43,6 +43,7 @@ SYMBOLS = {
     "mkt_load_pubkey": (_i, [_vp, _i, _vp, _i]),
     "mkt_load_crs": (_i, [_vp, _vp, _i]),
     "mkt_keygen_device": (_i, [_vp, _i, _vp, _vp]),
+    "mkt_keygen_device_export": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "mkt_get_ksk": (_i, [_vp, _i, _vp]),
     "mkt_gate_batch": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _i]),
     "mkt_not_batch": (_i, [_vp, _vp, _sz, _i]),
@@ -64,6 +65,7 @@ SYMBOLS = {
     "mkt_client_party_secrets": (_i, [_pp, _vp, _i, _vp, _dbl, _dbl, C.POINTER(_vp)]),
     "mkt_client_party_destroy": (_i, [_vp]),
     "mkt_client_lwekey": (_vp, [_vp]),
+    "mkt_client_ringkey": (_vp, [_vp, _i, C.POINTER(_sz)]),
     "mkt_client_brk": (_vp, [_vp, C.POINTER(_sz)]),
     "mkt_client_ksk": (_vp, [_vp, C.POINTER(_sz)]),
     "mkt_client_rlk_d": (_vp, [_vp, C.POINTER(_sz)]),

@@ -331,6 +331,12 @@ int mkt_client_party_destroy(mkt_client_party *p) {
     return MKT_OK;
 }
 const uint32_t *mkt_client_lwekey(const mkt_client_party *p) { return p ? p->lwekey.data() : nullptr; }
+// ring secret key polynomial idx (SK schemes: idx < k; CCS: 0; KMS: 0 = gsw key z', 1 = uni key z), N entries 0/1
+const int8_t *mkt_client_ringkey(const mkt_client_party *p, int idx, size_t *bytes) {
+    if (!p || idx < 0 || idx >= (int)p->zring.size()) { if (bytes) *bytes = 0; return nullptr; }
+    if (bytes) *bytes = p->zring[idx].size();
+    return p->zring[idx].data();
+}
 const void *mkt_client_brk(const mkt_client_party *p, size_t *bytes) { if (bytes) *bytes = p->brk.size(); return p->brk.data(); }
 const uint32_t *mkt_client_ksk(const mkt_client_party *p, size_t *bytes) { if (bytes) *bytes = p->ksk.size() * 4; return p->ksk.data(); }
 const void *mkt_client_rlk_d(const mkt_client_party *p, size_t *bytes) { if (bytes) *bytes = p->rlk_d.size(); return p->rlk_d.data(); }

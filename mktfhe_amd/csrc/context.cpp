@@ -451,7 +451,7 @@ int mkt_load_crs(mkt_ctx *c, const void *a, int fmt) {
 
 // Bootstrapping key and key-switching key of party `party` generated on the device from the party's secrets
 // (keygen.hip: the seeded streams of mkt_client_party_keygen, identical words), pre-transformed in place of an upload.
-int mkt_keygen_device(mkt_ctx *c, int party, const mkt_client_party *K, const void *crs) {
+static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, const void *crs, void *brk_out, uint32_t *ksk_out) {
     if (!c || !K || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
     const mkt_params &p = c->p;
     if (std::memcmp(&K->p, &p, sizeof(mkt_params)) != 0 || K->party != party) return fail(c, MKT_ERR_ARG, "mkt_keygen_device: the party's keys were made for other parameters / another party index");
@@ -483,6 +483,7 @@ int mkt_keygen_device(mkt_ctx *c, int party, const mkt_client_party *K, const vo
     if (unienc) { a.kr = 1; a.l = p.l_uni; a.logB = p.logB_uni; a.zoff = 0; }
     else { a.kr = c->sh.kr; a.l = p.l_gsw; a.logB = p.logB_gsw; a.zoff = 0; }
     e = mktd::launch_keygen_brk(a, unienc ? 1 : 0, c->stream);
+    if (e == hipSuccess && brk_out) e = hipMemcpyAsync(brk_out, d_out, brk_polys_total * poly_bytes(c), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->d_brk + (size_t)party * c->brk_party_cplx, brk_polys_total, 1, c->stream);
     uint32_t *ksk = c->d_ksk + (size_t)party * c->ksk_party_words;
     if (e == hipSuccess) e = hipMemsetAsync(ksk, 0, c->ksk_party_words * sizeof(uint32_t), c->stream);
@@ -492,7 +493,20 @@ int mkt_keygen_device(mkt_ctx *c, int party, const mkt_client_party *K, const vo
     cleanup();
     if (e != hipSuccess) return hipfail(c, e, "device keygen");
     c->brk_loaded[party] = 1; c->ksk_loaded[party] = 1;
+    if (ksk_out) return mkt_get_ksk(c, party, ksk_out);
     return MKT_OK;
+}
+
+int mkt_keygen_device(mkt_ctx *c, int party, const mkt_client_party *K, const void *crs) {
+    return keygen_device_impl(c, party, K, crs, nullptr, nullptr);
+}
+
+// the same, and the generated keys are also copied out in the host layouts of mkt_load_brk (MKT_FMT_INT_COEFF) /
+// mkt_load_ksk: a party generates its evaluation keys on its OWN GPU and ships them (key blob) to the evaluator,
+// which never sees a secret
+int mkt_keygen_device_export(mkt_ctx *c, int party, const mkt_client_party *K, const void *crs, void *brk_out, uint32_t *ksk_out) {
+    if (!brk_out || !ksk_out) return fail(c, MKT_ERR_ARG, "null output");
+    return keygen_device_impl(c, party, K, crs, brk_out, ksk_out);
 }
 
 // debug / test read-back of a party's key-switching key in the host layout of mkt_load_ksk

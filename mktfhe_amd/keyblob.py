@@ -56,6 +56,15 @@ def dump_party(keys) -> bytes:
     return _pack(p, keys.party, secs)
 
 
+def dump_arrays(params: Params, party, brk, ksk, rlk_d=None, rlk_f=None, pubkey=None) -> bytes:
+    """serialise evaluation-key arrays (e.g. the export of Scheme.keygen_device on the party's own GPU)"""
+    secs = [("brk", np.ascontiguousarray(brk, dtype=params.ring_dtype).reshape(-1)), ("ksk", np.ascontiguousarray(ksk, dtype=np.uint32).reshape(-1))]
+    for name, v in (("rlk_d", rlk_d), ("rlk_f", rlk_f), ("pubkey", pubkey)):
+        if v is not None:
+            secs.append((name, np.ascontiguousarray(v, dtype=params.ring_dtype).reshape(-1)))
+    return _pack(params, party, secs)
+
+
 def dump_crs(params: Params, crs) -> bytes:
     return _pack(params, -1, [("crs", np.ascontiguousarray(crs, dtype=params.ring_dtype).reshape(-1))])
 

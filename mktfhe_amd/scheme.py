@@ -31,9 +31,13 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
-def _arg(x, dtype, writable=False):
-    """-> (pointer, mem kind, keepalive, numpy-or-tensor)"""
+def _arg(x, dtype, writable=False, scheme=None):
+    """-> (pointer, mem kind, keepalive).  GPU tensors must live on the scheme's device; unless the caller pinned a stream
+    with Scheme.set_stream, the engine enqueues on torch's CURRENT stream of that device, so its kernels are ordered
+    with the producer and the consumer of the tensor like any torch op."""
     if _is_torch(x):
+        if scheme is not None:
+            scheme._follow_torch(x)
         if not x.is_cuda:
             raise ValueError("torch tensors must live on the GPU; pass numpy arrays for host memory")
         if not x.is_contiguous():
@@ -102,17 +106,29 @@ class PartyKeys:
                 pass
             self.h = None
 
+    def _view(self, addr, nbytes, dtype):
+        """zero-copy numpy view of key material owned by the C object; the view keeps this PartyKeys (and with it the
+        memory) alive"""
+        raw = (C.c_uint8 * nbytes).from_address(addr)
+        raw._owner = self
+        return np.frombuffer(raw, dtype=dtype)
+
     def _buf(self, fn, dtype):
         n = C.c_size_t(0)
         p = fn(self.h, C.byref(n))
         if not n.value:
             return None
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).view(dtype)
+        return self._view(p, n.value, dtype)
 
     @property
     def lwekey(self):
-        p = _lib.lib().mkt_client_lwekey(self.h)
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(self.params.n,))
+        return self._view(_lib.lib().mkt_client_lwekey(self.h), 4 * self.params.n, np.uint32)
+
+    def ringkey(self, idx=0):
+        """ring secret polynomial idx as int8 [N] (SK schemes: idx < k; CCS: 0; KMS: 0 = gsw key, 1 = uni key)"""
+        n = C.c_size_t(0)
+        p = _lib.lib().mkt_client_ringkey(self.h, idx, C.byref(n))
+        return self._view(p, n.value, np.int8) if n.value else None
 
     @property
     def brk(self):
@@ -181,6 +197,14 @@ class Scheme:
         h = C.c_void_p()
         check(_lib.lib().mkt_ctx_create(C.byref(params.c()), arith, device, C.byref(h)))
         self.h = h
+        self._user_stream = False     # True once set_stream pinned a stream; else torch's current stream is followed
+
+    def _follow_torch(self, t):
+        if t.device.index != self.device:
+            raise ValueError(f"tensor lives on cuda:{t.device.index}, this scheme on device {self.device}")
+        if not self._user_stream:
+            import torch
+            self._ck(_lib.lib().mkt_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -208,19 +232,41 @@ class Scheme:
         if pubkey is not None:
             self._ck(L.mkt_load_pubkey(self.h, party, _np_ptr(np.ascontiguousarray(pubkey, dtype=kd)), fmt))
 
-    def keygen_device(self, party, keys: PartyKeys):
+    def keygen_device(self, party, keys: PartyKeys, export=False):
         """keygen.jl:13-23 etc. on the GPU: bootstrapping + key-switching key of `party` from its secrets (the small
-        keys -- public key, relinearisation key -- are uploaded from `keys`)"""
+        keys -- public key, relinearisation key -- are uploaded from `keys`).  This hands the party's SECRETS to this
+        context's GPU: it is the party's own step.  export=True also returns (brk, ksk) in the integer layouts of
+        load_party, i.e. what the party ships to the evaluator (keyblob.dump_arrays)."""
         L = _lib.lib()
         crs_p = _np_ptr(keys._crs) if (self.params.scheme == CCS and keys._crs is not None) else None
-        self._ck(L.mkt_keygen_device(self.h, party, keys.h, crs_p))
+        out = None
+        if export:
+            p = self.params
+            brk = np.empty(self.brk_words(), dtype=p.ring_dtype)
+            ksk = np.empty(self.get_ksk_shape(), dtype=np.uint32)
+            self._ck(L.mkt_keygen_device_export(self.h, party, keys.h, crs_p, _np_ptr(brk), _np_ptr(ksk)))
+            out = (brk, ksk.ravel())
+        else:
+            self._ck(L.mkt_keygen_device(self.h, party, keys.h, crs_p))
         self.load_party(party, rlk_d=keys.rlk_d, rlk_f=keys.rlk_f, pubkey=keys.pubkey)
+        return out
 
-    def get_ksk(self, party):
+    def brk_words(self):
+        """ring words of one party's bootstrapping key (include/mktfhe.h layouts)"""
+        p = self.params
+        if p.scheme == CCS:
+            return p.n * 3 * p.l_uni * p.N
+        kr = 1 if p.scheme in (KMS, KMS_BLOCK) else p.k
+        return p.n * (kr + 1) * p.l_gsw * (kr + 1) * p.N
+
+    def get_ksk_shape(self):
         p = self.params
         D = 1 << p.logD
         rows = (1 if p.multikey else p.k) * p.N * (D // 2 if p.scheme in (LMSS, KMS_BLOCK) else D - 1) * p.f
-        out = np.empty((rows, p.n + 1), dtype=np.uint32)
+        return (rows, p.n + 1)
+
+    def get_ksk(self, party):
+        out = np.empty(self.get_ksk_shape(), dtype=np.uint32)
         self._ck(_lib.lib().mkt_get_ksk(self.h, party, _np_ptr(out)))
         return out
 
@@ -229,7 +275,10 @@ class Scheme:
         self._ck(_lib.lib().mkt_load_crs(self.h, _np_ptr(np.ascontiguousarray(a, dtype=kd)), fmt))
 
     def set_stream(self, stream_handle):
-        self._ck(_lib.lib().mkt_set_stream(self.h, C.c_void_p(stream_handle)))
+        """pin the HIP stream (hipStream_t handle) every later call is enqueued on; None = back to the default:
+        follow torch's current stream for GPU tensors (the NULL stream for host arrays)"""
+        self._user_stream = stream_handle is not None
+        self._ck(_lib.lib().mkt_set_stream(self.h, C.c_void_p(stream_handle or 0)))
 
     def synchronize(self):
         self._ck(_lib.lib().mkt_synchronize(self.h))
@@ -261,13 +310,13 @@ class Scheme:
         return int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
 
     def gate(self, op, x, y, out=None):
-        px, mem, kx = _arg(x, np.uint32)
-        py, mem2, ky = _arg(y, np.uint32)
+        px, mem, kx = _arg(x, np.uint32, scheme=self)
+        py, mem2, ky = _arg(y, np.uint32, scheme=self)
         if mem != mem2:
             raise ValueError("x and y must both be host arrays or both be GPU tensors")
         if out is None:
             out = kx.new_empty(kx.shape) if mem == MEM_DEVICE else np.empty_like(kx)
-        po, mem3, ko = _arg(out, np.uint32, writable=True)
+        po, mem3, ko = _arg(out, np.uint32, writable=True, scheme=self)
         if mem3 != mem:
             raise ValueError("out must live where the inputs live")
         if tuple(kx.shape) != tuple(ky.shape) or kx.shape[-1] != self.params.lwe_len:
@@ -276,14 +325,14 @@ class Scheme:
         return ko
 
     def bootstrapping_(self, ctxt):
-        p, mem, k = _arg(ctxt, np.uint32, writable=True)
+        p, mem, k = _arg(ctxt, np.uint32, writable=True, scheme=self)
         if k.shape[-1] != self.params.lwe_len:
             raise ValueError("ciphertext shape mismatch")
         self._ck(_lib.lib().mkt_bootstrap_batch(self.h, p, self._batch(k), mem))
         return k
 
     def not_(self, ctxt):
-        p, mem, k = _arg(ctxt, np.uint32, writable=True)
+        p, mem, k = _arg(ctxt, np.uint32, writable=True, scheme=self)
         self._ck(_lib.lib().mkt_not_batch(self.h, p, self._batch(k), mem))
         return k
 
@@ -296,8 +345,8 @@ class Scheme:
         return at, bt
 
     def blindrotate_(self, atilde, acc):
-        pa, mem, ka = _arg(atilde, np.uint32)
-        pc, mem2, kc = _arg(acc, self.params.ring_dtype, writable=True)
+        pa, mem, ka = _arg(atilde, np.uint32, scheme=self)
+        pc, mem2, kc = _arg(acc, self.params.ring_dtype, writable=True, scheme=self)
         if mem != mem2:
             raise ValueError("atilde and acc must live in the same memory")
         self._ck(_lib.lib().mkt_blindrotate_batch(self.h, pa, pc, self._batch(ka), mem))
@@ -320,19 +369,19 @@ class Scheme:
         return out
 
     def transform_fwd(self, p, out=None):
-        pp, mem, kp = _arg(p, self.params.ring_dtype)
+        pp, mem, kp = _arg(p, self.params.ring_dtype, scheme=self)
         if out is None:
             if mem == MEM_DEVICE:
                 import torch
                 out = torch.empty(tuple(kp.shape[:-1]) + (self.params.N // 2,), dtype=torch.complex128, device=kp.device)
             else:
                 out = np.empty(kp.shape[:-1] + (self.params.N // 2,), dtype=np.complex128)
-        po, _, ko = _arg(out, np.complex128, writable=True)
+        po, _, ko = _arg(out, np.complex128, writable=True, scheme=self)
         self._ck(_lib.lib().mkt_transform_fwd_batch(self.h, pp, po, self._batch(kp), mem))
         return ko
 
     def transform_inv(self, t, out=None):
-        pt, mem, kt = _arg(t, np.complex128)
+        pt, mem, kt = _arg(t, np.complex128, scheme=self)
         if out is None:
             if mem == MEM_DEVICE:
                 import torch
@@ -340,7 +389,7 @@ class Scheme:
                 out = torch.empty(tuple(kt.shape[:-1]) + (self.params.N,), dtype=tdt, device=kt.device)
             else:
                 out = np.empty(kt.shape[:-1] + (self.params.N,), dtype=self.params.ring_dtype)
-        po, _, ko = _arg(out, self.params.ring_dtype, writable=True)
+        po, _, ko = _arg(out, self.params.ring_dtype, writable=True, scheme=self)
         self._ck(_lib.lib().mkt_transform_inv_batch(self.h, pt, po, self._batch(kt), mem))
         return ko
 

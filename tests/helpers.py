@@ -58,3 +58,30 @@ GATE_FUNCS = {
     0: lambda x, y: ~(x & y), 1: lambda x, y: x & y, 2: lambda x, y: x | y,
     3: lambda x, y: x ^ y, 4: lambda x, y: ~(x ^ y), 5: lambda x, y: ~(x | y),
 }
+
+
+# ---- tests/golden/kat_tiny.npz (gen_kat.py): fixture with inputs AND expected outputs ----
+def kat_cases():
+    import types
+    from golden.gen_kat import params_of
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kat_tiny.npz"))
+    names = sorted({k.split("/")[0] for k in g.files})
+    for name in names:
+        d = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/")}
+        p = params_of(d["params"], name="kat_" + name)
+        keys = []
+        for i in range(p.nparty):
+            keys.append(types.SimpleNamespace(brk=d[f"brk{i}"], ksk=d[f"ksk{i}"], pubkey=d.get(f"pub{i}"),
+                                              rlk_d=d.get(f"rlkd{i}"), rlk_f=d.get(f"rlkf{i}"), lwekey=d["lwekeys"][i]))
+        yield name, p, d, keys
+
+
+def kat_decrypt(p, d, ct):
+    """scheme.jl:388-407 with the fixture's LWE secrets, in numpy"""
+    ph = ct[..., -1].astype(np.uint64)
+    for i in range(p.nparty):
+        ph = ph + (ct[..., i * p.n:(i + 1) * p.n].astype(np.uint64) * d["lwekeys"][i].astype(np.uint64)).sum(-1)
+    ph = ph & np.uint64(0xFFFFFFFF)
+    if p.multikey:
+        return ph < (1 << 31)
+    return ((ph >> np.uint64(29)) + ((ph >> np.uint64(28)) & np.uint64(1))) == 1

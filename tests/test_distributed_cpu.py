@@ -56,3 +56,17 @@ def test_shard_slices():
     assert shard_slices(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert shard_slices(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
     assert shard_slices(0, 2) == [(0, 0), (0, 0)]
+
+
+def test_bench_gpus_n_spawns_ranks_and_propagates_failure():
+    """`python bench.py --gpus 2` without a torchrun environment starts two rank processes itself.  On this CPU-only
+    box each rank dies at torch.cuda.set_device: the parent must exit non-zero and print no JSON line (never a silent
+    one-rank run reported as n_gpus 1)."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = ""; env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "4",
+                        "--no-cpu-baseline", "--no-roofline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout
+    assert "ranks failed" in r.stderr

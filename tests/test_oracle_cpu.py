@@ -191,6 +191,30 @@ def test_forward_inverse_roundtrip_small_values():
             assert np.abs(d.astype(np.int64)).max() <= 2048
 
 
+def test_forward_transform_edge_words_in_both_halves():
+    """fft.jl:60: coefficient i + M enters as -signed(p[i + M]) with the negation done in the INTEGER type, so typemin
+    (0x80..0) wraps to itself and converts to -2^(W-1), not +2^(W-1).  Special words at indices < M and >= M, the C oracle
+    against the independent numpy transcription, raw bits."""
+    import ref_numpy as R
+    rng = np.random.default_rng(61)
+    for N, W in ((256, 32), (256, 64), (1024, 32), (1024, 64), (2048, 64)):
+        m = (1 << W) - 1
+        special = [0, 1, 2, m, m - 1, 1 << (W - 1), (1 << (W - 1)) - 1, (1 << (W - 1)) + 1, 1 << (W - 3), m - (1 << (W - 3)) + 1]
+        v = (rng.integers(0, 1 << 63, N, dtype=np.uint64) * 2 + rng.integers(0, 2, N, dtype=np.uint64)) & np.uint64(m)
+        v[:10] = special; v[N // 2:N // 2 + 10] = special; v[N - 10:] = special[::-1]
+        t_c = O.Ffter(N, W).fwd(v[None, :])[0]
+        t_n = R.FFT(N, W).fwd(v.astype(np.uint64 if W == 64 else np.uint32))
+        assert np.array_equal(t_c.real.view(np.uint64), t_n.re.view(np.uint64)), (N, W)
+        assert np.array_equal(t_c.imag.view(np.uint64), t_n.im.view(np.uint64)), (N, W)
+        # the typemin word in the upper half contributes -(-2^(W-1)) ... i.e. the imaginary input is -2^(W-1) exactly
+        one = np.zeros(N, dtype=np.uint64); one[N // 2 + 3] = 1 << (W - 1)
+        z = O.Ffter(N, W).fwd(one[None, :])[0]
+        lone = np.zeros(N, dtype=np.uint64); lone[3] = 1 << (W - 1)
+        zl = O.Ffter(N, W).fwd(lone[None, :])[0]
+        # both are -2^(W-1) placed in the imaginary / real slot of point 3: z = i * zl
+        assert np.array_equal(z.real.view(np.uint64), (-zl.imag).view(np.uint64)) and np.array_equal(z.imag.view(np.uint64), zl.real.view(np.uint64))
+
+
 def test_monomial_table_semantics():
     N = 64
     f = O.Ffter(N, 32)
@@ -256,6 +280,26 @@ def test_end_to_end_golden_hashes():
 
 
 # ---------------------------------------------------------------- second, independent restatement (numpy)
+def test_kat_fixture_reproduced_by_the_oracle():
+    """tests/golden/kat_tiny.npz holds inputs (integer keys, CRS, ciphertexts) and expected outputs for all five
+    schemes; the oracle reproduces every word, and the outputs decrypt to the gate truth tables"""
+    from helpers import kat_cases, kat_decrypt
+    seen = 0
+    for name, p, d, keys in kat_cases():
+        so = oracle_scheme(p, d.get("crs"), keys)
+        x, y = d["x"], d["y"]
+        for op in range(6):
+            got = np.stack([so.gate(op, x[j], y[j]) for j in range(4)])
+            assert np.array_equal(got, d["out"][op]), (name, op)
+            assert np.array_equal(kat_decrypt(p, d, got), GATE_FUNCS[op](d["bits"][:4], d["bits"][4:])), (name, op, "decrypt")
+        for j in range(4):
+            at, bt = so.modswitch(O.gate_linear(0, x[j], y[j]))
+            assert np.array_equal(at, d["atilde"][j]) and bt == d["btilde"][j]
+            assert np.array_equal(so.blindrotate(at, so.testvector(bt)), d["acc"][j]), (name, "blindrotate")
+        seen += 1
+    assert seen == 5
+
+
 @pytest.mark.parametrize("p", [
     mk.CGGIparam.scaled(n=10, N=256), mk.CGGIparam.scaled(n=6, N=256, k=2), mk.KMS2party.scaled(n=6, N=256),
     mk.KMS4party.scaled(n=4, N=256, k=3), mk.KMS2party_N1024_l2.scaled(n=4), mk.CGGIparam, mk.KMS2party.scaled(n=40),

@@ -1,25 +1,30 @@
-"""Copy the judged summaries of a tools/profile_round.sh run from gpurun_out/<tag>/ into profiles/ (tracked)."""
-import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+"""Copy the judged summaries of a tools/profile_round.sh run from gpurun_out/<tag>/ into profiles/ (tracked).
+usage: python tools/collect_profiles.py <tag> [workload]"""
+import csv, glob, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+wl = sys.argv[2] if len(sys.argv) > 2 else "kms2_n1024"
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(f"{src}/bench_*.json"):
     lines = [l for l in open(f) if l.startswith('{"metric"')]
-    open(f"{dst}/{tag}_{os.path.basename(f)}", "w").write("".join(lines))
-for f in glob.glob(f"{src}/trace/*/*kernel_stats.csv"):
-    shutil.copy(f, f"{dst}/{tag}_bench_kms2_n1024_kernel_stats.csv")
-with open(f"{dst}/{tag}_bench_kms2_n1024_pmc.txt", "w") as out:
-    out.write("# rocprofv3 --kernel-trace --pmc <counters> (separate passes), python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline\n")
-    out.write("# FETCH_SIZE / WRITE_SIZE unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of a coalesced read stream -> x2.\n")
-    out.write("# kernel, grid, counter, mean value over dispatches, mean duration ms, dispatches\n")
-    for d in sorted(glob.glob(f"{src}/pmc_*")):
-        agg = {}
-        for f in glob.glob(f"{d}/*/*counter_collection.csv"):
-            for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"]
-                if "mktd" not in k: continue
-                key = (k.split("(")[0].replace("void ", ""), r["Grid_Size"], r["Counter_Name"])
-                agg.setdefault(key, []).append((float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
-        for (k, g, c), v in sorted(agg.items()):
-            out.write(f"{k},{g},{c},{sum(x[0] for x in v)/len(v):.6g},{sum(x[1] for x in v)/len(v):.4f},{len(v)}\n")
-print(os.listdir(dst))
+    if lines:
+        open(f"{dst}/{tag}_{os.path.basename(f)}", "w").write("".join(lines))
+for f in glob.glob(f"{src}/trace_{wl}/*/*kernel_stats.csv"):
+    shutil.copy(f, f"{dst}/{tag}_bench_{wl}_kernel_stats.csv")
+dirs = sorted(glob.glob(f"{src}/pmc_{wl}_*"))
+if dirs:
+    with open(f"{dst}/{tag}_bench_{wl}_pmc.txt", "w") as out:
+        out.write(f"# rocprofv3 --kernel-trace --pmc <counters> (separate passes), python3 bench.py --steps 2 --warmup 0 --workload {wl} --no-cpu-baseline --no-secondary\n")
+        out.write("# FETCH_SIZE / WRITE_SIZE unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of a coalesced read stream -> x2.\n")
+        out.write("# kernel, grid, counter, mean value over dispatches, mean duration ms, dispatches\n")
+        for d in dirs:
+            agg = {}
+            for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+                for r in csv.DictReader(open(f)):
+                    k = r["Kernel_Name"]
+                    if "mktd" not in k: continue
+                    key = (k.split("(")[0].replace("void ", ""), r["Grid_Size"], r["Counter_Name"])
+                    agg.setdefault(key, []).append((float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+            for (k, g, c), v in sorted(agg.items()):
+                out.write(f"{k},{g},{c},{sum(x[0] for x in v)/len(v):.6g},{sum(x[1] for x in v)/len(v):.4f},{len(v)}\n")
+print(sorted(os.listdir(dst)))
