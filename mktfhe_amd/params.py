@@ -89,10 +89,11 @@ KMS2party_N1024_l2 = Params("KMS2party_N1024_l2", KMS, 560, 1024, 2, 64, 2.0**17
                             l_gsw=2, logB_gsw=16, l_lev=2, logB_lev=6, l_uni=3, logB_uni=10)
 
 # BASELINE.json configs[0]: "CGGI single-key NAND bootstrap, N=1024, n=630, l=2" -- the reference's CGGIparam has l = 3
-# (params.jl:1-6); this is the l = 2 gadget with the base that keeps 20 bits of each accumulator word (the classic
-# TFHE (l, Bg) = (2, 2^10)): output phase error ~2^25.4 on the 2^32 torus against the 2^29 margin.
-CGGI_N1024_l2 = Params("CGGI_N1024_l2", CGGI, 630, 1024, 1, 32, 2.0**17, 2.0**7, l_gsw=2, logB_gsw=10)
-# BASELINE.json configs[3]: "CCS multi-key k=8, N=2048" -- the reference's CCS8party has N = 1024 (params.jl:31-37);
-# same gadget and noise, twice the ring dimension (a synthetic performance shape: like CCS8party itself it decrypts
-# wrongly now and then on gates that involve many parties -- the set's own noise, not the engine's).
-CCS8party_N2048 = Params("CCS8party_N2048", CCS, 560, 2048, 8, 32, 2.0**17, 2.0**4, l_uni=5, logB_uni=6)
+# (params.jl:1-6); this is the l = 2 gadget with the base of least output noise (tools/noise_probe.py on the GPU:
+# phase error std 0.006 at logB = 8 against the 0.125 margin; 0.010 at 7 and 9, 0.020 at 10 -- CGGIparam itself: 0.012).
+CGGI_N1024_l2 = Params("CGGI_N1024_l2", CGGI, 630, 1024, 1, 32, 2.0**17, 2.0**7, l_gsw=2, logB_gsw=8)
+# BASELINE.json configs[3]: "CCS multi-key k=8, N=2048" -- the reference's CCS8party has N = 1024 (params.jl:31-37) and
+# is noisy already (phase error std 0.040: 1-3 % wrong decryptions on 8-party gates); at N = 2048 the same beta = 2^4
+# gives 0.075 (25 % wrong).  The doubled ring dimension carries its security with less noise: beta = 1 (std 0.011, no
+# failures in 2048 gates, tools/noise_probe.py); gadget as CCS8party.
+CCS8party_N2048 = Params("CCS8party_N2048", CCS, 560, 2048, 8, 32, 2.0**17, 1.0, l_uni=5, logB_uni=6)

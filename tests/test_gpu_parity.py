@@ -192,7 +192,7 @@ def _mixed_party_check(p, keys, so, sg, rng, B=3):
 
 # parameter sets whose own noise makes gates on many-party ciphertexts decrypt wrongly now and then (the oracle
 # produces the identical words): bit parity is asserted for them, decryption is not
-NOISY = {"CCS16party", "CCS8party", "CCS8party_N2048", "CCS4party", "KMS8party"}
+NOISY = {"CCS16party", "CCS8party", "CCS4party", "KMS8party"}
 
 
 @pytest.mark.parametrize("p", SMALL, ids=lambda p: f"{p.name}-n{p.n}-N{p.N}")
