@@ -36,6 +36,8 @@ struct RotArgs {
     int tout_natural;         // 1: reference point order (API output); 0: device order (feeds phase 2)
     int variant;              // tuning: 10*LOGR + transforms per group (0 = default)
     int stagger;              // start-up delay of alternate workgroup groups, in units of 512 cycles (0 = off)
+    unsigned block0;          // first workgroup index of this launch (a rotation batch may be issued as several launches)
+    unsigned split;           // workgroups per launch (0 = the whole batch in one launch)
 };
 
 // KMS phase 2 (bootstrapping.jl:448-558), one workgroup per ciphertext.

@@ -68,9 +68,12 @@ struct Plan {
         if (OVL) return p == PA ? OVL : lo(p) + LOGR - 1;
         return p < NPASS - 1 ? lo(p) + LOGR - 1 : nst(p) - 1;
     }
-    // LDS staging: NB transforms side by side, two buffers (one barrier per exchange)
+    // LDS staging: NB transforms side by side.  Workgroups of more than one wave alternate between two buffers (one
+    // barrier per exchange); a single wave's LDS operations complete in order, so one buffer and no barrier do
     static constexpr int BUF = NB * M;
-    static constexpr int LDS_CPLX = 2 * BUF;
+    static constexpr int NBUF = NT > 64 ? 2 : 1;
+    __host__ __device__ static constexpr int buf_off(int pass) { return NBUF == 2 ? (pass & 1) * BUF : 0; }
+    static constexpr int LDS_CPLX = NBUF * BUF;
     static constexpr size_t LDS_BYTES = (size_t)LDS_CPLX * sizeof(cplx);
 };
 
@@ -267,7 +270,7 @@ __device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *lds, in
     constexpr int R = Route<LOGM, LOGR, MO>::of(LO_FROM, LO_TO);
     if constexpr (R == 1) exchange_lane_full<(LO_FROM < LO_TO ? LO_FROM : LO_TO), NB>(z, lx);
     else if constexpr (R == 2) { constexpr int LB = Plan<LOGM, LOGR>::OVL; if constexpr (FWD) exchange_lane_odd_fwd<NB, LB>(z, lx); else exchange_lane_odd_inv<NB, LB>(z, lx); }
-    else exchange_lds<LOGM, LOGR, NB>(z, lds + (PASS & 1) * Plan<LOGM, LOGR, NB>::BUF, t, LO_FROM, LO_TO);
+    else exchange_lds<LOGM, LOGR, NB>(z, lds + Plan<LOGM, LOGR, NB>::buf_off(PASS), t, LO_FROM, LO_TO);
 }
 
 // fft.jl:105-155: for stage bit b (stride k = 2^b, m = 2^(LOGM-1-b)), butterfly on (j, j+k):
@@ -374,15 +377,38 @@ template <> struct WordTraits<uint64_t> { static constexpr int W = 64; typedef i
 template <typename WORD>
 __device__ __forceinline__ double word_to_f64(WORD x) { return (double)(typename WordTraits<WORD>::S)x; }
 
-// arithmetic.jl:1-9 native(x, mask)
+// arithmetic.jl:1-9 native(x, mask):  x -= floor(x * 2^-W) * 2^W;  x == 2^W ? 0 : trunc_to_unsigned(x)
+// The reduction is the reference's two operations (the scaling by a power of two is exact, the subtraction rounds as
+// it does there) and leaves y in [0, 2^W].  The conversion is done without v_cvt / v_cmp / v_cndmask: for an integer v
+// in [0, 2^32] the low dword of the double v + 2^52 is v mod 2^32 (the sum is exact below 2^53), which maps the one
+// special value 2^W -- the rounded-up sum of a tiny negative x and 2^W -- to 0 exactly like the reference's test.
+// MKT_NATIVE_MAGIC 0 keeps the literal compare-and-convert form (same bits; tests/test_gpu_parity.py covers both builds'
+// outputs against the oracle).
+#ifndef MKT_NATIVE_MAGIC
+#define MKT_NATIVE_MAGIC 1
+#endif
+__device__ __forceinline__ uint32_t low_dword_of_sum_2p52(double v) {
+    const double s = v + 4503599627370496.0;   // 2^52
+    return (uint32_t)__double2loint(s);
+}
 template <typename WORD> __device__ __forceinline__ WORD native(double x);
 template <> __device__ __forceinline__ uint32_t native<uint32_t>(double x) {
     x -= floor(x * 2.3283064365386963e-10) * 4.294967296e9;
+#if MKT_NATIVE_MAGIC
+    return low_dword_of_sum_2p52(trunc(x));                  // trunc, as the reference (x >= 0 unless x * 2^-W underflowed)
+#else
     return x == 4.294967296e9 ? 0u : (uint32_t)x;
+#endif
 }
 template <> __device__ __forceinline__ uint64_t native<uint64_t>(double x) {
     x -= floor(x * 5.421010862427522e-20) * 1.8446744073709552e19;
+#if MKT_NATIVE_MAGIC
+    const double hi = trunc(x * 2.3283064365386963e-10);    // in [0, 2^32], exact
+    const double lo = trunc(x - hi * 4.294967296e9);        // exact difference in [0, 2^32), fraction dropped
+    return ((uint64_t)low_dword_of_sum_2p52(hi) << 32) | (uint64_t)low_dword_of_sum_2p52(lo);
+#else
     return x == 1.8446744073709552e19 ? (uint64_t)0 : (uint64_t)x;
+#endif
 }
 
 // arithmetic.jl:23-27 divbits (bit may be 0: Julia shifts by >= width give 0)

@@ -133,7 +133,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
             const bool contig = !dev_order && MKT_FFT_CONTIG_STORE && P::NPASS > 1;
             if (contig) {
                 __syncthreads();
-                exchange_lds<LOGM, LOGR, NBT>(z, lds + ((P::NPASS - 1) & 1) * P::BUF, t, 0, P::lo(0));
+                exchange_lds<LOGM, LOGR, NBT>(z, lds + P::buf_off(P::NPASS - 1), t, 0, P::lo(0));
                 __syncthreads();      // the next transform's exchanges reuse the buffers
             }
 #pragma unroll
@@ -186,7 +186,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_inv_kernel(T
             if (b + (size_t)PF * gridDim.x < B) load(d, b + (size_t)PF * gridDim.x);
             if (CONTIG) {   // contiguous ownership (e*NT + t) -> the inverse transform's first window (4t + e)
                 __syncthreads();
-                exchange_lds<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][R]>(z), lds + (P::NPASS & 1) * P::BUF, t, P::lo(0), 0);
+                exchange_lds<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][R]>(z), lds + P::buf_off(P::NPASS), t, P::lo(0), 0);
                 __syncthreads();
             }
 #if MKT_FFT_TW_LDS
@@ -336,6 +336,15 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 #ifndef MKT_ROT_BUFLOAD
 #define MKT_ROT_BUFLOAD 1
 #endif
+// Software prefetch of the rotation loop's table reads (bit mask): 1 = the monomial row of this step is requested at the
+// top of the step (its index only depends on the LWE mask word) instead of right before its use; 2 = the key rows of a
+// digit group are requested before the group's forward transform instead of during its last pass.
+#ifndef MKT_ROT_PF
+#define MKT_ROT_PF 1      // measured on MI355X (KMS k=2 N=1024, 4096 gates): 1 -> -4 %, 2 -> +0.5 % (register pressure), with ROOTS_REG -6 %
+#endif
+#ifndef MKT_ROT_ROOTS_REG
+#define MKT_ROT_ROOTS_REG 1   // roots / rootsinv of the thread's points in registers for the whole rotation (2 * R * 4 VGPRs): 20 of the 51 table loads of a CMux gone
+#endif
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void *p, size_t bytes) {
     const unsigned long long a = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
@@ -369,7 +378,8 @@ void blindrotate_k1_kernel(const RotArgs a) {
     // co-resident workgroups run the same loop in near lock-step and then fight for the VALU and the LDS at the same
     // moments; delaying every other group of 256 workgroups (= every other workgroup of a CU under round-robin
     // dispatch; speed only, never correctness) de-phases them
-    if (a.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+    const unsigned bid = blockIdx.x + a.block0;
+    if (a.stagger > 0 && ((bid >> 8) & 1)) {
         for (int s = 0; s < a.stagger; s++) __builtin_amdgcn_s_sleep(8);
     }
 #if MKT_TW_LDS
@@ -385,8 +395,8 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #endif
     // workgroups are dealt slot-major (all ciphertexts' rotations of one party/row are adjacent), so the workgroups
     // resident at any time stream the SAME party's key rows through L2; results are stored ciphertext-major
-    const size_t gate = blockIdx.x % (size_t)a.ngates;
-    const int slot = (int)(blockIdx.x / (size_t)a.ngates);
+    const size_t gate = bid % (size_t)a.ngates;
+    const int slot = (int)(bid / (size_t)a.ngates);
     const size_t rot = gate * (size_t)a.rows_per_gate + slot;
     const int party = __builtin_amdgcn_readfirstlane(a.slot_party[slot]), row = __builtin_amdgcn_readfirstlane(a.slot_row[slot]);
     const uint32_t *at_src = a.lwe + gate * (size_t)a.lwe_stride + (size_t)party * a.n;
@@ -401,6 +411,14 @@ void blindrotate_k1_kernel(const RotArgs a) {
     // LT, BT > 0: gadget length and base known at compile time -- every digit shift / mask is an immediate
     const Gadget<WORD> gd(LT ? LT : a.l, (LT && BT) ? BT : a.logB);
     const int l = LT ? LT : a.l;   // LT > 0: gadget length known at compile time, the digit loop unrolls fully
+
+    constexpr bool RREG = MKT_ROT_ROOTS_REG && LB == 1;   // the block kernels have no registers to spare (measured: -12 % at KMS2partyblock)
+    cplx rt_reg[R], ri_reg[R];                // RREG: the twist / untwist factors of this thread's points stay in registers
+#pragma unroll
+    for (int e = 0; e < R; e++) {
+        if (RREG) { rt_reg[e] = a.tw.roots[e * NT + t]; ri_reg[e] = a.tw.rootsinv[e * NT + t]; }
+        else { rt_reg[e].re = rt_reg[e].im = 0.0; ri_reg[e] = rt_reg[e]; }
+    }
 
     WORD acc[2][R][2];
     if (a.init_mode == 0) {
@@ -430,6 +448,14 @@ void blindrotate_k1_kernel(const RotArgs a) {
         }
         if (!any) continue;                                              // :48 / :145 / :413 / :638
 
+        cplx mono_pf[R];
+        constexpr bool PF_MONO = (MKT_ROT_PF & 1) && LB == 1 && MKT_ROT_BUFLOAD, PF_KEYS = (MKT_ROT_PF & 2) && LB == 1 && MKT_ROT_BUFLOAD;
+        if (PF_MONO) {
+#pragma unroll
+            for (int e = 0; e < R; e++) mono_pf[e] = table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[0] - 1) * M * sizeof(cplx)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
         cplx tacc[LB][2][R];
 #pragma unroll
         for (int q = 0; q < LB; q++)
@@ -442,6 +468,16 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll (LT ? 2 * LT : 1)
         for (int g0 = 0; g0 < 2 * l; g0 += NB) {
             cplx z[NB][R];
+            cplx kpf[NB][2][R];
+            if (PF_KEYS) {
+#pragma unroll
+                for (int h2 = 0; h2 < NB; h2++) {
+                    const unsigned so_row = (unsigned)((((size_t)blk * 2 * l + (size_t)(g0 + h2)) * 2) * M * sizeof(cplx));
+#pragma unroll
+                    for (int e = 0; e < R; e++) { kpf[h2][0][e] = table_load(rs_brk, vo_dev[e], so_row); kpf[h2][1][e] = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int h2 = 0; h2 < NB; h2++) {
                 const int g = g0 + h2;
@@ -453,7 +489,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
                     int d0, d1;
                     d0 = gd.digit(gd.prep(w0), j); d1 = gd.digit(gd.prep(w1), j);
                     cplx v; v.re = (double)d0; v.im = (double)(-d1);
-                    z[h2][e] = cmul(v, MKT_ROT_BUFLOAD ? table_load(rs_roots, vo_nat[e], 0) : a.tw.roots[e * NT + t]);
+                    z[h2][e] = cmul(v, RREG ? rt_reg[e] : MKT_ROT_BUFLOAD ? table_load(rs_roots, vo_nat[e], 0) : a.tw.roots[e * NT + t]);
                 }
             }
             fft_forward<LOGM, LR, NB, MO>(z, MKT_PSI_F, lds, t, xs.lx);  // :54-59 fftto!
@@ -467,7 +503,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
                     for (int e = 0; e < R; e++) {                        // :63-68 muladdto!(tacc, digit, row)
                         cplx kb, ka;
-                        if (MKT_ROT_BUFLOAD) { kb = table_load(rs_brk, vo_dev[e], so_row); ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
+                        if (PF_KEYS) { kb = kpf[h2][0][e]; ka = kpf[h2][1][e]; } else if (MKT_ROT_BUFLOAD) { kb = table_load(rs_brk, vo_dev[e], so_row); ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
                         tacc[q][0][e] = cadd(tacc[q][0][e], cmul(z[h2][e], kb));
                         tacc[q][1][e] = cadd(tacc[q][1][e], cmul(z[h2][e], ka));
                         if (RotOcc<LOGM, NB>::MINW >= 3) __builtin_amdgcn_sched_barrier(0);   // keep the key-row live ranges short at 3 waves/SIMD
@@ -481,7 +517,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int e = 0; e < R; e++) { cplx mv; mv = MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[0] - 1) * M * sizeof(cplx))) : mono[dev_pos(t * R + e, NT)]; t2[c][e] = cmul(mv, tacc[0][c][e]); }
+                for (int e = 0; e < R; e++) { cplx mv; mv = PF_MONO ? mono_pf[e] : MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[0] - 1) * M * sizeof(cplx))) : mono[dev_pos(t * R + e, NT)]; t2[c][e] = cmul(mv, tacc[0][c][e]); }
         } else {                                                         // :157 / :648 tacc2 += monomial * tacc
 #pragma unroll
             for (int c = 0; c < 2; c++)
@@ -505,7 +541,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < R; e++) {
-            const cplx ri = MKT_ROT_BUFLOAD ? table_load(rs_rinv, vo_nat[e], 0) : a.tw.rootsinv[e * NT + t];
+            const cplx ri = RREG ? ri_reg[e] : MKT_ROT_BUFLOAD ? table_load(rs_rinv, vo_nat[e], 0) : a.tw.rootsinv[e * NT + t];
 #pragma unroll
             for (int c = 0; c < 2; c++) {                                // fft.jl:76-80 untwist + native; :73 add!
                 const cplx v = cmul(t2[c][e], ri);
@@ -1093,6 +1129,13 @@ static hipError_t set_lds(K kern, size_t bytes) {
 bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
 #endif
 
+#ifdef MKT_ONLY_LOGM   // development builds: instantiate one transform size only (seconds instead of a minute per unit)
+#define MKT_DISPATCH_LOGM(logM, ...)                 \
+    switch (logM) {                                  \
+    case MKT_ONLY_LOGM: { constexpr int LM = MKT_ONLY_LOGM; __VA_ARGS__; } break; \
+    default: return hipErrorInvalidValue;            \
+    }
+#else
 #define MKT_DISPATCH_LOGM(logM, ...)                 \
     switch (logM) {                                  \
     case 4:  { constexpr int LM = 4;  __VA_ARGS__; } break; \
@@ -1105,6 +1148,7 @@ bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
     case 11: { constexpr int LM = 11; __VA_ARGS__; } break; \
     default: return hipErrorInvalidValue;            \
     }
+#endif
 
 #if MKT_IN_TU(0)
 template <int LM, typename WORD, int NBT>
@@ -1209,7 +1253,16 @@ static hipError_t launch_rot_lt(const RotArgs &a, size_t nrot, hipStream_t s) {
     const size_t lds_bytes = P::LDS_BYTES + (MKT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
     hipError_t e = set_lds(blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT, BT>, lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT, BT>), dim3((unsigned)nrot), dim3(P::NT), lds_bytes, s, a);
+    if (a.split == 0 || a.split >= nrot) {
+        hipLaunchKernelGGL((blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT, BT>), dim3((unsigned)nrot), dim3(P::NT), lds_bytes, s, a);
+        return hipGetLastError();
+    }
+    RotArgs b = a;
+    for (size_t b0 = 0; b0 < nrot; b0 += a.split) {
+        b.block0 = (unsigned)b0;
+        const size_t g = nrot - b0 < a.split ? nrot - b0 : a.split;
+        hipLaunchKernelGGL((blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT, BT>), dim3((unsigned)g), dim3(P::NT), lds_bytes, s, b);
+    }
     return hipGetLastError();
 }
 

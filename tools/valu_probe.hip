@@ -1,0 +1,98 @@
+// Issue-cost microbenchmark for gfx950 (MI355X): cycles per wave-instruction of the VALU / LDS instructions the
+// blind-rotation kernel is made of, and of the integer instructions an exact 64-bit-prime NTT butterfly would be made
+// of (the F64REF-vs-EXACT decision).  Independent instruction streams (8 accumulators), s_memtime stamps,
+// one workgroup per CU, 1 or 2 waves per SIMD.
+//   hipcc -O3 --offload-arch=gfx950 tools/valu_probe.hip -o /tmp/valu_probe && /tmp/valu_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+#define REP8(X) X X X X X X X X
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+template <int OP>
+__global__ __launch_bounds__(1024) void probe(uint64_t *out, int iters, double seed) {
+    double a0 = seed + threadIdx.x, a1 = a0 + 1.5, a2 = a0 + 2.5, a3 = a0 + 3.5, a4 = a0 + 4.5, a5 = a0 + 5.5, a6 = a0 + 6.5, a7 = a0 + 7.5;
+    double c = 1.0000001, d = 0.9999999;
+    unsigned i0 = threadIdx.x * 2654435761u, i1 = i0 + 17, i2 = i0 + 29, i3 = i0 + 31, i4 = i0 + 37, i5 = i0 + 41, i6 = i0 + 43, i7 = i0 + 47;
+    unsigned long long l0 = i0 * 0x9E3779B97F4A7C15ull, l1 = l0 + 3, l2 = l0 + 5, l3 = l0 + 7;
+    unsigned m = 0x10001u * (threadIdx.x + 3);
+    int e = 3;
+    __shared__ double4 lds[1024];
+    lds[threadIdx.x & 1023] = double4{a0, a1, a2, a3};
+    __syncthreads();
+    const unsigned laddr = (threadIdx.x & 63) * 16 + ((threadIdx.x >> 6) & 7) * 1024;
+    u4 r0 = {1, 2, 3, 4}, r1 = r0, r2 = r0, r3 = r0;
+    asm volatile("s_nop 0" ::: "memory");
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        if constexpr (OP == 0) { REP8(asm volatile("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));) }
+        if constexpr (OP == 1) { REP8(asm volatile("v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %9\n v_mul_f64 %2, %2, %8\n v_mul_f64 %3, %3, %9\n v_mul_f64 %4, %4, %8\n v_mul_f64 %5, %5, %9\n v_mul_f64 %6, %6, %8\n v_mul_f64 %7, %7, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));) }
+        if constexpr (OP == 2) { REP8(asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %9, %8\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %9, %8\n v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %9, %8\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %9, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));) }
+        if constexpr (OP == 3) { REP8(asm volatile("v_cvt_f64_i32 %0, %8\n v_cvt_f64_i32 %1, %9\n v_cvt_f64_i32 %2, %10\n v_cvt_f64_i32 %3, %11\n v_cvt_f64_i32 %4, %8\n v_cvt_f64_i32 %5, %9\n v_cvt_f64_i32 %6, %10\n v_cvt_f64_i32 %7, %11" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
+        if constexpr (OP == 4) { REP8(asm volatile("v_cvt_u32_f64 %0, %8\n v_cvt_u32_f64 %1, %9\n v_cvt_u32_f64 %2, %10\n v_cvt_u32_f64 %3, %11\n v_cvt_u32_f64 %4, %8\n v_cvt_u32_f64 %5, %9\n v_cvt_u32_f64 %6, %10\n v_cvt_u32_f64 %7, %11" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));) }
+        if constexpr (OP == 5) { REP8(asm volatile("v_floor_f64 %0, %0\n v_floor_f64 %1, %1\n v_floor_f64 %2, %2\n v_floor_f64 %3, %3\n v_floor_f64 %4, %4\n v_floor_f64 %5, %5\n v_floor_f64 %6, %6\n v_floor_f64 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+        if constexpr (OP == 6) { REP8(asm volatile("v_trunc_f64 %0, %0\n v_trunc_f64 %1, %1\n v_trunc_f64 %2, %2\n v_trunc_f64 %3, %3\n v_trunc_f64 %4, %4\n v_trunc_f64 %5, %5\n v_trunc_f64 %6, %6\n v_trunc_f64 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+        if constexpr (OP == 7) { REP8(asm volatile("v_ldexp_f64 %0, %0, %8\n v_ldexp_f64 %1, %1, %8\n v_ldexp_f64 %2, %2, %8\n v_ldexp_f64 %3, %3, %8\n v_ldexp_f64 %4, %4, %8\n v_ldexp_f64 %5, %5, %8\n v_ldexp_f64 %6, %6, %8\n v_ldexp_f64 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(e));) }
+        if constexpr (OP == 8) { REP8(asm volatile("v_mov_b32_dpp %0, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %9 row_ror:4 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %11 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m), "v"(e), "v"(m), "v"(e));) }
+        if constexpr (OP == 9) { REP8(asm volatile("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n v_permlane32_swap_b32 %0, %2\n v_permlane32_swap_b32 %1, %3\n v_permlane32_swap_b32 %4, %6\n v_permlane32_swap_b32 %5, %7" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));) }
+        if constexpr (OP == 10) { REP8(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m) : "vcc");) }
+        if constexpr (OP == 21) { REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[20:21]\n v_cndmask_b32_e64 %4, %4, %8, s[20:21]\n v_cndmask_b32_e64 %5, %5, %8, s[20:21]\n v_cndmask_b32_e64 %6, %6, %8, s[20:21]\n v_cndmask_b32_e64 %7, %7, %8, s[20:21]" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m) : "s20", "s21");) }
+        if constexpr (OP == 22) { REP8(asm volatile("v_cndmask_b32 %0, %8, %9, vcc\n v_cndmask_b32 %1, %9, %8, vcc\n v_cndmask_b32 %2, %8, %9, vcc\n v_cndmask_b32 %3, %9, %8, vcc\n v_cndmask_b32 %4, %8, %9, vcc\n v_cndmask_b32 %5, %9, %8, vcc\n v_cndmask_b32 %6, %8, %9, vcc\n v_cndmask_b32 %7, %9, %8, vcc" : "=v"(i0), "=v"(i1), "=v"(i2), "=v"(i3), "=v"(i4), "=v"(i5), "=v"(i6), "=v"(i7) : "v"(m), "v"(e) : "vcc");) }
+        if constexpr (OP == 11) { REP8(asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m));) }
+        if constexpr (OP == 12) { REP8(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %5, %6, %1\n v_mad_u64_u32 %2, vcc, %6, %7, %2\n v_mad_u64_u32 %3, vcc, %7, %4, %3\n v_mad_u64_u32 %0, vcc, %5, %7, %0\n v_mad_u64_u32 %1, vcc, %4, %6, %1\n v_mad_u64_u32 %2, vcc, %4, %4, %2\n v_mad_u64_u32 %3, vcc, %5, %5, %3" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3) : "v"(i0), "v"(i1), "v"(i2), "v"(i3) : "vcc");) }
+        if constexpr (OP == 13) { REP8(asm volatile("v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n v_mul_hi_u32 %4, %4, %8\n v_mul_hi_u32 %5, %5, %8\n v_mul_hi_u32 %6, %6, %8\n v_mul_hi_u32 %7, %7, %8" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m));) }
+        if constexpr (OP == 14) { REP8(asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m));) }
+        if constexpr (OP == 15) { REP8(asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %2, %2, 0, %3\n v_lshl_add_u64 %3, %3, 0, %0\n v_lshl_add_u64 %0, %0, 1, %2\n v_lshl_add_u64 %1, %1, 1, %3\n v_lshl_add_u64 %2, %2, 1, %0\n v_lshl_add_u64 %3, %3, 1, %1" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));) }
+        if constexpr (OP == 16) { REP8(asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m));) }
+        if constexpr (OP == 17) { REP8(asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:4096\n ds_read_b128 %2, %4 offset:8192\n ds_read_b128 %3, %4 offset:12288\n s_waitcnt lgkmcnt(0)" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3) : "v"(laddr) : "memory");) }
+        if constexpr (OP == 18) { REP8(asm volatile("ds_write_b128 %4, %0\n ds_write_b128 %4, %1 offset:4096\n ds_write_b128 %4, %2 offset:8192\n ds_write_b128 %4, %3 offset:12288\n s_waitcnt lgkmcnt(0)" :: "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(laddr) : "memory");) }
+        if constexpr (OP == 19) { REP8(asm volatile("v_cvt_f64_u32 %0, %8\n v_cvt_f64_u32 %1, %9\n v_cvt_f64_u32 %2, %10\n v_cvt_f64_u32 %3, %11\n v_cvt_f64_u32 %4, %8\n v_cvt_f64_u32 %5, %9\n v_cvt_f64_u32 %6, %10\n v_cvt_f64_u32 %7, %11" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
+        if constexpr (OP == 20) { REP8(asm volatile("v_add_f64 %0, %0, %8\n v_mov_b32_dpp %4, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f64 %1, %1, %8\n v_mov_b32_dpp %5, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f64 %2, %2, %8\n v_mov_b32_dpp %6, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f64 %3, %3, %8\n v_mov_b32_dpp %7, %10 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(c), "v"(d), "v"(m));) }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_nop 0" ::: "memory");
+    double s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7) + (double)(l0 + l1 + l2 + l3) + (double)(r0.x + r1.y + r2.z + r3.w);
+    if (s == 12345.678) out[1 << 20] = 1;
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+static const char *NAMES[] = {"v_add_f64", "v_mul_f64", "v_fma_f64", "v_cvt_f64_i32", "v_cvt_u32_f64", "v_floor_f64", "v_trunc_f64", "v_ldexp_f64",
+                              "v_mov_b32_dpp", "v_permlane16/32_swap_b32", "v_cndmask_b32", "v_mov_b32", "v_mad_u64_u32", "v_mul_hi_u32", "v_mul_lo_u32",
+                              "v_lshl_add_u64", "v_add_u32", "ds_read_b128 (x4 then wait)", "ds_write_b128 (x4 then wait)", "v_cvt_f64_u32", "v_add_f64 + v_mov_dpp pairs (per pair)", "v_cndmask_b32_e64 sgpr mask", "v_cndmask_b32 vcc, fresh dst"};
+static const int PER_ITER[] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64, 32, 64, 64};
+
+template <int OP>
+void run(uint64_t *d_out, int waves) {
+    const int iters = 2000, blocks = 256;
+    std::vector<uint64_t> h(blocks * 16);
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) {
+        hipLaunchKernelGGL(probe<OP>, dim3(blocks), dim3(64 * waves), 0, 0, d_out, iters, 1.25);
+        hipDeviceSynchronize();
+        hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> v;
+        for (int b = 0; b < blocks; b++) for (int w = 0; w < waves; w++) v.push_back((double)h[b * 16 + w]);
+        std::sort(v.begin(), v.end());
+        best = std::min(best, v[v.size() / 2]);
+    }
+    // cycles per wave-instruction as one wave sees it, and per SIMD (waves / 4 waves share a SIMD)
+    const double per_wave = best / (iters * (double)PER_ITER[OP]);
+    printf("%-42s %d wave(s)/SIMD: %6.2f cycles per instruction per wave, %6.2f per SIMD issue slot\n", NAMES[OP], waves / 4, per_wave, per_wave / (waves / 4));
+}
+
+template <int OP>
+void both(uint64_t *d) { run<OP>(d, 4); run<OP>(d, 8); }
+template <int OP>
+void four(uint64_t *d) { run<OP>(d, 4); run<OP>(d, 8); run<OP>(d, 12); run<OP>(d, 16); }
+
+int main() {
+    uint64_t *d;
+    hipMalloc(&d, ((1 << 20) + 8) * 8);
+    four<0>(d); both<1>(d); both<2>(d); both<3>(d); both<19>(d); both<4>(d); both<5>(d); both<6>(d); both<7>(d); four<8>(d); both<9>(d); four<10>(d); both<21>(d); both<22>(d); both<11>(d);
+    both<20>(d); both<12>(d); both<13>(d); both<14>(d); both<15>(d); both<16>(d); both<17>(d); both<18>(d);
+    hipFree(d);
+    return 0;
+}
