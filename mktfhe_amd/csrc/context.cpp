@@ -187,6 +187,7 @@ mktd::RotArgs rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
     a.stagger = 16;   // tools/stagger.sh: 16.99 -> 15.63 ms at KMS k=2 N=1024 on one device, neutral elsewhere
     if (const char *v = getenv("MKT_ROT_STAGGER")) a.stagger = atoi(v);
     if (const char *v = getenv("MKT_ROT_SPLIT")) a.split = (unsigned)atoi(v);
+    if (const char *v = getenv("MKT_ROT_WIDE")) a.wide = atoi(v);
     return a;
 }
 

@@ -36,6 +36,7 @@ struct RotArgs {
     int tout_natural;         // 1: reference point order (API output); 0: device order (feeds phase 2)
     int variant;              // tuning: 10*LOGR + transforms per group (0 = default)
     int stagger;              // start-up delay of alternate workgroup groups, in units of 512 cycles (0 = off)
+    int wide;                 // latency variant: 0 automatic, 1 never, 2 always where supported (MKT_ROT_WIDE)
     unsigned block0;          // first workgroup index of this launch (a rotation batch may be issued as several launches)
     unsigned split;           // workgroups per launch (0 = the whole batch in one launch)
 };

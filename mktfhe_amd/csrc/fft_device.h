@@ -242,13 +242,16 @@ __device__ __forceinline__ void exchange_lane_odd_inv(cplx (&z)[NB][4], const La
 #endif
 
 // which route the exchange between two windows of the schedule takes (compile time): 0 LDS, 1 in-wave 4x4, 2 odd window
-template <int LOGM, int LOGR, int MO = -1>      // MO >= 0: exchange-route mode of this kernel (else MKT_LANE_EXCHANGE)
+// MO >= 0: per-kernel override -- low byte = exchange-route mode (0xff = the library default MKT_LANE_EXCHANGE), bit 8 =
+// ONE staging buffer with a barrier on both sides of every LDS exchange (kernels whose LDS budget has no room for two)
+template <int LOGM, int LOGR, int MO = -1>
 struct Route {
+    static constexpr bool SB = MO >= 0 && (MO & 0x100) != 0;
     using P = Plan<LOGM, LOGR>;
     static constexpr int LANEBITS = (LOGM - LOGR) < 6 ? (LOGM - LOGR) : 6;   // thread bits that are lane bits
     __host__ __device__ static constexpr int of(int lo_a, int lo_b) {
         const int lomin = lo_a < lo_b ? lo_a : lo_b, diff = lo_a < lo_b ? lo_b - lo_a : lo_a - lo_b;
-        constexpr int MODE = MO >= 0 ? MO : MKT_LANE_EXCHANGE == 4 ? 8 : ((LOGM & 1) && MKT_LANE_EXCHANGE >= 5 && MKT_LANE_EXCHANGE <= 7 ? 2 : MKT_LANE_EXCHANGE);
+        constexpr int MODE = (MO >= 0 && (MO & 0xff) != 0xff) ? (MO & 0xff) : MKT_LANE_EXCHANGE == 4 ? 8 : ((LOGM & 1) && MKT_LANE_EXCHANGE >= 5 && MKT_LANE_EXCHANGE <= 7 ? 2 : MKT_LANE_EXCHANGE);
         if ((MODE == 1 || (MODE == 3 && lomin == 0) || (MODE == 5 && (lomin == 4 || lomin == 0)) || (MODE == 6 && lomin == 4) || (MODE == 7 && (lomin == 4 || lomin == 2)) || (MODE == 8 && (lomin == 4 || lomin == 2))) && LOGR == 2 && diff == 2 && lomin + 2 <= LANEBITS && lomin + 2 <= (MKT_PERMLANE_SWAP ? 6 : 5)) return 1;
         if (MODE >= 1 && LOGR == 2 && diff == 1 && lomin == P::OVL && LANEBITS >= lomin + 1) return 2;
         return 0;
@@ -259,8 +262,8 @@ struct Route {
     __host__ __device__ static constexpr int inv_first() { for (int p = P::NPASS - 1; p >= 1; p--) if (of(P::lo(p), P::lo(p - 1)) == 0) return p & 1; return -1; }
     __host__ __device__ static constexpr int inv_last() { for (int p = 1; p <= P::NPASS - 1; p++) if (of(P::lo(p), P::lo(p - 1)) == 0) return p & 1; return -1; }
     // a transform must open with a barrier if its first LDS exchange reuses the buffer of the previous transform's last
-    static constexpr bool guard_fwd = fwd_first() >= 0 && (fwd_first() == fwd_last() || fwd_first() == inv_last());
-    static constexpr bool guard_inv = inv_first() >= 0 && (inv_first() == fwd_last() || inv_first() == inv_last());
+    static constexpr bool guard_fwd = !SB && fwd_first() >= 0 && (fwd_first() == fwd_last() || fwd_first() == inv_last());
+    static constexpr bool guard_inv = !SB && inv_first() >= 0 && (inv_first() == fwd_last() || inv_first() == inv_last());
 };
 
 // one exchange between the windows lo_from / lo_to of the schedule, by the cheapest legal route; PASS = the pass
@@ -270,7 +273,11 @@ __device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *lds, in
     constexpr int R = Route<LOGM, LOGR, MO>::of(LO_FROM, LO_TO);
     if constexpr (R == 1) exchange_lane_full<(LO_FROM < LO_TO ? LO_FROM : LO_TO), NB>(z, lx);
     else if constexpr (R == 2) { constexpr int LB = Plan<LOGM, LOGR>::OVL; if constexpr (FWD) exchange_lane_odd_fwd<NB, LB>(z, lx); else exchange_lane_odd_inv<NB, LB>(z, lx); }
-    else exchange_lds<LOGM, LOGR, NB>(z, lds + Plan<LOGM, LOGR, NB>::buf_off(PASS), t, LO_FROM, LO_TO);
+    else {
+        constexpr bool SB = Route<LOGM, LOGR, MO>::SB;
+        if (SB) __syncthreads();                     // every reader of the single buffer is done before it is rewritten
+        exchange_lds<LOGM, LOGR, NB>(z, lds + (SB ? 0 : Plan<LOGM, LOGR, NB>::buf_off(PASS)), t, LO_FROM, LO_TO);
+    }
 }
 
 // fft.jl:105-155: for stage bit b (stride k = 2^b, m = 2^(LOGM-1-b)), butterfly on (j, j+k):

@@ -11,7 +11,7 @@
 // The file is compiled once per translation unit MKT_TU (Makefile) so the template instantiations build in parallel:
 //   0 transforms, small kernels, key switch, dispatchers      3 / 5 blind rotation of the block schemes (LMSS, KMS_block), 32- / 64-bit ring
 //   1 blind rotation, 32-bit ring, plain schemes              4 general-k rotation, KMS phase 2, CCS
-//   2 blind rotation, 64-bit ring, plain schemes
+//   2 blind rotation, 64-bit ring, plain schemes              6 blind rotation, latency variant (one rotation over 2l thread groups)
 // MKT_TU undefined = everything in one unit.
 #ifdef MKT_TU
 #define MKT_IN_TU(n) (MKT_TU == (n))
@@ -1351,8 +1351,15 @@ hipError_t launch_rot_plain_u32(int logM, const RotArgs &a, size_t nrot, hipStre
 hipError_t launch_rot_plain_u64(int logM, const RotArgs &a, size_t nrot, hipStream_t s);
 hipError_t launch_rot_block_u32(int logM, const RotArgs &a, size_t nrot, hipStream_t s);
 hipError_t launch_rot_block_u64(int logM, const RotArgs &a, size_t nrot, hipStream_t s);
+bool wide_supported(int logM, int l, int blk_len);
+hipError_t launch_blindrotate_wide(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s);
 hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s) {
     if (!nrot) return hipSuccess;
+    // few rotations in flight (a single gate, small batches): the latency variant spreads one rotation over 2l thread
+    // groups of one CU; a.wide: 0 = automatic (at most one rotation per CU, M <= 512: measured 3-16 % less latency there,
+    // 2x MORE at M = 1024 where the groups need 8 points per thread), 1 = never, 2 = always where supported
+    if (a.wide != 1 && wide_supported(logM, a.l, a.blk_len) && (a.wide == 2 || (nrot <= 256 && logM <= 9)))
+        return launch_blindrotate_wide(logM, W, a, nrot, s);
     if (a.blk_len > 1) return W == 64 ? launch_rot_block_u64(logM, a, nrot, s) : launch_rot_block_u32(logM, a, nrot, s);
     return W == 64 ? launch_rot_plain_u64(logM, a, nrot, s) : launch_rot_plain_u32(logM, a, nrot, s);
 }
@@ -1462,5 +1469,165 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     return hipGetLastError();
 }
 #endif  // TU 0
+
+#if MKT_IN_TU(6)
+// ------------------------------------------------------------------------------------------------
+// Blind rotation, latency variant (few rotations in flight: a single gate, small batches).  Same arithmetic as
+// blindrotate_k1_kernel, LB = 1: bootstrapping.jl:32-76 (CGGI, k = 1), :389-443 (KMS phase 1).  ONE workgroup per
+// rotation, but the 2l digit transforms of a CMux step (:54-59) run side by side on 2l thread groups of NT threads:
+// group g decomposes its polynomial of the accumulator (b for g < l, a otherwise -- every group keeps its own copy of
+// that polynomial in registers), transforms digit g, multiplies by key row g (:63-68).  The 2l products meet in LDS and
+// are summed IN THE REFERENCE'S ORDER (g = 0 .. 2l-1, starting from 0) by every group that needs the sum -- the l
+// groups of polynomial b sum the b-components, the others the a-components -- so every rounding is the reference's.
+// Each group then multiplies by the monomial, runs the inverse transform of its polynomial (redundantly within the l
+// groups of one polynomial: latency, not throughput, is the point) and updates its copy (:71-73).
+// LDS: Psi | region[2l][M]: FFT staging of group g (one buffer: barriers on both sides of an exchange), reused for the
+// product exchange between the forward and the inverse transforms.  Keys are read in the resident (LOGR = 2) device
+// point order whatever LR this kernel uses.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int dev_pos_lr2(int x, int M) { const int NT2 = M >> 2; return ((x & 3) >> 1) * (2 * NT2) + ((x >> 2) << 1) + (x & 1); }
+
+template <int LOGM, typename WORD, int LR, int LT>
+__global__ __launch_bounds__((2 * LT * Plan<LOGM, LR>::NT)) void blindrotate_wide_kernel(const RotArgs a) {
+    using P = Plan<LOGM, LR, 1>;
+    constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W, G = 2 * LT;
+    constexpr int MO = 0x1ff;                 // library-default exchange routes, single staging buffer
+    static_assert(MKT_LOGR == 2, "the resident tables are in the LOGR = 2 device point order");
+    cplx *psi_l = reinterpret_cast<cplx *>(mkt_smem);
+    cplx *region = psi_l + M;
+    const int tid = threadIdx.x, grp = tid / NT, t = tid % NT;
+    const int c = grp >= LT ? 1 : 0, j = c ? grp - LT : grp;
+    XS xs = make_xs();
+    for (int i = tid; i < M; i += G * NT) psi_l[i] = a.tw.psi[i];
+    __syncthreads();
+    const unsigned bid = blockIdx.x + a.block0;
+    const size_t gate = bid % (size_t)a.ngates;
+    const int slot = (int)(bid / (size_t)a.ngates);
+    const size_t rot = gate * (size_t)a.rows_per_gate + slot;
+    const int party = __builtin_amdgcn_readfirstlane(a.slot_party[slot]), row = __builtin_amdgcn_readfirstlane(a.slot_row[slot]);
+    const uint32_t *at_src = a.lwe + gate * (size_t)a.lwe_stride + (size_t)party * a.n;
+    const cplx *brk = a.brk + (size_t)party * a.brk_party_stride;
+    const Gadget<WORD> gd(LT, a.logB);
+    cplx *stage = region + (size_t)grp * M;
+
+    cplx rt[R], ri[R];
+    int kp[R];                                // resident-table position of the point slot e holds after a forward transform
+#pragma unroll
+    for (int e = 0; e < R; e++) { rt[e] = a.tw.roots[e * NT + t]; ri[e] = a.tw.rootsinv[e * NT + t]; kp[e] = dev_pos_lr2(t * R + e, M); }
+
+    WORD acc[R][2];                           // this group's polynomial (c) of the accumulator
+    if (a.init_mode == 0) {
+        const WORD *src = reinterpret_cast<const WORD *>(a.acc_io) + rot * 2 * N + (size_t)c * N;
+#pragma unroll
+        for (int e = 0; e < R; e++) { acc[e][0] = src[e * NT + t]; acc[e][1] = src[M + e * NT + t]; }
+    } else {                                  // bootstrapping.jl:403-406
+#pragma unroll
+        for (int e = 0; e < R; e++) { acc[e][0] = 0; acc[e][1] = 0; }
+        if (c == 0 && t == 0) acc[0][0] = (WORD)1 << (W - (row + 1) * a.logB_lev);
+    }
+
+    const int msbit = 32 - a.logN - 1;
+    for (int blk = 0; blk < a.n; blk++) {
+        const uint32_t v0 = at_src[blk];
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+        if (at == 0) continue;                                           // :48 / :413 (uniform over the workgroup)
+        cplx z[1][R];
+#pragma unroll
+        for (int e = 0; e < R; e++) {                                    // :50-51 decompto!, fft.jl:57-63
+            const int d0 = gd.digit(gd.prep(acc[e][0]), j), d1 = gd.digit(gd.prep(acc[e][1]), j);
+            cplx v; v.re = (double)d0; v.im = (double)(-d1);
+            z[0][e] = cmul(v, rt[e]);
+        }
+        fft_forward<LOGM, LR, 1, MO>(z, psi_l, stage, t, xs.lx);         // :54-59
+        const cplx *krow = brk + (((size_t)blk * G + (size_t)grp) * 2) * M;
+        cplx pb[R], pa[R], ts[R];
+#pragma unroll
+        for (int e = 0; e < R; e++) { pb[e] = cmul(z[0][e], krow[kp[e]]); pa[e] = cmul(z[0][e], krow[M + kp[e]]); }
+        const cplx *mono = a.monomial + (size_t)(at - 1) * M;
+        cplx mv[R];
+#pragma unroll
+        for (int e = 0; e < R; e++) mv[e] = mono[kp[e]];
+#pragma unroll
+        for (int ph = 0; ph < 2; ph++) {                                 // :63-68: sum over the rows, reference order
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < R; e++) stage[e * NT + t] = ph ? pa[e] : pb[e];
+            __syncthreads();
+            if (c == ph) {
+#pragma unroll
+                for (int e = 0; e < R; e++) { ts[e].re = 0.0; ts[e].im = 0.0; }
+#pragma unroll
+                for (int g = 0; g < G; g++)
+#pragma unroll
+                    for (int e = 0; e < R; e++) ts[e] = cadd(ts[e], region[(size_t)g * M + e * NT + t]);
+            }
+        }
+        cplx s[1][R];
+#pragma unroll
+        for (int e = 0; e < R; e++) s[0][e] = cmul(mv[e], ts[e]);        // :71
+        fft_inverse<LOGM, LR, 1, true, MO>(s, psi_l, stage, t, xs.lx);   // :72 (the first exchange's leading barrier also fences the product reads)
+#pragma unroll
+        for (int e = 0; e < R; e++) {                                    // fft.jl:76-80, :73
+            const cplx v = cmul(s[0][e], ri[e]);
+            acc[e][0] = (WORD)(acc[e][0] + native<WORD>(v.re));
+            acc[e][1] = (WORD)(acc[e][1] + native<WORD>(-v.im));
+        }
+    }
+
+    if (a.out_mode == 0) {
+        if (j == 0) {
+            WORD *dst = reinterpret_cast<WORD *>(a.acc_io) + rot * 2 * N + (size_t)c * N;
+#pragma unroll
+            for (int e = 0; e < R; e++) { dst[e * NT + t] = acc[e][0]; dst[M + e * NT + t] = acc[e][1]; }
+        }
+    } else {                                                             // :441 fftto!(tacc, acc); every group runs it (barriers), one per polynomial stores
+        cplx z[1][R];
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            cplx v; v.re = word_to_f64<WORD>(acc[e][0]); v.im = word_to_f64<WORD>((WORD)((WORD)0 - acc[e][1]));
+            z[0][e] = cmul(v, rt[e]);
+        }
+        fft_forward<LOGM, LR, 1, MO>(z, psi_l, stage, t, xs.lx);
+        if (j == 0) {
+            cplx *o = a.tout + (rot * 2 + c) * M;
+#pragma unroll
+            for (int e = 0; e < R; e++) o[a.tout_natural ? t * R + e : kp[e]] = z[0][e];
+        }
+    }
+}
+
+template <int LM, typename WORD, int LR, int LT>
+static hipError_t launch_wide_one(const RotArgs &a, size_t nrot, hipStream_t s) {
+    using P = Plan<LM, LR, 1>;
+    constexpr int threads = 2 * LT * P::NT;
+    static_assert(threads <= 1024, "workgroup too large");
+    const size_t lds_bytes = (size_t)(1 + 2 * LT) * P::M * sizeof(cplx);
+    hipError_t e = set_lds(blindrotate_wide_kernel<LM, WORD, LR, LT>, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((blindrotate_wide_kernel<LM, WORD, LR, LT>), dim3((unsigned)nrot), dim3(threads), lds_bytes, s, a);
+    return hipGetLastError();
+}
+template <int LM, typename WORD>
+static hipError_t launch_wide_lm(const RotArgs &a, size_t nrot, hipStream_t s) {
+    // points per thread chosen so that 2l groups fit one workgroup: 4 up to M = 512, 8 at M = 1024
+    constexpr int LR = LM >= 10 ? 3 : 2;
+    switch (a.l) {
+    case 2: return launch_wide_one<LM, WORD, LR, 2>(a, nrot, s);
+    case 3: return launch_wide_one<LM, WORD, LR, 3>(a, nrot, s);
+    case 4: return launch_wide_one<LM, WORD, LR, 4>(a, nrot, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+bool wide_supported(int logM, int l, int blk_len) { return blk_len == 1 && logM >= 8 && logM <= 10 && l >= 2 && l <= 4; }
+hipError_t launch_blindrotate_wide(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s) {
+    if (!nrot) return hipSuccess;
+    switch (logM) {
+    case 8:  return W == 64 ? launch_wide_lm<8, uint64_t>(a, nrot, s) : launch_wide_lm<8, uint32_t>(a, nrot, s);
+    case 9:  return W == 64 ? launch_wide_lm<9, uint64_t>(a, nrot, s) : launch_wide_lm<9, uint32_t>(a, nrot, s);
+    case 10: return W == 64 ? launch_wide_lm<10, uint64_t>(a, nrot, s) : launch_wide_lm<10, uint32_t>(a, nrot, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+#endif  // TU 6
 
 }  // namespace mktd

@@ -699,3 +699,50 @@ def test_bench_multi_rank_launch_on_a_shared_gpu(require_gpu):
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["decrypt_errors"] == 0
     assert abs(j["value"] - 2 * 128 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
     assert j["roofline"]["kernel"] == "blindrotate_k1_kernel" and 0 < j["roofline"]["frac"] < 1
+
+
+WIDE_SETS = [
+    mk.CGGIparam.scaled(n=24, N=512), mk.CGGIparam.scaled(n=20, N=1024), mk.CGGI_N1024_l2.scaled(n=16), mk.CGGIparam.scaled(n=10, N=2048),
+    mk.CGGIparam.scaled(n=12, N=1024, l_gsw=4, logB_gsw=7),
+    mk.KMS2party_N1024_l2.scaled(n=12), mk.KMS2party.scaled(n=10), mk.KMS2party.scaled(n=10, N=512), mk.KMS8party.scaled(n=3, N=1024, k=3),
+]
+
+
+@pytest.mark.parametrize("p", WIDE_SETS, ids=lambda p: f"{p.name}-n{p.n}-N{p.N}")
+def test_latency_variant_of_the_rotation_is_bit_identical(require_gpu, p, monkeypatch):
+    """Small batches run the blind rotation on the latency variant (one rotation spread over 2l thread groups, products
+    summed through LDS in the reference's order, bootstrapping.jl:63-68).  Forced on (MKT_ROT_WIDE=2) and off (=1):
+    accumulators, KMS phase-1 transforms (raw f64 bits) and gate outputs equal the oracle and each other, including
+    skipped (zero) and full-turn (2N) mask words."""
+    crs, keys = keygen(p, 31)
+    so = oracle_scheme(p, crs, keys)
+    sg = gpu_scheme(p, crs, keys)
+    B = 5
+    rng = np.random.default_rng(32)
+    bits = rng.integers(0, 2, 2 * B).astype(bool)
+    c = encrypt_bits(p, keys, bits, seed=3200)
+    x, y = c[:B], c[B:]
+    lin = np.stack([O.gate_linear(0, x[j], y[j]) for j in range(B)])
+    at, bt = sg.modswitch(lin)
+    at[0, :3] = [0, 2 * p.N, p.N]; at[1, :] = 0; at[2, ::2] = 0
+    acc0 = np.stack([so.testvector(bt[j]) for j in range(B)])
+    acc_o = np.stack([so.blindrotate(at[j], acc0[j]) for j in range(B)])
+    res = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("MKT_ROT_WIDE", mode)
+        acc_g = sg.blindrotate_(at, acc0.astype(p.ring_dtype).copy())
+        assert np.array_equal(acc_g.astype(np.uint64), acc_o), f"blindrotate, MKT_ROT_WIDE={mode}"
+        lev = sg.kms_phase1(at) if p.scheme == mk.KMS else None
+        out = np.stack([sg.gate(op, x, y) for op in (0, 3, 5)])
+        res[mode] = (lev, out)
+        for i, op in enumerate((0, 3, 5)):
+            assert np.array_equal(out[i], np.stack([so.gate(op, x[j], y[j]) for j in range(B)])), f"gate {op}, MKT_ROT_WIDE={mode}"
+            assert np.array_equal(mk.lwe_decrypt(out[i], keys if p.multikey else keys[0], p), GATE_FUNCS[op](bits[:B], bits[B:]))
+    if res["1"][0] is not None:
+        assert bits_equal(res["1"][0], res["2"][0])
+        row = 0
+        for party in range(p.k):
+            lev_o = so.kms_phase1(party, at[3, party * p.n:(party + 1) * p.n])
+            assert bits_equal(res["2"][0][3, row:row + lev_o.shape[0]], lev_o)
+            row += lev_o.shape[0]
+    sg.close()
