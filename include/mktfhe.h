@@ -91,9 +91,14 @@ typedef struct mkt_client_party mkt_client_party;   /* one party's keys (client 
 int mkt_abi_version(void);
 int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx **out);
 int mkt_ctx_destroy(mkt_ctx *ctx);
+/* a second context over the SAME resident keys and tables (no copy; freed with the last context that holds them): own
+ * stream, workspace and timing -- one per concurrent caller, matching the reference's contract of one read-only scheme
+ * shared by concurrent bootstrapping! calls (bootstrapping.jl:38-45: all scratch is per call).  Once forked, the key set
+ * is immutable: mkt_load_*, mkt_set_twiddles and mkt_keygen_device return MKT_ERR_STATE on every sharer. */
+int mkt_ctx_fork(mkt_ctx *ctx, mkt_ctx **out);
 const char *mkt_last_error(const mkt_ctx *ctx); /* ctx may be NULL: last creation error */
 /* HIP stream (hipStream_t) all subsequent batch calls are enqueued on; NULL = default stream.  The per-batch workspace
- * belongs to the context: calls on one context must not overlap (one context per host thread / stream). */
+ * belongs to the context: calls on one context must not overlap (one context per host thread / stream: mkt_ctx_fork). */
 int mkt_set_stream(mkt_ctx *ctx, void *hip_stream);
 int mkt_synchronize(mkt_ctx *ctx);
 

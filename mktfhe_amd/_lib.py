@@ -31,6 +31,7 @@ SYMBOLS = {
     "mkt_abi_version": (_i, []),
     "mkt_ctx_create": (_i, [_pp, _i, _i, C.POINTER(_vp)]),
     "mkt_ctx_destroy": (_i, [_vp]),
+    "mkt_ctx_fork": (_i, [_vp, C.POINTER(_vp)]),
     "mkt_last_error": (C.c_char_p, [_vp]),
     "mkt_set_stream": (_i, [_vp, _vp]),
     "mkt_synchronize": (_i, [_vp]),

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -21,18 +22,15 @@ thread_local std::string g_create_error;
 struct TimedSpan { int cls; hipEvent_t a, b; };
 }  // namespace
 
-struct mkt_ctx {
-    mkt_params p;
-    mkt::Shape sh;
+// The evaluation keys and tables of one scheme on one device: immutable once a second context shares them
+// (mkt_ctx_fork), freed when the last context that holds them is destroyed.  This is the reference's scheme object
+// proper -- read-only during evaluation, shared by concurrent callers (bootstrapping.jl:38-45 allocates all scratch per
+// call) -- while mkt_ctx adds what a caller must not share: stream, workspace, timing spans, error string.
+struct KeySet {
     int device = 0;
-    int logM = 0, logN = 0, M = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
     mkt::Twiddles tw;
-    // device tables
     cplx *d_tw = nullptr;        // psi | psiinv | roots | rootsinv, M each
     cplx *d_monomial = nullptr;  // [2N][M]
-    // keys
     cplx *d_brk = nullptr;  size_t brk_party_cplx = 0;  std::vector<char> brk_loaded;
     uint32_t *d_ksk = nullptr; size_t ksk_party_words = 0; int n1p = 0; std::vector<char> ksk_loaded;
     cplx *d_rlk_d = nullptr, *d_rlk_f = nullptr, *d_pub = nullptr, *d_crs = nullptr;
@@ -40,6 +38,24 @@ struct mkt_ctx {
     // rotation slots (KMS phase 1: party-major rows)
     int rtot = 1;
     int *d_slot_party = nullptr, *d_slot_row = nullptr;
+    ~KeySet() {
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) (void)hipSetDevice(device);
+        void *ptrs[] = {d_tw, d_monomial, d_brk, d_ksk, d_rlk_d, d_rlk_f, d_pub, d_crs, d_slot_party, d_slot_row};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    }
+};
+
+struct mkt_ctx {
+    mkt_params p;
+    mkt::Shape sh;
+    int device = 0;
+    int logM = 0, logN = 0, M = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::shared_ptr<KeySet> ks;  // shared with the contexts forked from this one
     // workspace
     size_t ws_gates = 0;
     uint32_t *ws_lin = nullptr;
@@ -49,7 +65,8 @@ struct mkt_ctx {
     bool timing = false;
     std::vector<TimedSpan> spans;
 
-    mktd::TwPtrs twp() const { return mktd::TwPtrs{d_tw, d_tw + M, d_tw + 2 * (size_t)M, d_tw + 3 * (size_t)M}; }
+    mktd::TwPtrs twp() const { return mktd::TwPtrs{ks->d_tw, ks->d_tw + M, ks->d_tw + 2 * (size_t)M, ks->d_tw + 3 * (size_t)M}; }
+    bool keys_shared() const { return ks.use_count() > 1; }
 };
 
 namespace {
@@ -118,19 +135,19 @@ int build_monomial(mkt_ctx *c) {   // scheme.jl:121-146
     for (int e = 1; e < N; e++) { set(e, 0, m1); set(e, e, 1); }            // -1 + X^e
     set(N, 0, m1 - 1);                                                       // -2
     for (int e = N + 1; e < 2 * N; e++) { set(e, 0, m1); set(e, e - N, m1); } // -1 - X^(e-N)
-    int r = upload_polys(c, host.data(), (size_t)2 * N, c->d_monomial, MKT_FMT_INT_COEFF);
+    int r = upload_polys(c, host.data(), (size_t)2 * N, c->ks->d_monomial, MKT_FMT_INT_COEFF);
     if (r) return r;
-    HIPCHK(c, hipMemsetAsync(c->d_monomial + (size_t)(2 * N - 1) * c->M, 0, (size_t)c->M * sizeof(cplx), c->stream));  // entry 2N = 0
+    HIPCHK(c, hipMemsetAsync(c->ks->d_monomial + (size_t)(2 * N - 1) * c->M, 0, (size_t)c->M * sizeof(cplx), c->stream));  // entry 2N = 0
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MKT_OK;
 }
 
 int upload_twiddles(mkt_ctx *c) {
     const size_t tb = (size_t)c->M * sizeof(cplx);
-    HIPCHK(c, hipMemcpy(c->d_tw, c->tw.psi.data(), tb, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_tw + c->M, c->tw.psiinv.data(), tb, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_tw + 2 * (size_t)c->M, c->tw.roots.data(), tb, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_tw + 3 * (size_t)c->M, c->tw.rootsinv.data(), tb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->ks->d_tw, c->ks->tw.psi.data(), tb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->ks->d_tw + c->M, c->ks->tw.psiinv.data(), tb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->ks->d_tw + 2 * (size_t)c->M, c->ks->tw.roots.data(), tb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->ks->d_tw + 3 * (size_t)c->M, c->ks->tw.rootsinv.data(), tb, hipMemcpyHostToDevice));
     return MKT_OK;
 }
 
@@ -145,7 +162,7 @@ int ensure_workspace(mkt_ctx *c, size_t gates) {
     HIPCHK(c, hipMalloc((void **)&c->ws_lin, gates * (size_t)c->sh.lwe_len * 4));
     HIPCHK(c, hipMalloc(&c->ws_acc, gates * (size_t)(1 + c->sh.kacc) * poly_bytes(c)));
     if (mkt::is_kms(p.scheme)) {
-        HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * (size_t)c->rtot * 2 * c->M * sizeof(cplx)));
+        HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * (size_t)c->ks->rtot * 2 * c->M * sizeof(cplx)));
         HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)2 * (p.k + 1) * c->M * sizeof(cplx)));
     } else if (p.scheme == MKT_CCS) {
         HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * poly_bytes(c)));    // v scratch (ring words)
@@ -159,12 +176,12 @@ constexpr size_t CHUNK_GATES = 8192;   // bounds the workspace (KMS N=2048, k=2:
 
 int check_ready(mkt_ctx *c, bool need_brk, bool need_ksk) {
     for (int i = 0; i < c->sh.nparty; i++) {
-        if (need_brk && !c->brk_loaded[i]) return fail(c, MKT_ERR_STATE, "bootstrapping key not loaded");
-        if (need_ksk && !c->ksk_loaded[i]) return fail(c, MKT_ERR_STATE, "key-switching key not loaded");
-        if (need_brk && c->p.scheme == MKT_CCS && !c->pub_loaded[i]) return fail(c, MKT_ERR_STATE, "public key not loaded");
-        if (need_brk && mkt::is_kms(c->p.scheme) && (!c->rlk_loaded[i] || !c->pub_loaded[i])) return fail(c, MKT_ERR_STATE, "rlk / public key not loaded");
+        if (need_brk && !c->ks->brk_loaded[i]) return fail(c, MKT_ERR_STATE, "bootstrapping key not loaded");
+        if (need_ksk && !c->ks->ksk_loaded[i]) return fail(c, MKT_ERR_STATE, "key-switching key not loaded");
+        if (need_brk && c->p.scheme == MKT_CCS && !c->ks->pub_loaded[i]) return fail(c, MKT_ERR_STATE, "public key not loaded");
+        if (need_brk && mkt::is_kms(c->p.scheme) && (!c->ks->rlk_loaded[i] || !c->ks->pub_loaded[i])) return fail(c, MKT_ERR_STATE, "rlk / public key not loaded");
     }
-    if (need_brk && mkt::is_mk(c->p.scheme) && !c->crs_loaded) return fail(c, MKT_ERR_STATE, "crs not loaded");
+    if (need_brk && mkt::is_mk(c->p.scheme) && !c->ks->crs_loaded) return fail(c, MKT_ERR_STATE, "crs not loaded");
     return MKT_OK;
 }
 
@@ -176,12 +193,12 @@ int unsupported_scheme(mkt_ctx *c) {
 mktd::RotArgs rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
     const mkt_params &p = c->p;
     mktd::RotArgs a{};
-    a.tw = c->twp(); a.brk = c->d_brk; a.brk_party_stride = c->brk_party_cplx; a.monomial = c->d_monomial;
+    a.tw = c->twp(); a.brk = c->ks->d_brk; a.brk_party_stride = c->ks->brk_party_cplx; a.monomial = c->ks->d_monomial;
     a.lwe = lwe; a.lwe_stride = stride; a.pre_switched = pre; a.n = p.n; a.logN = c->logN;
     a.l = p.l_gsw; a.logB = p.logB_gsw;
     a.blk_len = mkt::is_block(p.scheme) ? p.blk_len : 1;
     a.blk_accum = mkt::is_block(p.scheme) ? 1 : 0;
-    a.rows_per_gate = c->rtot; a.slot_party = c->d_slot_party; a.slot_row = c->d_slot_row;
+    a.rows_per_gate = c->ks->rtot; a.slot_party = c->ks->d_slot_party; a.slot_row = c->ks->d_slot_row;
     a.logB_lev = p.logB_lev;
     if (const char *v = getenv("MKT_ROT_VARIANT")) a.variant = atoi(v);
     a.stagger = 16;   // tools/stagger.sh: 16.99 -> 15.63 ms at KMS k=2 N=1024 on one device, neutral elsewhere
@@ -197,8 +214,8 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
     if (p.scheme == MKT_CCS) {
         mktd::CcsArgs q{};
         q.tw = c->twp(); q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.logN = c->logN; q.k = p.k;
-        q.l = p.l_uni; q.logB = p.logB_uni; q.brk = c->d_brk; q.brk_party_stride = c->brk_party_cplx; q.pub_b = c->d_pub; q.crs = c->d_crs;
-        q.monomial = c->d_monomial; q.acc = acc; q.scratch = scratch; q.vscratch = lev;
+        q.l = p.l_uni; q.logB = p.logB_uni; q.brk = c->ks->d_brk; q.brk_party_stride = c->ks->brk_party_cplx; q.pub_b = c->ks->d_pub; q.crs = c->ks->d_crs;
+        q.monomial = c->ks->d_monomial; q.acc = acc; q.scratch = scratch; q.vscratch = lev;
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_ccs_blindrotate(c->logM, p.W, q, B, c->stream));
         return MKT_OK;
@@ -219,12 +236,12 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         mktd::RotArgs a = rot_args(c, lwe, stride, pre);
         a.init_mode = 1; a.out_mode = 1; a.tout = lev; a.tout_natural = 0; a.ngates = B;
         Timer tm(c, 1);
-        HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, p.W, a, B * (size_t)c->rtot, c->stream));
+        HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, p.W, a, B * (size_t)c->ks->rtot, c->stream));
     }
     mktd::Phase2Args q{};
     q.tw = c->twp(); q.lin = lin_for_tv; q.lwe_stride = c->sh.lwe_len; q.logN = c->logN;
     q.k = p.k; q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni;
-    q.levkey = lev; q.rtot = c->rtot; q.rlk_d = c->d_rlk_d; q.rlk_f = c->d_rlk_f; q.pub_b = c->d_pub; q.crs = c->d_crs;
+    q.levkey = lev; q.rtot = c->ks->rtot; q.rlk_d = c->ks->d_rlk_d; q.rlk_f = c->ks->d_rlk_f; q.pub_b = c->ks->d_pub; q.crs = c->ks->d_crs;
     q.acc = acc; q.scratch = scratch;
     Timer tm(c, 4);
     HIPCHK(c, mktd::launch_kms_phase2(c->logM, p.W, q, B, c->stream));
@@ -234,7 +251,7 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
 int do_keyswitch(mkt_ctx *c, const void *acc, uint32_t *out, size_t B) {
     const mkt_params &p = c->p;
     mktd::KsArgs a{};
-    a.acc = acc; a.out = out; a.ksk = c->d_ksk; a.ksk_party_stride = c->ksk_party_words; a.n1p = c->n1p;
+    a.acc = acc; a.out = out; a.ksk = c->ks->d_ksk; a.ksk_party_stride = c->ks->ksk_party_words; a.n1p = c->ks->n1p;
     a.N = p.N; a.n = p.n; a.f = p.f; a.logD = p.logD; a.drows = c->sh.ksk_drows; a.kacc = c->sh.kacc;
     a.mk = mkt::is_mk(p.scheme) ? 1 : 0; a.balanced = mkt::is_block(p.scheme) ? 1 : 0; a.lmss = p.scheme == MKT_LMSS ? 1 : 0;
     Timer tm(c, 2);
@@ -306,6 +323,8 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
         return fail(nullptr, MKT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", the engine is built for gfx950 only");
 
     auto *c = new mkt_ctx();
+    c->ks = std::make_shared<KeySet>();
+    c->ks->device = device;
     c->p = *params; c->sh = mkt::shape_of(*params); c->device = device;
     c->logN = logN; c->logM = logN - 1; c->M = params->N / 2;
     DevGuard dg(device);
@@ -313,34 +332,34 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     if (!dg.ok) { c->err = "hipSetDevice failed"; return bail(MKT_ERR_HIP); }
     const mkt_params &p = c->p;
     const int np = c->sh.nparty, N = p.N, M = c->M;
-    c->brk_loaded.assign(np, 0); c->ksk_loaded.assign(np, 0); c->rlk_loaded.assign(np, 0); c->pub_loaded.assign(np, 0);
-    mkt::make_twiddles(N, c->tw);
+    c->ks->brk_loaded.assign(np, 0); c->ks->ksk_loaded.assign(np, 0); c->ks->rlk_loaded.assign(np, 0); c->ks->pub_loaded.assign(np, 0);
+    mkt::make_twiddles(N, c->ks->tw);
 #define CK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(_e); return bail(_e == hipErrorOutOfMemory ? MKT_ERR_NOMEM : MKT_ERR_HIP); } } while (0)
-    CK(hipMalloc((void **)&c->d_tw, (size_t)4 * M * sizeof(cplx)));
-    CK(hipMalloc((void **)&c->d_monomial, (size_t)2 * N * M * sizeof(cplx)));
-    c->brk_party_cplx = (size_t)p.n * c->sh.brk_polys * M;
-    CK(hipMalloc((void **)&c->d_brk, (size_t)np * c->brk_party_cplx * sizeof(cplx)));
-    c->n1p = (p.n + 1 + 3) / 4 * 4;   // device rows padded to 16 B
-    c->ksk_party_words = (size_t)c->sh.ksk_kr * N * c->sh.ksk_drows * p.f * c->n1p;
-    CK(hipMalloc((void **)&c->d_ksk, (size_t)np * c->ksk_party_words * sizeof(uint32_t)));
+    CK(hipMalloc((void **)&c->ks->d_tw, (size_t)4 * M * sizeof(cplx)));
+    CK(hipMalloc((void **)&c->ks->d_monomial, (size_t)2 * N * M * sizeof(cplx)));
+    c->ks->brk_party_cplx = (size_t)p.n * c->sh.brk_polys * M;
+    CK(hipMalloc((void **)&c->ks->d_brk, (size_t)np * c->ks->brk_party_cplx * sizeof(cplx)));
+    c->ks->n1p = (p.n + 1 + 3) / 4 * 4;   // device rows padded to 16 B
+    c->ks->ksk_party_words = (size_t)c->sh.ksk_kr * N * c->sh.ksk_drows * p.f * c->ks->n1p;
+    CK(hipMalloc((void **)&c->ks->d_ksk, (size_t)np * c->ks->ksk_party_words * sizeof(uint32_t)));
     if (mkt::is_mk(p.scheme)) {
-        CK(hipMalloc((void **)&c->d_pub, (size_t)np * p.l_uni * M * sizeof(cplx)));
-        CK(hipMalloc((void **)&c->d_crs, (size_t)p.l_uni * M * sizeof(cplx)));
+        CK(hipMalloc((void **)&c->ks->d_pub, (size_t)np * p.l_uni * M * sizeof(cplx)));
+        CK(hipMalloc((void **)&c->ks->d_crs, (size_t)p.l_uni * M * sizeof(cplx)));
     }
     if (mkt::is_kms(p.scheme)) {
-        CK(hipMalloc((void **)&c->d_rlk_d, (size_t)np * p.l_uni * M * sizeof(cplx)));
-        CK(hipMalloc((void **)&c->d_rlk_f, (size_t)np * p.l_uni * 2 * M * sizeof(cplx)));
+        CK(hipMalloc((void **)&c->ks->d_rlk_d, (size_t)np * p.l_uni * M * sizeof(cplx)));
+        CK(hipMalloc((void **)&c->ks->d_rlk_f, (size_t)np * p.l_uni * 2 * M * sizeof(cplx)));
     }
     // rotation slots: KMS phase 1 runs 1 row for party 0 and l_lev rows for the others (bootstrapping.jl:400)
     std::vector<int> sp, sr;
     if (mkt::is_kms(p.scheme)) {
         for (int i = 0; i < p.k; i++) { int rows = i == 0 ? 1 : p.l_lev; for (int r = 0; r < rows; r++) { sp.push_back(i); sr.push_back(r); } }
     } else { sp.push_back(0); sr.push_back(0); }
-    c->rtot = (int)sp.size();
-    CK(hipMalloc((void **)&c->d_slot_party, sp.size() * sizeof(int)));
-    CK(hipMalloc((void **)&c->d_slot_row, sr.size() * sizeof(int)));
-    CK(hipMemcpy(c->d_slot_party, sp.data(), sp.size() * sizeof(int), hipMemcpyHostToDevice));
-    CK(hipMemcpy(c->d_slot_row, sr.data(), sr.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->ks->rtot = (int)sp.size();
+    CK(hipMalloc((void **)&c->ks->d_slot_party, sp.size() * sizeof(int)));
+    CK(hipMalloc((void **)&c->ks->d_slot_row, sr.size() * sizeof(int)));
+    CK(hipMemcpy(c->ks->d_slot_party, sp.data(), sp.size() * sizeof(int), hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->ks->d_slot_row, sr.data(), sr.size() * sizeof(int), hipMemcpyHostToDevice));
 #undef CK
     int r = upload_twiddles(c);
     if (!r) r = build_monomial(c);
@@ -352,12 +371,24 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
 int mkt_ctx_destroy(mkt_ctx *c) {
     if (!c) return MKT_OK;
     DevGuard dg(c->device);
-    (void)hipDeviceSynchronize();
+    (void)hipStreamSynchronize(c->stream);
     clear_spans(c);
-    void *ptrs[] = {c->d_tw, c->d_monomial, c->d_brk, c->d_ksk, c->d_rlk_d, c->d_rlk_f, c->d_pub, c->d_crs,
-                    c->d_slot_party, c->d_slot_row, c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch};
+    void *ptrs[] = {c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    delete c;
+    delete c;                      // drops this context's reference to the key set; the last one frees it
+    return MKT_OK;
+}
+
+// A second context over the SAME resident keys and tables (no copy): own stream, own workspace, own timing -- one per
+// concurrent caller / host thread / stream, as the reference's read-only scheme object is shared by concurrent
+// bootstrapping! calls.  From the first fork on the key set is immutable (mkt_load_*, mkt_set_twiddles,
+// mkt_keygen_device return MKT_ERR_STATE on every context that shares it).
+int mkt_ctx_fork(mkt_ctx *c, mkt_ctx **out) {
+    if (!c || !out) return fail(c, MKT_ERR_ARG, "null argument");
+    auto *f = new mkt_ctx();
+    f->p = c->p; f->sh = c->sh; f->device = c->device; f->logM = c->logM; f->logN = c->logN; f->M = c->M;
+    f->ks = c->ks;
+    *out = f;
     return MKT_OK;
 }
 
@@ -374,12 +405,13 @@ int mkt_get_twiddles(mkt_ctx *c, int which, double *out_host) {
     if (!c || !out_host || which < 0 || which > 3) return fail(c, MKT_ERR_ARG, "bad argument");
     DevGuard dg(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out_host, c->d_tw + (size_t)which * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out_host, c->ks->d_tw + (size_t)which * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
     return MKT_OK;
 }
 
 int mkt_set_twiddles(mkt_ctx *c, const double *psi, const double *psiinv, const double *roots, const double *rootsinv) {
     if (!c || !psi || !psiinv || !roots || !rootsinv) return fail(c, MKT_ERR_ARG, "null table");
+    if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     const size_t nd = (size_t)2 * c->M;
     // the kernels derive the inverse twiddles from the forward table: Psiinv must be conj(Psi) entry for entry,
@@ -387,8 +419,8 @@ int mkt_set_twiddles(mkt_ctx *c, const double *psi, const double *psiinv, const 
     for (int i = 1; i < c->M; i++)
         if (std::memcmp(&psi[2 * i], &psiinv[2 * i], 8) != 0 || psiinv[2 * i + 1] != -psi[2 * i + 1])
             return fail(c, MKT_ERR_ARG, "mkt_set_twiddles: Psiinv is not the conjugate of Psi");
-    c->tw.psi.assign(psi, psi + nd); c->tw.psiinv.assign(psiinv, psiinv + nd);
-    c->tw.roots.assign(roots, roots + nd); c->tw.rootsinv.assign(rootsinv, rootsinv + nd);
+    c->ks->tw.psi.assign(psi, psi + nd); c->ks->tw.psiinv.assign(psiinv, psiinv + nd);
+    c->ks->tw.roots.assign(roots, roots + nd); c->ks->tw.rootsinv.assign(rootsinv, rootsinv + nd);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int r = upload_twiddles(c);
     if (r) return r;
@@ -400,7 +432,7 @@ int mkt_get_monomial(mkt_ctx *c, int e, double *out_host) {
     DevGuard dg(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<cplx> dev((size_t)c->M);
-    HIPCHK(c, hipMemcpy(dev.data(), c->d_monomial + (size_t)(e - 1) * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dev.data(), c->ks->d_monomial + (size_t)(e - 1) * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
     const int NT = c->M >> MKT_LOGR;              // device order -> the reference's order
     cplx *o = reinterpret_cast<cplx *>(out_host);
     for (int x = 0; x < c->M; x++) o[x] = dev[(size_t)mktd::dev_pos(x, NT)];
@@ -409,45 +441,50 @@ int mkt_get_monomial(mkt_ctx *c, int e, double *out_host) {
 
 int mkt_load_brk(mkt_ctx *c, int party, const void *data, int fmt) {
     if (!c || !data || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
-    int r = upload_polys(c, data, (size_t)c->p.n * c->sh.brk_polys, c->d_brk + (size_t)party * c->brk_party_cplx, fmt);
-    if (!r) c->brk_loaded[party] = 1;
+    int r = upload_polys(c, data, (size_t)c->p.n * c->sh.brk_polys, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, fmt);
+    if (!r) c->ks->brk_loaded[party] = 1;
     return r;
 }
 
 int mkt_load_ksk(mkt_ctx *c, int party, const uint32_t *data) {
     if (!c || !data || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     const size_t rows = (size_t)c->sh.ksk_kr * c->p.N * c->sh.ksk_drows * c->p.f, n1 = (size_t)c->p.n + 1;
-    HIPCHK(c, hipMemset(c->d_ksk + (size_t)party * c->ksk_party_words, 0, c->ksk_party_words * sizeof(uint32_t)));
-    HIPCHK(c, hipMemcpy2D(c->d_ksk + (size_t)party * c->ksk_party_words, (size_t)c->n1p * 4, data, n1 * 4, n1 * 4, rows, hipMemcpyHostToDevice));
-    c->ksk_loaded[party] = 1;
+    HIPCHK(c, hipMemset(c->ks->d_ksk + (size_t)party * c->ks->ksk_party_words, 0, c->ks->ksk_party_words * sizeof(uint32_t)));
+    HIPCHK(c, hipMemcpy2D(c->ks->d_ksk + (size_t)party * c->ks->ksk_party_words, (size_t)c->ks->n1p * 4, data, n1 * 4, n1 * 4, rows, hipMemcpyHostToDevice));
+    c->ks->ksk_loaded[party] = 1;
     return MKT_OK;
 }
 
 int mkt_load_rlk(mkt_ctx *c, int party, const void *d, const void *f, int fmt) {
     if (!c || !d || !f || party < 0 || party >= c->sh.nparty || !mkt::is_kms(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     const size_t l = (size_t)c->p.l_uni;
-    int r = upload_polys(c, d, l, c->d_rlk_d + (size_t)party * l * c->M, fmt);
-    if (!r) r = upload_polys(c, f, 2 * l, c->d_rlk_f + (size_t)party * 2 * l * c->M, fmt);
-    if (!r) c->rlk_loaded[party] = 1;
+    int r = upload_polys(c, d, l, c->ks->d_rlk_d + (size_t)party * l * c->M, fmt);
+    if (!r) r = upload_polys(c, f, 2 * l, c->ks->d_rlk_f + (size_t)party * 2 * l * c->M, fmt);
+    if (!r) c->ks->rlk_loaded[party] = 1;
     return r;
 }
 
 int mkt_load_pubkey(mkt_ctx *c, int party, const void *b, int fmt) {
     if (!c || !b || party < 0 || party >= c->sh.nparty || !mkt::is_mk(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
-    int r = upload_polys(c, b, (size_t)c->p.l_uni, c->d_pub + (size_t)party * c->p.l_uni * c->M, fmt);
-    if (!r) c->pub_loaded[party] = 1;
+    int r = upload_polys(c, b, (size_t)c->p.l_uni, c->ks->d_pub + (size_t)party * c->p.l_uni * c->M, fmt);
+    if (!r) c->ks->pub_loaded[party] = 1;
     return r;
 }
 
 int mkt_load_crs(mkt_ctx *c, const void *a, int fmt) {
     if (!c || !a || !mkt::is_mk(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
-    int r = upload_polys(c, a, (size_t)c->p.l_uni, c->d_crs, fmt);
-    if (!r) c->crs_loaded = true;
+    int r = upload_polys(c, a, (size_t)c->p.l_uni, c->ks->d_crs, fmt);
+    if (!r) c->ks->crs_loaded = true;
     return r;
 }
 
@@ -455,6 +492,7 @@ int mkt_load_crs(mkt_ctx *c, const void *a, int fmt) {
 // (keygen.hip: the seeded streams of mkt_client_party_keygen, identical words), pre-transformed in place of an upload.
 static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, const void *crs, void *brk_out, uint32_t *ksk_out) {
     if (!c || !K || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     const mkt_params &p = c->p;
     if (std::memcmp(&K->p, &p, sizeof(mkt_params)) != 0 || K->party != party) return fail(c, MKT_ERR_ARG, "mkt_keygen_device: the party's keys were made for other parameters / another party index");
     const bool unienc = p.scheme == MKT_CCS;
@@ -486,15 +524,15 @@ static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, 
     else { a.kr = c->sh.kr; a.l = p.l_gsw; a.logB = p.logB_gsw; a.zoff = 0; }
     e = mktd::launch_keygen_brk(a, unienc ? 1 : 0, c->stream);
     if (e == hipSuccess && brk_out) e = hipMemcpyAsync(brk_out, d_out, brk_polys_total * poly_bytes(c), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->d_brk + (size_t)party * c->brk_party_cplx, brk_polys_total, 1, c->stream);
-    uint32_t *ksk = c->d_ksk + (size_t)party * c->ksk_party_words;
-    if (e == hipSuccess) e = hipMemsetAsync(ksk, 0, c->ksk_party_words * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, brk_polys_total, 1, c->stream);
+    uint32_t *ksk = c->ks->d_ksk + (size_t)party * c->ks->ksk_party_words;
+    if (e == hipSuccess) e = hipMemsetAsync(ksk, 0, c->ks->ksk_party_words * sizeof(uint32_t), c->stream);
     a.zoff = mkt::is_kms(p.scheme) ? 1 : 0;      // the key switch targets the uni key of the KMS schemes
-    if (e == hipSuccess) e = mktd::launch_keygen_ksk(a, ksk, c->n1p, c->sh.ksk_kr, c->sh.ksk_drows, mkt::is_block(p.scheme) ? 1 : 0, c->stream);
+    if (e == hipSuccess) e = mktd::launch_keygen_ksk(a, ksk, c->ks->n1p, c->sh.ksk_kr, c->sh.ksk_drows, mkt::is_block(p.scheme) ? 1 : 0, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) return hipfail(c, e, "device keygen");
-    c->brk_loaded[party] = 1; c->ksk_loaded[party] = 1;
+    c->ks->brk_loaded[party] = 1; c->ks->ksk_loaded[party] = 1;
     if (ksk_out) return mkt_get_ksk(c, party, ksk_out);
     return MKT_OK;
 }
@@ -517,7 +555,7 @@ int mkt_get_ksk(mkt_ctx *c, int party, uint32_t *out_host) {
     DevGuard dg(c->device);
     const size_t rows = (size_t)c->sh.ksk_kr * c->p.N * c->sh.ksk_drows * c->p.f, n1 = (size_t)c->p.n + 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy2D(out_host, n1 * 4, c->d_ksk + (size_t)party * c->ksk_party_words, (size_t)c->n1p * 4, n1 * 4, rows, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy2D(out_host, n1 * 4, c->ks->d_ksk + (size_t)party * c->ks->ksk_party_words, (size_t)c->ks->n1p * 4, n1 * 4, rows, hipMemcpyDeviceToHost));
     return MKT_OK;
 }
 
@@ -605,12 +643,12 @@ int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, siz
     int r;
     if ((r = check_ready(c, true, false))) return r;
     DevGuard dg(c->device);
-    const size_t alen = (size_t)c->sh.lwe_len - 1, lb = (size_t)c->rtot * 2 * c->M * sizeof(cplx);
+    const size_t alen = (size_t)c->sh.lwe_len - 1, lb = (size_t)c->ks->rtot * 2 * c->M * sizeof(cplx);
     Staged sa{c}, sl{c};
     if ((r = sa.in(atilde, B * alen * 4, mem, true)) || (r = sl.in(levkey, B * lb, mem, false))) return r;
     mktd::RotArgs a = rot_args(c, (const uint32_t *)sa.dev, (int)alen, 1);
     a.init_mode = 1; a.out_mode = 1; a.tout = (cplx *)sl.dev; a.tout_natural = 1; a.ngates = B;
-    { Timer tm(c, 1); HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, c->p.W, a, B * (size_t)c->rtot, c->stream)); }
+    { Timer tm(c, 1); HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, c->p.W, a, B * (size_t)c->ks->rtot, c->stream)); }
     return sl.out(levkey);
 }
 

@@ -206,6 +206,17 @@ class Scheme:
             import torch
             self._ck(_lib.lib().mkt_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)))
 
+    def fork(self):
+        """a second Scheme over the SAME resident keys (mkt_ctx_fork: no copy) with its own stream and workspace -- one
+        per concurrent caller, as concurrent bootstrapping! calls share one read-only scheme object in the reference.
+        From then on the keys are immutable on every sharer."""
+        f = object.__new__(Scheme)
+        f.params, f.device, f._user_stream = self.params, self.device, False
+        h = C.c_void_p()
+        self._ck(_lib.lib().mkt_ctx_fork(self.h, C.byref(h)))
+        f.h = h
+        return f
+
     def close(self):
         if getattr(self, "h", None):
             _lib.lib().mkt_ctx_destroy(self.h)

@@ -746,3 +746,47 @@ def test_latency_variant_of_the_rotation_is_bit_identical(require_gpu, p, monkey
             assert bits_equal(res["2"][0][3, row:row + lev_o.shape[0]], lev_o)
             row += lev_o.shape[0]
     sg.close()
+
+
+def test_forked_contexts_share_one_key_set(require_gpu):
+    """mkt_ctx_fork: the reference's contract is ONE read-only scheme shared by concurrent bootstrapping! calls (all
+    scratch per call, bootstrapping.jl:38-45).  Forks share the resident keys (no second copy in HBM), each with its own
+    stream and workspace: four host threads evaluate different batches concurrently and reproduce the single-threaded
+    words; the shared key set is immutable; it outlives the context it was loaded through."""
+    import threading
+    import torch
+    p = mk.KMS2party.scaled(n=40, N=1024)
+    crs, keys = keygen(p, 61)
+    base = gpu_scheme(p, crs, keys)
+    so = oracle_scheme(p, crs, keys)
+    rng = np.random.default_rng(62)
+    bits = rng.integers(0, 2, 2 * 96).astype(bool)
+    c = encrypt_bits(p, keys, bits, seed=6200)
+    x, y = c[:96], c[96:]
+    want = base.gate(0, x, y)
+    assert np.array_equal(want[:4], so.gate_batch(0, x[:4], y[:4], threads=4))
+    free0 = torch.cuda.mem_get_info()[0]
+    forks = [base.fork() for _ in range(4)]
+    key_bytes = p.k * (p.n * 2 * p.l_gsw * 2 * p.N // 2 * 16 + p.N * 3 * p.f * (p.n + 4) * 4)
+    assert free0 - torch.cuda.mem_get_info()[0] < key_bytes // 4          # a fork allocates no key copy
+    with pytest.raises(mk.MktError):                                       # immutable once shared
+        base.load_party(0, keys[0])
+    with pytest.raises(mk.MktError):
+        forks[0].load_crs(crs)
+    base.close()                                                           # the forks keep the key set alive
+    outs = [None] * 4
+
+    def run(i):
+        st = torch.cuda.Stream()
+        forks[i].set_stream(st.cuda_stream)
+        sl = slice(i * 24, (i + 1) * 24)
+        res = [forks[i].gate(0, x[sl], y[sl]) for _ in range(5)]
+        forks[i].synchronize()
+        outs[i] = res
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for i in range(4):
+        assert all(np.array_equal(o, want[i * 24:(i + 1) * 24]) for o in outs[i]), f"fork {i}"
+    for f in forks:
+        f.close()
