@@ -51,3 +51,13 @@ def test_deterministic_seed_is_explicit_and_reproducible():
     assert np.array_equal(c, mk.lwe_ith_encrypt(1, 1, k1, p, deterministic_seed=9))
     raw = bytes(range(32))
     assert np.array_equal(mk.CRS(p, deterministic_seed=raw), mk.CRS(p, deterministic_seed=raw))
+
+
+def test_native_conversion_without_compare_matches_the_reference_form(tmp_path):
+    """fft_device.h native(): the select-free conversion (low dword of v + 2^52) equals arithmetic.jl:1-9's
+    `x == 2^W ? 0 : trunc(x)` on every input class: both signs, every exponent from denormals to 2^119, exact multiples
+    of 2^W minus tiny offsets (the rounded-up-to-2^W case), fractions"""
+    exe = str(tmp_path / "native_check")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tests", "csrc", "native_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith(" 0 mismatches"), out.stdout[-500:]
