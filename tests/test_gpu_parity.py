@@ -459,15 +459,17 @@ def test_blindrotate_special_exponents(require_gpu, p):
     sg.close()
 
 
-def test_fixture_replay_path(require_gpu, tmp_path):
+@pytest.mark.parametrize("kind", ["KMS", "CGGI", "LMSS", "CCS", "KMSblock"])
+def test_fixture_replay_path(require_gpu, tmp_path, kind):
     """tools/replay_fixture.py replays fixtures in the format tools/dump_fixture.jl (Julia reference, unexecuted here)
-    writes; the path is exercised with a fixture written by the oracle in the same format"""
+    writes -- all five scheme kinds, with the mod-switch, the accumulator after blindrotate! and the key switch checked
+    separately; the path is exercised with fixtures written by the oracle in the same format"""
     import subprocess, sys
     from helpers import ROOT
     d = str(tmp_path / "fx")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "replay_fixture.py"), "--make", d])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "replay_fixture.py"), "--make", d, kind])
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "replay_fixture.py"), d], capture_output=True, text=True)
-    assert out.returncode == 0 and "True" in out.stdout, out.stdout + out.stderr
+    assert out.returncode == 0 and "False" not in out.stdout and out.stdout.count("True") >= 4, out.stdout + out.stderr
 
 
 @pytest.mark.parametrize("p,B", [(mk.KMS4party, 8192 + 17), (mk.CCS8party, 1024), (mk.CCS8party_N2048, 1024), (mk.Blockparam, 16384), (mk.KMS2partyblock, 2048)],
