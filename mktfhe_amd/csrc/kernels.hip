@@ -19,6 +19,10 @@
 #define MKT_IN_TU(n) 1
 #endif
 
+#ifndef MKT_CCS_PF
+#define MKT_CCS_PF 1      // CCS kernel: key rows of a digit requested before its forward transform (CCS2party +3 %, CCS8party +1 %)
+#endif
+
 namespace mktd {
 
 constexpr int LOGR = MKT_LOGR;  // points per thread (4 by default)
@@ -865,13 +869,19 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
         const cplx *vk = q == 0 ? a.crs : a.pub_b + (size_t)(q - 1) * l * M;
         for (int j = 0; j < l; j++) {
             cplx z[R];
+            const cplx *kd = ud + (size_t)j * M, *kv = vk + (size_t)j * M;
+            cplx kdr[R], kvr[R];
+            if (MKT_CCS_PF) {                                                    // key rows requested before the transform that needs them
+#pragma unroll
+                for (int e = 0; e < R; e++) { kdr[e] = kd[dp[e]]; kvr[e] = kv[dp[e]]; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             digit_points<WORD, R>(z, tp, gd, j, rt);
             fft_forward1<LOGM>(z, psi_l, lds, t, xs);
-            const cplx *kd = ud + (size_t)j * M, *kv = vk + (size_t)j * M;
 #pragma unroll
             for (int e = 0; e < R; e++) {
-                tu[e] = cadd(tu[e], cmul(z[e], kd[dp[e]]));
-                const cplx pr = cmul(z[e], kv[dp[e]]);
+                tu[e] = cadd(tu[e], cmul(z[e], MKT_CCS_PF ? kdr[e] : kd[dp[e]]));
+                const cplx pr = cmul(z[e], MKT_CCS_PF ? kvr[e] : kv[dp[e]]);
                 tvq[e] = q == 0 ? csub(tvq[e], pr) : cadd(tvq[e], pr);          // :290 mulsubto!, :293 muladdto!
             }
         }
@@ -883,11 +893,17 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
         for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(vw[e][0]); tp[e][1] = gd.prep(vw[e][1]); }
         for (int j = 0; j < l; j++) {
             cplx z[R];
+            const cplx *fb = uf + (size_t)(2 * j) * M, *fa = fb + M;
+            cplx fbr[R], far[R];
+            if (MKT_CCS_PF) {
+#pragma unroll
+                for (int e = 0; e < R; e++) { fbr[e] = fb[dp[e]]; far[e] = fa[dp[e]]; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             digit_points<WORD, R>(z, tp, gd, j, rt);
             fft_forward1<LOGM>(z, psi_l, lds, t, xs);
-            const cplx *fb = uf + (size_t)(2 * j) * M, *fa = fb + M;
 #pragma unroll
-            for (int e = 0; e < R; e++) { tb[e] = cadd(tb[e], cmul(z[e], fb[dp[e]])); ta[e] = cadd(ta[e], cmul(z[e], fa[dp[e]])); }
+            for (int e = 0; e < R; e++) { tb[e] = cadd(tb[e], cmul(z[e], MKT_CCS_PF ? fbr[e] : fb[dp[e]])); ta[e] = cadd(ta[e], cmul(z[e], MKT_CCS_PF ? far[e] : fa[dp[e]])); }
         }
     };
     auto inv_words = [&](cplx (&z)[R], WORD (&w)[R][2]) {                        // fft.jl:74-81
