@@ -356,6 +356,29 @@ __device__ __forceinline__ void fft_inverse(cplx (&z)[NB][1 << LOGR], const cplx
     fft_inverse_pass<LOGM, LOGR, NB, CONJ, Plan<LOGM, LOGR, NB>::NPASS - 1, MO>(z, psiinv, lds, t, lx);
 }
 
+// The barriers of fft_inverse / fft_forward without the transform: thread groups of a workgroup that sit out a transform
+// which other groups run must still arrive at every workgroup barrier it contains.
+template <int LOGM, int LOGR, int NB, int LO_FROM, int LO_TO, int MO>
+__device__ __forceinline__ void exchange_barriers_only() {
+    if constexpr (Route<LOGM, LOGR, MO>::of(LO_FROM, LO_TO) == 0) {
+        if (Route<LOGM, LOGR, MO>::SB) __syncthreads();
+        __syncthreads();                             // the one inside exchange_lds
+    }
+}
+template <int LOGM, int LOGR, int NB, int PASS, int MO>
+__device__ __forceinline__ void fft_inverse_barriers_pass() {
+    using P = Plan<LOGM, LOGR, NB>;
+    if constexpr (PASS > 0) {
+        exchange_barriers_only<LOGM, LOGR, NB, P::lo(PASS), P::lo(PASS - 1), MO>();
+        fft_inverse_barriers_pass<LOGM, LOGR, NB, PASS - 1, MO>();
+    }
+}
+template <int LOGM, int LOGR, int NB, int MO = -1>
+__device__ __forceinline__ void fft_inverse_barriers_only() {
+    if (Route<LOGM, LOGR, MO>::guard_inv) __syncthreads();
+    fft_inverse_barriers_pass<LOGM, LOGR, NB, Plan<LOGM, LOGR, NB>::NPASS - 1, MO>();
+}
+
 // Device point order of the resident TransPolys (keys, monomial table, phase-1 output): where the
 // reference-order point x = 4t+e (slot e of thread t after the forward transform) is stored.
 #ifndef MKT_DEVORDER

@@ -1493,10 +1493,10 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
 // rotation, but the 2l digit transforms of a CMux step (:54-59) run side by side on 2l thread groups of NT threads:
 // group g decomposes its polynomial of the accumulator (b for g < l, a otherwise -- every group keeps its own copy of
 // that polynomial in registers), transforms digit g, multiplies by key row g (:63-68).  The 2l products meet in LDS and
-// are summed IN THE REFERENCE'S ORDER (g = 0 .. 2l-1, starting from 0) by every group that needs the sum -- the l
-// groups of polynomial b sum the b-components, the others the a-components -- so every rounding is the reference's.
-// Each group then multiplies by the monomial, runs the inverse transform of its polynomial (redundantly within the l
-// groups of one polynomial: latency, not throughput, is the point) and updates its copy (:71-73).
+// are summed IN THE REFERENCE'S ORDER (g = 0 .. 2l-1, starting from 0), so every rounding is the reference's.  The group
+// of digit 0 of each polynomial then multiplies by the monomial, runs the inverse transform and updates its copy of the
+// polynomial (:71-73); the other l-1 groups of that polynomial wait at the transform's barriers and copy the new words
+// from LDS.
 // LDS: Psi | region[2l][M]: FFT staging of group g (one buffer: barriers on both sides of an exchange), reused for the
 // product exchange between the forward and the inverse transforms.  Keys are read in the resident (LOGR = 2) device
 // point order whatever LR this kernel uses.
@@ -1569,7 +1569,7 @@ __global__ __launch_bounds__((2 * LT * Plan<LOGM, LR>::NT)) void blindrotate_wid
 #pragma unroll
             for (int e = 0; e < R; e++) stage[e * NT + t] = ph ? pa[e] : pb[e];
             __syncthreads();
-            if (c == ph) {
+            if (c == ph && j == 0) {
 #pragma unroll
                 for (int e = 0; e < R; e++) { ts[e].re = 0.0; ts[e].im = 0.0; }
 #pragma unroll
@@ -1578,15 +1578,34 @@ __global__ __launch_bounds__((2 * LT * Plan<LOGM, LR>::NT)) void blindrotate_wid
                     for (int e = 0; e < R; e++) ts[e] = cadd(ts[e], region[(size_t)g * M + e * NT + t]);
             }
         }
-        cplx s[1][R];
+        // :71-73 once per polynomial, by the group of its digit 0; the other groups of that polynomial only keep the
+        // workgroup barriers company and then pick the new words up from LDS (exact integers: every copy stays identical)
+        WORD *xw = reinterpret_cast<WORD *>(region) + (size_t)c * N;      // [2][N] words at the head of the region
+        if (j == 0) {
+            cplx s[1][R];
 #pragma unroll
-        for (int e = 0; e < R; e++) s[0][e] = cmul(mv[e], ts[e]);        // :71
-        fft_inverse<LOGM, LR, 1, true, MO>(s, psi_l, stage, t, xs.lx);   // :72 (the first exchange's leading barrier also fences the product reads)
+            for (int e = 0; e < R; e++) s[0][e] = cmul(mv[e], ts[e]);    // :71
+            fft_inverse<LOGM, LR, 1, true, MO>(s, psi_l, stage, t, xs.lx);   // :72 (its first barrier also fences the product reads)
 #pragma unroll
-        for (int e = 0; e < R; e++) {                                    // fft.jl:76-80, :73
-            const cplx v = cmul(s[0][e], ri[e]);
-            acc[e][0] = (WORD)(acc[e][0] + native<WORD>(v.re));
-            acc[e][1] = (WORD)(acc[e][1] + native<WORD>(-v.im));
+            for (int e = 0; e < R; e++) {                                // fft.jl:76-80, :73
+                const cplx v = cmul(s[0][e], ri[e]);
+                acc[e][0] = (WORD)(acc[e][0] + native<WORD>(v.re));
+                acc[e][1] = (WORD)(acc[e][1] + native<WORD>(-v.im));
+            }
+        } else {
+            fft_inverse_barriers_only<LOGM, LR, 1, MO>();
+        }
+        if (LT > 1) {
+            __syncthreads();                                             // the last staging reads of the inverse are done
+            if (j == 0) {
+#pragma unroll
+                for (int e = 0; e < R; e++) { xw[e * NT + t] = acc[e][0]; xw[M + e * NT + t] = acc[e][1]; }
+            }
+            __syncthreads();
+            if (j != 0) {
+#pragma unroll
+                for (int e = 0; e < R; e++) { acc[e][0] = xw[e * NT + t]; acc[e][1] = xw[M + e * NT + t]; }
+            }
         }
     }
 
