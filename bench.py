@@ -317,7 +317,7 @@ def main():
     pname, desc = WORKLOADS[args.workload]
     p = getattr(mk, pname)
     B = args.batch
-    need_host_keys = rank == 0 and not args.no_cpu_baseline
+    need_host_keys = rank == 0 and world == 1 and not args.no_cpu_baseline
     crs, keys, sch = make_scheme(mk, p, local, need_host_keys)
     bits, x, y = make_inputs(mk, torch, p, keys, sch, B, rank, dev, args.inputs)
     torch.cuda.synchronize()
@@ -363,11 +363,11 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- transform roofline legs (BASELINE.json metric 2) ----
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline:
         line["roofline_transform"] = transform_roofline(mk, torch, local, dev)
 
-    # ---- CPU baseline leg (oracle, "port") ----
-    if rank == 0 and not args.no_cpu_baseline:
+    # ---- CPU baseline leg (oracle, "port"): rank 0 at N = 1 only ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from helpers import oracle_scheme
         so = oracle_scheme(p, crs, keys)
         cores = effective_cpus()                   # host threads this process may actually run on (cgroup quota aware)

@@ -792,3 +792,24 @@ def test_forked_contexts_share_one_key_set(require_gpu):
         assert all(np.array_equal(o, want[i * 24:(i + 1) * 24]) for o in outs[i]), f"fork {i}"
     for f in forks:
         f.close()
+
+
+@pytest.mark.parametrize("p,nfold", [(mk.KMS8party, 2), (mk.KMS4party, 3)], ids=lambda v: getattr(v, "name", str(v)))
+def test_many_party_sets_at_full_size(require_gpu, p, nfold):
+    """params.jl:55-69 at full size (N = 2048, n = 560, k = 4 / 8 parties, gadget lengths 5 / 4): NAND folds over one fresh
+    encryption per party -- the reference's own test shape (test/KMS.jl:23-37) -- every gate output equal to the oracle's
+    words, the final ciphertexts decrypt."""
+    crs, keys = keygen(p, 91)
+    so = oracle_scheme(p, crs, keys)
+    sg = gpu_scheme(p, crs, keys)
+    k = p.k
+    bits = np.random.default_rng(92).integers(0, 2, nfold * k).astype(bool)
+    c = encrypt_bits(p, keys, bits, seed=9200)                       # ciphertext j under party j mod k
+    acc, ab = c[0::k].copy(), bits[0::k].copy()
+    for i in range(1, k):
+        nxt = c[i::k]
+        out = sg.gate(0, acc, nxt)
+        assert np.array_equal(out, so.gate_batch(0, acc, nxt, threads=16)), f"fold step {i}"
+        acc, ab = out, ~(ab & bits[i::k])
+    assert np.array_equal(mk.lwe_decrypt(acc, keys, p), ab)
+    sg.close()
