@@ -43,6 +43,7 @@ WORKLOADS = {
     "cggi": ("CGGIparam", "CGGIparam single-key, N=1024, l=3 (src/tfhe/params.jl:1-6)"),
     "cggi_l2": ("CGGI_N1024_l2", "CGGI single-key, N=1024, n=630, l=2 (BASELINE.json configs[0], synthetic gadget)"),
     "lmss": ("Blockparam", "Blockparam LMSS block-binary single-key, N=1024 (src/tfhe/params.jl:8-13)"),
+    "lmss_k2": ("Blockparam_k2", "LMSS block-binary, N=1024, RLWE length k=2 (BASELINE.json configs[4], synthetic shape)"),
     "kms2partyblock": ("KMS2partyblock", "KMS2partyblock k=2, N=2048, block-binary keys (src/tfhe/params.jl:87-93)"),
     "kms4party": ("KMS4party", "KMS4party k=4, N=2048 (src/tfhe/params.jl:55-61)"),
     "ccs2party": ("CCS2party", "CCS2party k=2, N=1024 (src/tfhe/params.jl:15-21)"),
@@ -133,8 +134,10 @@ def blindrotate_flop(mk, p, B):
         return sum((idx + 2) * per_poly for idx in range(p.k)) * p.n * B, 1
     rows = (1 + (p.k - 1) * p.l_lev) if p.scheme in (mk.KMS, mk.KMS_BLOCK) else 1
     l = max(p.l_gsw, 1)
-    LB = max(p.blk_len, 1)     # block schemes: one decomposition + 2l+2 transforms per block of LB key bits
-    per_iter = (2 * l + 2) * (5 * M * lg + 6 * M) + LB * (4 * l * 8 * M + 2 * (8 if LB > 1 else 6) * M)
+    LB = max(p.blk_len, 1)     # block schemes: one decomposition + (kr+1)(l+1) transforms per block of LB key bits
+    kr = 1 if p.multikey else p.k          # RLWE length of the rotation (KMS rotates length-1 RLWE rows)
+    T = 5 * M * lg + 6 * M
+    per_iter = (kr + 1) * (l + 1) * T + LB * ((kr + 1) ** 2 * l * 8 * M + (kr + 1) * (8 if LB > 1 else 6) * M)
     return per_iter * (p.n // LB) * rows * B, rows
 
 
@@ -215,13 +218,15 @@ def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, w
 
 def rot_roofline(mk, p, B, t, workload):
     """the roofline object of the dominant kernel of this workload (plain / KMS schemes: blindrotate_k1_kernel)"""
-    flop, rows = blindrotate_flop(mk, p, B)
+    flop_step, rows = blindrotate_flop(mk, p, B)              # one step = ceil(B / 8192) launches (the engine's workspace chunk)
+    launches_per_step = max(1, -(-B // 8192))
+    flop = flop_step / launches_per_step
     avg_ms = t["rot_ms"] / max(t["rot_n"], 1)
     achieved = flop / (avg_ms * 1e-3) / 1e12
     kern = "ccs_blindrotate_kernel" if p.scheme == mk.CCS else ("blindrotate_kr_kernel" if (not p.multikey and p.k > 1) else "blindrotate_k1_kernel")
     r = {"bound": "f64-valu-nofma", "kernel": kern, "achieved": achieved, "peak": PEAK_F64_NOFMA_TFLOPS,
          "unit": "TFLOP/s", "frac": achieved / PEAK_F64_NOFMA_TFLOPS, "traffic": None,
-         "algorithmic_flop_per_launch": flop, "rotations_per_launch": rows * B, "cmux_per_rotation": p.n // max(p.blk_len, 1),
+         "algorithmic_flop_per_launch": flop, "rotations_per_launch": rows * B / launches_per_step, "cmux_per_rotation": p.n // max(p.blk_len, 1),
          "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
          "peak_note": "256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz, mul and add issued separately (no FMA: bit parity)"}
     prof = profiled_counters("mktd::" + kern, workload, want=("FETCH_SIZE", "WRITE_SIZE"))

@@ -589,7 +589,10 @@ void blindrotate_k1_kernel(const RotArgs a) {
 // are recomputed per key bit here (same values) instead of being held for the whole block.
 // brk layout [n][(KR+1)*l rows][KR+1 polys][M] (device point order), acc [rot][KR+1][N].
 // ------------------------------------------------------------------------------------------------
-template <int LOGM, typename WORD, int KR, bool BLK>
+// BL > 0 (LMSS, block length known at compile time): the digit transforms of a block are computed ONCE and multiplied into
+// one transform-domain accumulator per key bit of the block ((KR+1) * BL of them in registers), exactly the reference's
+// loop nest (:131-158); BL = 0 recomputes them per key bit (any block length).
+template <int LOGM, typename WORD, int KR, bool BLK, int BL = 0>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(const RotArgs a) {
     using P = Plan<LOGM, LOGR>;
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, NP = KR + 1;
@@ -613,6 +616,76 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(
 #pragma unroll
         for (int e = 0; e < R; e++) { acc[c][e][0] = accg[c * N + e * NT + t]; acc[c][e][1] = accg[c * N + M + e * NT + t]; }
     const int msbit = 32 - a.logN - 1;
+    if constexpr (BLK && BL > 0) {
+        for (int blk = 0; blk < a.n / BL; blk++) {
+            uint32_t ats[BL];
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < BL; q++) {
+                const uint32_t v0 = at_src[blk * BL + q];
+                ats[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+                any |= ats[q] != 0;
+            }
+            if (!any) continue;                                          // an all-zero block adds native(0) = 0 (:162-163)
+            cplx tacc[BL][NP][R];
+#pragma unroll
+            for (int q = 0; q < BL; q++)
+#pragma unroll
+                for (int pp = 0; pp < NP; pp++)
+#pragma unroll
+                    for (int e = 0; e < R; e++) { tacc[q][pp][e].re = 0.0; tacc[q][pp][e].im = 0.0; }
+#pragma unroll
+            for (int c = 0; c < NP; c++) {                               // :131-140 one decomposition per block
+                WORD tp[R][2];
+#pragma unroll
+                for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(acc[c][e][0]); tp[e][1] = gd.prep(acc[c][e][1]); }
+                for (int j = 0; j < l; j++) {
+                    cplx z[R];
+#pragma unroll
+                    for (int e = 0; e < R; e++) {
+                        const int d0 = gd.digit(tp[e][0], j), d1 = gd.digit(tp[e][1], j);
+                        cplx v; v.re = (double)d0; v.im = (double)(-d1);
+                        z[e] = cmul(v, a.tw.roots[e * NT + t]);
+                    }
+                    fft_forward1<LOGM>(z, psi_l, lds, t, xs);
+#pragma unroll
+                    for (int q = 0; q < BL; q++) {                       // :146-154, rows in the reference's order for every key bit
+                        if (ats[q] == 0) continue;
+                        const cplx *row = a.brk + ((size_t)(blk * BL + q) * NP * l + (size_t)(c * l + j)) * NP * M;
+#pragma unroll
+                        for (int pp = 0; pp < NP; pp++)
+#pragma unroll
+                            for (int e = 0; e < R; e++) tacc[q][pp][e] = cadd(tacc[q][pp][e], cmul(z[e], row[(size_t)pp * M + dp[e]]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < NP; pp++) {
+                cplx s2[R];
+#pragma unroll
+                for (int e = 0; e < R; e++) { s2[e].re = 0.0; s2[e].im = 0.0; }
+#pragma unroll
+                for (int q = 0; q < BL; q++) {                           // :157 tacc2 += monomial * tacc
+                    if (ats[q] == 0) continue;
+                    const cplx *mono = a.monomial + (size_t)(ats[q] - 1) * M;
+#pragma unroll
+                    for (int e = 0; e < R; e++) s2[e] = cadd(s2[e], cmul(mono[dp[e]], tacc[q][pp][e]));
+                }
+                fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(s2), psi_l, lds, t, xs.lx);   // :162-163
+#pragma unroll
+                for (int e = 0; e < R; e++) {
+                    const cplx v = cmul(s2[e], a.tw.rootsinv[e * NT + t]);
+                    acc[pp][e][0] = (WORD)(acc[pp][e][0] + native<WORD>(v.re));
+                    acc[pp][e][1] = (WORD)(acc[pp][e][1] + native<WORD>(-v.im));
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NP; c++)
+#pragma unroll
+            for (int e = 0; e < R; e++) { accg[c * N + e * NT + t] = acc[c][e][0]; accg[c * N + M + e * NT + t] = acc[c][e][1]; }
+        return;
+    }
     const int blen = BLK ? a.blk_len : 1;
     for (int blk = 0; blk < a.n / blen; blk++) {
         cplx t2[BLK ? NP : 1][R];                                        // :142 tacc2 (LMSS only)
@@ -1382,17 +1455,18 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
 #endif  // TU 0
 
 #if MKT_IN_TU(4)
-template <int LM, typename WORD, int KR, bool BLK>
+template <int LM, typename WORD, int KR, bool BLK, int BL = 0>
 static hipError_t launch_kr_one(const RotArgs &a, size_t nrot, hipStream_t s) {
     using P = Plan<LM, LOGR>;
     constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
-    hipError_t e = set_lds(blindrotate_kr_kernel<LM, WORD, KR, BLK>, LB);
+    hipError_t e = set_lds(blindrotate_kr_kernel<LM, WORD, KR, BLK, BL>, LB);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((blindrotate_kr_kernel<LM, WORD, KR, BLK>), dim3((unsigned)nrot), dim3(P::NT), LB, s, a);
+    hipLaunchKernelGGL((blindrotate_kr_kernel<LM, WORD, KR, BLK, BL>), dim3((unsigned)nrot), dim3(P::NT), LB, s, a);
     return hipGetLastError();
 }
 template <int LM, typename WORD>
 static hipError_t launch_kr_word(int kr, const RotArgs &a, size_t nrot, hipStream_t s) {
+    if (a.blk_len == 3 && kr == 2 && sizeof(WORD) == 4) return launch_kr_one<LM, WORD, 2, true, 3>(a, nrot, s);   // Blockparam's block length (params.jl:8-13)
     if (a.blk_len > 1) return kr == 2 ? launch_kr_one<LM, WORD, 2, true>(a, nrot, s) : launch_kr_one<LM, WORD, 3, true>(a, nrot, s);
     return kr == 2 ? launch_kr_one<LM, WORD, 2, false>(a, nrot, s) : launch_kr_one<LM, WORD, 3, false>(a, nrot, s);
 }

@@ -97,3 +97,7 @@ CGGI_N1024_l2 = Params("CGGI_N1024_l2", CGGI, 630, 1024, 1, 32, 2.0**17, 2.0**7,
 # gives 0.075 (25 % wrong).  The doubled ring dimension carries its security with less noise: beta = 1 (std 0.011, no
 # failures in 2048 gates, tools/noise_probe.py); gadget as CCS8party.
 CCS8party_N2048 = Params("CCS8party_N2048", CCS, 560, 2048, 8, 32, 2.0**17, 1.0, l_uni=5, logB_uni=6)
+# BASELINE.json configs[4]: "LMSS block-binary blind-rotation, N=1024, k=2": Blockparam (params.jl:8-13) with RLWE
+# length 2 -- a legal TFHEparams_block value (scheme.jl:22-36), not a shipped constant; noise as Blockparam, gadget
+# base 2^7 instead of 2^9 (twice the key dimension: phase error std 0.005 instead of 0.015, tools/noise_probe.py).
+Blockparam_k2 = Params("Blockparam_k2", LMSS, 229 * 3, 1024, 2, 32, 2.0**17, 2.0**7, l_gsw=3, logB_gsw=7, blk_len=3, blk_d=229)

@@ -111,6 +111,8 @@ SMALL = [
     mk.Blockparam.scaled(n=30, N=256, blk_d=10, k=2),       # LMSS with RLWE length > 1 (TFHEparams_block.k)
     mk.Blockparam.scaled(n=300, N=128, blk_d=100, k=3),     # n > N: the key switch copies whole components (:179-186)
     mk.Blockparam.scaled(n=150, N=128, blk_d=50, k=2, blk_len=3),
+    mk.Blockparam_k2.scaled(n=24, blk_d=8),                 # BASELINE configs[4] shape (N = 1024, k = 2, block length 3) at reduced n
+    mk.Blockparam_k2.scaled(n=24, blk_d=12, blk_len=2),     # other block lengths take the generic path
 ]
 
 
@@ -200,7 +202,7 @@ def test_stages_small(require_gpu, p):
     _stage_check(p)
 
 
-FULL = [mk.CGGIparam, mk.CGGI_N1024_l2, mk.Blockparam, mk.KMS2party, mk.KMS2partyblock, mk.KMS2party_N1024_l2, mk.CCS2party]
+FULL = [mk.CGGIparam, mk.CGGI_N1024_l2, mk.Blockparam, mk.Blockparam_k2, mk.KMS2party, mk.KMS2partyblock, mk.KMS2party_N1024_l2, mk.CCS2party]
 
 
 @pytest.mark.parametrize("p", FULL, ids=lambda p: p.name)
@@ -472,7 +474,7 @@ def test_fixture_replay_path(require_gpu, tmp_path, kind):
     assert out.returncode == 0 and "False" not in out.stdout and out.stdout.count("True") >= 4, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("p,B", [(mk.KMS4party, 8192 + 17), (mk.CCS8party, 1024), (mk.CCS8party_N2048, 1024), (mk.Blockparam, 16384), (mk.KMS2partyblock, 2048)],
+@pytest.mark.parametrize("p,B", [(mk.KMS4party, 8192 + 17), (mk.CCS8party, 1024), (mk.CCS8party_N2048, 1024), (mk.Blockparam, 16384), (mk.Blockparam_k2, 16384), (mk.KMS2partyblock, 2048)],
                          ids=lambda v: getattr(v, "name", str(v)))
 def test_baseline_config_shares(require_gpu, p, B):
     """BASELINE.json configs[2..4] at one GPU's share of the batch (65536 / 8 KMS4party gates -- plus a ragged tail that
