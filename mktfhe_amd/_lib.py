@@ -87,6 +87,13 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
                 "or make -C mktfhe_amd/csrc). mktfhe_amd has no CPU fallback.")
+        # When PyTorch is part of the process it brings its own copy of the HIP runtime (same SONAME).  Whichever copy is
+        # mapped first serves both; mapped in the other order (this library, then torch) the runtime this library was
+        # bound to sees no device.  So torch, if installed, goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
