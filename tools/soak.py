@@ -8,10 +8,11 @@ REPS = int(os.environ.get("REPS", "40"))
 sets = [mk.CGGIparam, mk.KMS2party_N1024_l2, mk.KMS2party, mk.Blockparam, mk.KMS2partyblock, mk.CCS2party,
         mk.CGGIparam.scaled(n=64, N=256), mk.KMS2party.scaled(n=64, N=512), mk.KMS4party.scaled(n=32, N=4096), mk.CGGIparam.scaled(n=64, N=2048, k=2)]
 bad = 0
-for p in sets:
+SMALL = {mk.CGGIparam.name, mk.KMS2party_N1024_l2.name}      # also at 64 gates: the latency variant of the rotation
+for p, Bs in [(p, None) for p in sets] + [(p, 64) for p in sets if p.name in SMALL and p.n > 100]:
     crs, keys = keygen(p, 3)
     sg = gpu_scheme(p, crs, keys)
-    B = 1024 if p.N <= 2048 and p.n > 100 else 512
+    B = Bs or (1024 if p.N <= 2048 and p.n > 100 else 512)
     bits = np.random.default_rng(4).integers(0, 2, 2 * B + 1).astype(bool)
     c = encrypt_bits(p, keys, bits, seed=40)
     x = torch.from_numpy(c[:B].view(np.int32)).cuda(); y = torch.from_numpy(c[B + 1:].view(np.int32)).cuda()
