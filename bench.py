@@ -275,8 +275,26 @@ def transform_roofline(mk, torch, local, dev):
                 e["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
                 e["traffic_source"] = src
             out.append(e)
-        del polys, tr, back
         s.close()
+        # the same buffers through the exact integer transform (MKT_ARITH_EXACT: Goldilocks NTT, N residues = 8 N bytes)
+        sx = mk.Scheme(p, device=local, arith=mk.ARITH_EXACT)
+        for direction in ("forward", "inverse"):
+            fn = (lambda: sx.transform_fwd(polys, out=tr)) if direction == "forward" else (lambda: sx.transform_inv(tr, out=back))
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            sx.enable_timing(True)
+            for _ in range(5):
+                fn()
+            ms, cnt = sx.kernel_ms(3)
+            sx.enable_timing(False)
+            achieved = nb * 16 * N / (ms / cnt * 1e-3) / 1e9
+            out.append({"bound": "hbm", "kernel": "ntt_fwd_kernel" if direction == "forward" else "ntt_inv_kernel", "arith": "EXACT (integer NTT, p = 2^64 - 2^32 + 1)",
+                        "direction": direction, "N": N, "ring_bits": 64, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                        "traffic": None, "algorithmic_bytes_per_launch": nb * 16 * N, "bytes_per_transform": 16 * N, "transforms_per_launch": nb,
+                        "avg_launch_ms": ms / cnt})
+        sx.close()
+        del polys, tr, back
         torch.cuda.empty_cache()
     return out
 

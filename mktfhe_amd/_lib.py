@@ -56,6 +56,7 @@ SYMBOLS = {
     "mkt_transform_fwd_batch": (_i, [_vp, _vp, _vp, _sz, _i]),
     "mkt_transform_inv_batch": (_i, [_vp, _vp, _vp, _sz, _i]),
     "mkt_decompose_batch": (_i, [_vp, _vp, _vp, _i, _i, _sz, _i]),
+    "mkt_exact_polymul_batch": (_i, [_vp, _vp, _vp, _vp, _sz, _i]),
     "mkt_get_monomial": (_i, [_vp, _i, _vp]),
     "mkt_enable_timing": (_i, [_vp, _i]),
     "mkt_last_kernel_ms": (_i, [_vp, _i, C.POINTER(_dbl)]),

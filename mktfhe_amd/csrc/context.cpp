@@ -56,6 +56,8 @@ struct mkt_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     std::shared_ptr<KeySet> ks;  // shared with the contexts forked from this one
+    bool exact = false;          // MKT_ARITH_EXACT: transform-level entry points only (integer NTT); d_ntt = psi_rev | psiinv_rev | N^-1
+    uint64_t *d_ntt = nullptr;
     // workspace
     size_t ws_gates = 0;
     uint32_t *ws_lin = nullptr;
@@ -296,6 +298,36 @@ struct Staged {
 
 bool mem_ok(int mem) { return mem == MKT_MEM_DEVICE || mem == MKT_MEM_HOST; }
 
+// ---- MKT_ARITH_EXACT: Goldilocks tables on the host (128-bit arithmetic), uploaded once ----
+constexpr uint64_t GLP = 0xFFFFFFFF00000001ull;
+uint64_t gl_mulmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % GLP); }
+uint64_t gl_powmod(uint64_t a, uint64_t e) { uint64_t r = 1; while (e) { if (e & 1) r = gl_mulmod(r, a); a = gl_mulmod(a, a); e >>= 1; } return r; }
+
+int create_exact(const mkt_params &p, int logN, int device, mkt_ctx **out) {
+    if (logN < 5 || logN > 12) return fail(nullptr, MKT_ERR_UNSUPPORTED, "EXACT mode: N must be 32..4096");
+    auto *c = new mkt_ctx();
+    c->ks = std::make_shared<KeySet>();
+    c->ks->device = device;
+    c->p = p; c->sh = mkt::shape_of(p); c->device = device; c->logN = logN; c->logM = logN - 1; c->M = p.N / 2; c->exact = true;
+    DevGuard dg(device);
+    const int N = p.N;
+    // psi = a primitive 2N-th root of unity: 7 generates Z_p^*, (p - 1) / 2N is an integer for N <= 2^31
+    const uint64_t psi = gl_powmod(7, (GLP - 1) / (2 * (uint64_t)N)), psiinv = gl_powmod(psi, GLP - 2);
+    std::vector<uint64_t> tab((size_t)2 * N + 1);
+    for (int i = 0; i < N; i++) {
+        int r = 0;
+        for (int b = 0; b < logN; b++) r |= ((i >> b) & 1) << (logN - 1 - b);
+        tab[i] = gl_powmod(psi, (uint64_t)r); tab[(size_t)N + i] = gl_powmod(psiinv, (uint64_t)r);
+    }
+    tab[(size_t)2 * N] = gl_powmod((uint64_t)N, GLP - 2);
+    hipError_t e = hipMalloc((void **)&c->d_ntt, tab.size() * 8);
+    if (e == hipSuccess) e = hipMemcpy(c->d_ntt, tab.data(), tab.size() * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { std::string m = std::string("EXACT tables: ") + hipGetErrorString(e); mkt_ctx_destroy(c); g_create_error = m; return MKT_ERR_HIP; }
+    *out = c;
+    return MKT_OK;
+}
+#define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; an MKT_ARITH_EXACT context offers the transform-level entry points only (mkt_transform_*_batch, mkt_exact_polymul_batch, mkt_decompose_batch)"); } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -309,8 +341,7 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     *out = nullptr;
     std::string why;
     if (mkt::validate_params(*params, why)) return fail(nullptr, MKT_ERR_ARG, why);
-    if (arith_mode == MKT_ARITH_EXACT) return fail(nullptr, MKT_ERR_UNSUPPORTED, "EXACT (integer NTT) mode is reserved; use MKT_ARITH_F64REF");
-    if (arith_mode != MKT_ARITH_F64REF) return fail(nullptr, MKT_ERR_ARG, "unknown arithmetic mode");
+    if (arith_mode != MKT_ARITH_F64REF && arith_mode != MKT_ARITH_EXACT) return fail(nullptr, MKT_ERR_ARG, "unknown arithmetic mode");
     const int logN = __builtin_ctz((unsigned)params->N);
     if (!mktd::transform_supported(logN - 1)) return fail(nullptr, MKT_ERR_UNSUPPORTED, "ring dimension not instantiated (N must be 32..4096)");
     int ndev = 0;
@@ -322,6 +353,7 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(nullptr, MKT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", the engine is built for gfx950 only");
 
+    if (arith_mode == MKT_ARITH_EXACT) return create_exact(*params, logN, device, out);
     auto *c = new mkt_ctx();
     c->ks = std::make_shared<KeySet>();
     c->ks->device = device;
@@ -373,7 +405,7 @@ int mkt_ctx_destroy(mkt_ctx *c) {
     DevGuard dg(c->device);
     (void)hipStreamSynchronize(c->stream);
     clear_spans(c);
-    void *ptrs[] = {c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch};
+    void *ptrs[] = {c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch, c->d_ntt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete c;                      // drops this context's reference to the key set; the last one frees it
     return MKT_OK;
@@ -385,6 +417,7 @@ int mkt_ctx_destroy(mkt_ctx *c) {
 // mkt_keygen_device return MKT_ERR_STATE on every context that shares it).
 int mkt_ctx_fork(mkt_ctx *c, mkt_ctx **out) {
     if (!c || !out) return fail(c, MKT_ERR_ARG, "null argument");
+    MKT_F64_ONLY(c);
     auto *f = new mkt_ctx();
     f->p = c->p; f->sh = c->sh; f->device = c->device; f->logM = c->logM; f->logN = c->logN; f->M = c->M;
     f->ks = c->ks;
@@ -403,6 +436,7 @@ int mkt_synchronize(mkt_ctx *c) {
 
 int mkt_get_twiddles(mkt_ctx *c, int which, double *out_host) {
     if (!c || !out_host || which < 0 || which > 3) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     DevGuard dg(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out_host, c->ks->d_tw + (size_t)which * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
@@ -411,6 +445,7 @@ int mkt_get_twiddles(mkt_ctx *c, int which, double *out_host) {
 
 int mkt_set_twiddles(mkt_ctx *c, const double *psi, const double *psiinv, const double *roots, const double *rootsinv) {
     if (!c || !psi || !psiinv || !roots || !rootsinv) return fail(c, MKT_ERR_ARG, "null table");
+    MKT_F64_ONLY(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     const size_t nd = (size_t)2 * c->M;
@@ -429,6 +464,7 @@ int mkt_set_twiddles(mkt_ctx *c, const double *psi, const double *psiinv, const 
 
 int mkt_get_monomial(mkt_ctx *c, int e, double *out_host) {
     if (!c || !out_host || e < 1 || e > 2 * c->p.N) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     DevGuard dg(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<cplx> dev((size_t)c->M);
@@ -441,6 +477,7 @@ int mkt_get_monomial(mkt_ctx *c, int e, double *out_host) {
 
 int mkt_load_brk(mkt_ctx *c, int party, const void *data, int fmt) {
     if (!c || !data || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     int r = upload_polys(c, data, (size_t)c->p.n * c->sh.brk_polys, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, fmt);
@@ -450,6 +487,7 @@ int mkt_load_brk(mkt_ctx *c, int party, const void *data, int fmt) {
 
 int mkt_load_ksk(mkt_ctx *c, int party, const uint32_t *data) {
     if (!c || !data || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     const size_t rows = (size_t)c->sh.ksk_kr * c->p.N * c->sh.ksk_drows * c->p.f, n1 = (size_t)c->p.n + 1;
@@ -461,6 +499,7 @@ int mkt_load_ksk(mkt_ctx *c, int party, const uint32_t *data) {
 
 int mkt_load_rlk(mkt_ctx *c, int party, const void *d, const void *f, int fmt) {
     if (!c || !d || !f || party < 0 || party >= c->sh.nparty || !mkt::is_kms(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     const size_t l = (size_t)c->p.l_uni;
@@ -472,6 +511,7 @@ int mkt_load_rlk(mkt_ctx *c, int party, const void *d, const void *f, int fmt) {
 
 int mkt_load_pubkey(mkt_ctx *c, int party, const void *b, int fmt) {
     if (!c || !b || party < 0 || party >= c->sh.nparty || !mkt::is_mk(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     int r = upload_polys(c, b, (size_t)c->p.l_uni, c->ks->d_pub + (size_t)party * c->p.l_uni * c->M, fmt);
@@ -481,6 +521,7 @@ int mkt_load_pubkey(mkt_ctx *c, int party, const void *b, int fmt) {
 
 int mkt_load_crs(mkt_ctx *c, const void *a, int fmt) {
     if (!c || !a || !mkt::is_mk(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     int r = upload_polys(c, a, (size_t)c->p.l_uni, c->ks->d_crs, fmt);
@@ -492,6 +533,7 @@ int mkt_load_crs(mkt_ctx *c, const void *a, int fmt) {
 // (keygen.hip: the seeded streams of mkt_client_party_keygen, identical words), pre-transformed in place of an upload.
 static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, const void *crs, void *brk_out, uint32_t *ksk_out) {
     if (!c || !K || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     const mkt_params &p = c->p;
     if (std::memcmp(&K->p, &p, sizeof(mkt_params)) != 0 || K->party != party) return fail(c, MKT_ERR_ARG, "mkt_keygen_device: the party's keys were made for other parameters / another party index");
@@ -552,6 +594,7 @@ int mkt_keygen_device_export(mkt_ctx *c, int party, const mkt_client_party *K, c
 // debug / test read-back of a party's key-switching key in the host layout of mkt_load_ksk
 int mkt_get_ksk(mkt_ctx *c, int party, uint32_t *out_host) {
     if (!c || !out_host || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     DevGuard dg(c->device);
     const size_t rows = (size_t)c->sh.ksk_kr * c->p.N * c->sh.ksk_drows * c->p.f, n1 = (size_t)c->p.n + 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -563,6 +606,7 @@ int mkt_get_ksk(mkt_ctx *c, int party, uint32_t *out_host) {
 
 int mkt_gate_batch(mkt_ctx *c, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem) {
     if (!c || !x || !y || !out || !mem_ok(mem) || op < MKT_NAND || op > MKT_NOR) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     int r;
     if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
     DevGuard dg(c->device);
@@ -592,6 +636,7 @@ int mkt_not_batch(mkt_ctx *c, uint32_t *x, size_t B, int mem) {
 
 int mkt_bootstrap_batch(mkt_ctx *c, uint32_t *lwe, size_t B, int mem) {
     if (!c || !lwe || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     int r;
     if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
     DevGuard dg(c->device);
@@ -623,6 +668,7 @@ int mkt_modswitch_batch(mkt_ctx *c, const uint32_t *lwe, uint32_t *atilde, uint3
 
 int mkt_blindrotate_batch(mkt_ctx *c, const uint32_t *atilde, void *acc, size_t B, int mem) {
     if (!c || !atilde || !acc || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     int r;
     if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, false))) return r;
     DevGuard dg(c->device);
@@ -640,6 +686,7 @@ int mkt_blindrotate_batch(mkt_ctx *c, const uint32_t *atilde, void *acc, size_t 
 
 int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, size_t B, int mem) {
     if (!c || !atilde || !levkey || !mem_ok(mem) || !mkt::is_kms(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     int r;
     if ((r = check_ready(c, true, false))) return r;
     DevGuard dg(c->device);
@@ -654,6 +701,7 @@ int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, siz
 
 int mkt_keyswitch_batch(mkt_ctx *c, const void *acc, uint32_t *out, size_t B, int mem) {
     if (!c || !acc || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_F64_ONLY(c);
     int r;
     if ((r = check_ready(c, false, true))) return r;
     DevGuard dg(c->device);
@@ -670,7 +718,8 @@ int mkt_transform_fwd_batch(mkt_ctx *c, const void *p, double *t, size_t B, int 
     Staged sp{c}, st{c};
     int r;
     if ((r = sp.in(p, B * poly_bytes(c), mem, true)) || (r = st.in(t, B * (size_t)c->M * sizeof(cplx), mem, false))) return r;
-    { Timer tm(c, 3); HIPCHK(c, mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), sp.dev, (cplx *)st.dev, B, 0, c->stream)); }
+    if (c->exact) { Timer tm(c, 3); HIPCHK(c, mktd::launch_ntt_fwd(c->logN, c->p.W, c->d_ntt, sp.dev, (uint64_t *)st.dev, B, c->stream)); }
+    else { Timer tm(c, 3); HIPCHK(c, mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), sp.dev, (cplx *)st.dev, B, 0, c->stream)); }
     return st.out(t);
 }
 
@@ -680,7 +729,8 @@ int mkt_transform_inv_batch(mkt_ctx *c, const double *t, void *p, size_t B, int 
     Staged st{c}, sp{c};
     int r;
     if ((r = st.in(t, B * (size_t)c->M * sizeof(cplx), mem, true)) || (r = sp.in(p, B * poly_bytes(c), mem, false))) return r;
-    { Timer tm(c, 3); HIPCHK(c, mktd::launch_transform_inv(c->logM, c->p.W, c->twp(), (const cplx *)st.dev, sp.dev, B, c->stream)); }
+    if (c->exact) { Timer tm(c, 3); HIPCHK(c, mktd::launch_ntt_inv(c->logN, c->p.W, c->d_ntt, (const uint64_t *)st.dev, sp.dev, B, c->stream)); }
+    else { Timer tm(c, 3); HIPCHK(c, mktd::launch_transform_inv(c->logM, c->p.W, c->twp(), (const cplx *)st.dev, sp.dev, B, c->stream)); }
     return sp.out(p);
 }
 
@@ -692,6 +742,18 @@ int mkt_decompose_batch(mkt_ctx *c, const void *p, void *digits, int l, int logB
     if ((r = sp.in(p, B * poly_bytes(c), mem, true)) || (r = sd.in(digits, B * (size_t)l * poly_bytes(c), mem, false))) return r;
     HIPCHK(c, mktd::launch_decompose(c->p.W, sp.dev, sd.dev, c->p.N, l, logB, B, c->stream));
     return sd.out(digits);
+}
+
+// MKT_ARITH_EXACT: out = a (*) b in Z_{2^W}[X]/(X^N + 1), exact, for a gadget-digit polynomial a (signed, |a_i| < 2^20) and any b
+int mkt_exact_polymul_batch(mkt_ctx *c, const void *a, const void *b, void *out, size_t B, int mem) {
+    if (!c || !a || !b || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (!c->exact) return fail(c, MKT_ERR_UNSUPPORTED, "mkt_exact_polymul_batch needs an MKT_ARITH_EXACT context");
+    DevGuard dg(c->device);
+    Staged sa{c}, sb{c}, so{c};
+    int r;
+    if ((r = sa.in(a, B * poly_bytes(c), mem, true)) || (r = sb.in(b, B * poly_bytes(c), mem, true)) || (r = so.in(out, B * poly_bytes(c), mem, false))) return r;
+    { Timer tm(c, 3); HIPCHK(c, mktd::launch_exact_polymul(c->logN, c->p.W, c->d_ntt, sa.dev, sb.dev, so.dev, B, c->stream)); }
+    return so.out(out);
 }
 
 int mkt_enable_timing(mkt_ctx *c, int on) {

@@ -119,4 +119,9 @@ hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, h
 hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s);
 bool transform_supported(int logM);
 
+// MKT_ARITH_EXACT, transform level (ntt_exact.hip): tab = psi_rev[N] | psiinv_rev[N] | N^-1, residues mod 2^64 - 2^32 + 1
+hipError_t launch_ntt_fwd(int logN, int W, const uint64_t *tab, const void *p, uint64_t *t, size_t B, hipStream_t s);
+hipError_t launch_ntt_inv(int logN, int W, const uint64_t *tab, const uint64_t *t, void *p, size_t B, hipStream_t s);
+hipError_t launch_exact_polymul(int logN, int W, const uint64_t *tab, const void *a, const void *b, void *out, size_t B, hipStream_t s);
+
 }  // namespace mktd

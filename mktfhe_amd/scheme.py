@@ -197,6 +197,7 @@ class Scheme:
         h = C.c_void_p()
         check(_lib.lib().mkt_ctx_create(C.byref(params.c()), arith, device, C.byref(h)))
         self.h = h
+        self.arith = arith
         self._user_stream = False     # True once set_stream pinned a stream; else torch's current stream is followed
 
     def _follow_torch(self, t):
@@ -403,6 +404,15 @@ class Scheme:
         po, _, ko = _arg(out, self.params.ring_dtype, writable=True, scheme=self)
         self._ck(_lib.lib().mkt_transform_inv_batch(self.h, pt, po, self._batch(kt), mem))
         return ko
+
+    def exact_polymul(self, a, b):
+        """MKT_ARITH_EXACT contexts: a (*) b mod (X^N + 1, 2^W), exactly, for digit polynomials a (signed, small) and ring
+        polynomials b; host arrays (..., N)"""
+        aa = np.ascontiguousarray(a, dtype=self.params.ring_dtype)
+        bb = np.ascontiguousarray(b, dtype=self.params.ring_dtype)
+        out = np.empty_like(aa)
+        self._ck(_lib.lib().mkt_exact_polymul_batch(self.h, _np_ptr(aa), _np_ptr(bb), _np_ptr(out), self._batch(aa), MEM_HOST))
+        return out
 
     def decompose(self, p, l, logB):
         a = np.ascontiguousarray(p, dtype=self.params.ring_dtype)

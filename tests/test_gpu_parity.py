@@ -289,8 +289,10 @@ def test_errors(require_gpu):
         s.gate(0, x, x)
     with pytest.raises(ValueError):       # wrong length (reference: @assert)
         s.gate(0, x[:, :-1], x[:, :-1])
-    with pytest.raises(mk.MktError):
-        mk.Scheme(p, arith=mk.ARITH_EXACT)
+    ex = mk.Scheme(p, arith=mk.ARITH_EXACT)      # transform-level mode: the gate path says so instead of computing something else
+    with pytest.raises(mk.MktError, match="Float64-reference gate path"):
+        ex.gate(0, x, x)
+    ex.close()
     s.close()
 
 
@@ -815,3 +817,42 @@ def test_many_party_sets_at_full_size(require_gpu, p, nfold):
         acc, ab = out, ~(ab & bits[i::k])
     assert np.array_equal(mk.lwe_decrypt(acc, keys, p), ab)
     sg.close()
+
+
+@pytest.mark.parametrize("N,W", [(32, 32), (64, 64), (256, 32), (1024, 32), (1024, 64), (2048, 64), (4096, 32)])
+def test_exact_mode_integer_ntt(require_gpu, N, W):
+    """MKT_ARITH_EXACT, transform level: the negacyclic NTT over Z_p[X]/(X^N+1), p = 2^64 - 2^32 + 1.  Forward transforms
+    equal a pure-Python restatement residue for residue (same network and table as the reference's FFT, fft.jl:105-155),
+    forward -> inverse is the identity on edge words, and the product of a gadget-digit polynomial with a ring polynomial
+    equals the exact schoolbook product mod 2^W (what polynomial.jl:99-113 approximates in Float64) -- bit-exact, also
+    where the Float64 path is one below (32-bit ring) or 2^33 off (64-bit ring)."""
+    import ref_ntt as R
+    rng = np.random.default_rng(N + W)
+    p = mk.CGGIparam.scaled(n=8, N=N, W=W)
+    ex = mk.Scheme(p, arith=mk.ARITH_EXACT)
+    B = 5
+    polys = np.stack([edge_words(W, N, rng) for _ in range(B)]).astype(p.ring_dtype)
+    t = ex.transform_fwd(polys).view(np.uint64)                       # N residues per polynomial
+    assert t.shape == (B, N)
+    if N <= 1024:
+        for b in range(2):
+            assert [int(v) for v in t[b]] == R.fwd(polys[b], W), (N, W, b)
+    back = ex.transform_inv(t.view(np.complex128))
+    if N <= 1024:
+        assert [int(v) for v in back[0]] == R.inv([int(v) for v in t[0]], W)
+    # the inverse returns the integer of least magnitude: the identity wherever |signed word| < p / 2 = 2^63 - 2^31
+    small = np.abs(polys.astype(np.int64 if W == 64 else np.int32).astype(np.float64)) < 2.0**62
+    assert np.array_equal(back[small], polys[small]) and small.mean() > 0.4
+    if W == 32:
+        assert small.all()
+    # digit polynomial (balanced digits of every shipped gadget base) times key-like polynomial
+    for logB in (2, 9, 16):
+        a = rng.integers(-(1 << (logB - 1)), 1 << (logB - 1), (B, N)).astype(np.int64)
+        a[0, :4] = [-(1 << (logB - 1)), (1 << (logB - 1)) - 1, 0, -1]
+        aw = a.astype(np.uint64).astype(p.ring_dtype) if W == 64 else (a & 0xFFFFFFFF).astype(np.uint32)
+        bw = polys
+        got = ex.exact_polymul(aw, bw)
+        for b in range(B):
+            ref = O.negacyclic(aw[b].astype(np.uint64) & np.uint64((1 << W) - 1), bw[b].astype(np.uint64), W)
+            assert np.array_equal(got[b].astype(np.uint64), ref), (N, W, logB, b)
+    ex.close()

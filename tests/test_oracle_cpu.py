@@ -215,6 +215,27 @@ def test_forward_transform_edge_words_in_both_halves():
         assert np.array_equal(z.real.view(np.uint64), (-zl.imag).view(np.uint64)) and np.array_equal(z.imag.view(np.uint64), zl.real.view(np.uint64))
 
 
+def test_exact_ntt_restatement_against_schoolbook():
+    """tests/ref_ntt.py (the checker of the MKT_ARITH_EXACT transforms on the GPU) against the oracle's exact schoolbook
+    product: NTT(a) . NTT(b) -> inverse == a (*) b mod (X^N + 1, 2^W) for digit polynomials a, and fwd -> inv = id"""
+    import ref_ntt as R
+    rng = np.random.default_rng(81)
+    for N, W in ((32, 32), (128, 64), (256, 32)):
+        a = rng.integers(-256, 256, N).astype(np.int64)
+        aw = a.astype(np.uint64) & np.uint64((1 << W) - 1)
+        b = rng.integers(0, 1 << 63, N, dtype=np.uint64) & np.uint64((1 << W) - 1)
+        ref = O.negacyclic(aw, b, W)
+        got = np.zeros(N, dtype=np.uint64)
+        za = R.fwd(aw, W)
+        for h in range(W // 32):                                  # 32-bit pieces of b keep every true coefficient below p / 2
+            piece = [(int(x) >> (32 * h)) & 0xFFFFFFFF for x in b]
+            zb = R.fwd(piece, 64)
+            prod = R.inv([x * y % R.P for x, y in zip(za, zb)], 64)
+            got = (got + (np.array(prod, dtype=np.uint64) << np.uint64(32 * h))) & np.uint64((1 << W) - 1)
+        assert np.array_equal(got, ref), (N, W)
+        assert R.inv(R.fwd(aw, W), W) == [int(x) for x in aw]
+
+
 def test_monomial_table_semantics():
     N = 64
     f = O.Ffter(N, 32)
