@@ -59,9 +59,12 @@ enum { MKT_NAND = 0, MKT_AND = 1, MKT_OR = 2, MKT_XOR = 3, MKT_XNOR = 4, MKT_NOR
 enum {
     MKT_ARITH_F64REF = 0, /* the reference's Float64 twisted FFT, operation for operation (fft.jl) */
     MKT_ARITH_EXACT = 1   /* exact integer arithmetic: the negacyclic NTT over Z_p[X]/(X^N+1), p = 2^64 - 2^32 + 1.
-                             Transform-level entry points only (mkt_transform_*_batch, mkt_exact_polymul_batch,
-                             mkt_decompose_batch, mkt_modswitch_batch, mkt_not_batch); the gate path is Float64-reference
-                             only and returns MKT_ERR_UNSUPPORTED on such a context */
+                             Transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch,
+                             mkt_decompose_batch, mkt_modswitch_batch, mkt_not_batch) for every scheme; the gate path
+                             (mkt_load_brk/ksk, mkt_keygen_device, mkt_gate, mkt_bootstrap, mkt_blindrotate,
+                             mkt_keyswitch) for MKT_CGGI with a 32-bit ring, whose ciphertexts are valid but NOT the
+                             reference's words (no Float64 truncation); other schemes return MKT_ERR_UNSUPPORTED
+                             there */
 };
 /* where batch pointers live */
 enum { MKT_MEM_DEVICE = 0, MKT_MEM_HOST = 1 };

@@ -103,6 +103,7 @@ size_t poly_bytes(const mkt_ctx *c) { return (size_t)c->p.N * c->sh.word; }
 
 // transform `npolys` coefficient-form polynomials (host) into TransPolys at `dst` (device)
 int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt) {
+    if (c->exact && fmt != MKT_FMT_INT_COEFF) return fail(c, MKT_ERR_UNSUPPORTED, "an MKT_ARITH_EXACT context takes keys in integer form (MKT_FMT_INT_COEFF)");
     if (fmt == MKT_FMT_F64_FFT) {   // the reference's Trans* values: copy, then natural -> device point order
         cplx *tmpc = nullptr;
         const size_t nb = npolys * (size_t)c->M * sizeof(cplx);
@@ -118,7 +119,8 @@ int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt
     void *tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, npolys * poly_bytes(c)));
     hipError_t e = hipMemcpyAsync(tmp, host, npolys * poly_bytes(c), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, 1, c->stream);
+    if (e == hipSuccess) e = c->exact ? mktd::launch_ntt_fwd(c->logN, c->p.W, c->d_ntt, tmp, reinterpret_cast<uint64_t *>(dst), npolys, c->stream)   // N residues = the bytes of M complex
+                               : mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, 1, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) return hipfail(c, e, "key pre-transform");
@@ -222,6 +224,12 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         HIPCHK(c, mktd::launch_ccs_blindrotate(c->logM, p.W, q, B, c->stream));
         return MKT_OK;
     }
+    if (c->exact) {          // CGGI, RLWE length 1, 32-bit ring (exact_gate_ok): every product exact mod 2^32
+        Timer tm(c, 1);
+        HIPCHK(c, mktd::launch_exact_blindrotate(c->logN, c->d_ntt, reinterpret_cast<const uint64_t *>(c->ks->d_brk), reinterpret_cast<const uint64_t *>(c->ks->d_monomial),
+                                                 lwe, stride, pre, p.n, p.l_gsw, p.logB_gsw, (uint32_t *)acc, B, c->stream));
+        return MKT_OK;
+    }
     if (!mkt::is_kms(p.scheme)) {
         mktd::RotArgs a = rot_args(c, lwe, stride, pre);
         a.init_mode = 0; a.out_mode = 0; a.acc_io = acc;
@@ -303,15 +311,9 @@ constexpr uint64_t GLP = 0xFFFFFFFF00000001ull;
 uint64_t gl_mulmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % GLP); }
 uint64_t gl_powmod(uint64_t a, uint64_t e) { uint64_t r = 1; while (e) { if (e & 1) r = gl_mulmod(r, a); a = gl_mulmod(a, a); e >>= 1; } return r; }
 
-int create_exact(const mkt_params &p, int logN, int device, mkt_ctx **out) {
-    if (logN < 5 || logN > 12) return fail(nullptr, MKT_ERR_UNSUPPORTED, "EXACT mode: N must be 32..4096");
-    auto *c = new mkt_ctx();
-    c->ks = std::make_shared<KeySet>();
-    c->ks->device = device;
-    c->p = p; c->sh = mkt::shape_of(p); c->device = device; c->logN = logN; c->logM = logN - 1; c->M = p.N / 2; c->exact = true;
-    DevGuard dg(device);
-    const int N = p.N;
-    // psi = a primitive 2N-th root of unity: 7 generates Z_p^*, (p - 1) / 2N is an integer for N <= 2^31
+// psi_rev[N] | psiinv_rev[N] | N^-1 for the transform of size N (psi = a primitive 2N-th root of unity: 7 generates Z_p^*)
+int upload_ntt_tables(mkt_ctx *c) {
+    const int N = c->p.N, logN = c->logN;
     const uint64_t psi = gl_powmod(7, (GLP - 1) / (2 * (uint64_t)N)), psiinv = gl_powmod(psi, GLP - 2);
     std::vector<uint64_t> tab((size_t)2 * N + 1);
     for (int i = 0; i < N; i++) {
@@ -320,13 +322,14 @@ int create_exact(const mkt_params &p, int logN, int device, mkt_ctx **out) {
         tab[i] = gl_powmod(psi, (uint64_t)r); tab[(size_t)N + i] = gl_powmod(psiinv, (uint64_t)r);
     }
     tab[(size_t)2 * N] = gl_powmod((uint64_t)N, GLP - 2);
-    hipError_t e = hipMalloc((void **)&c->d_ntt, tab.size() * 8);
-    if (e == hipSuccess) e = hipMemcpy(c->d_ntt, tab.data(), tab.size() * 8, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { std::string m = std::string("EXACT tables: ") + hipGetErrorString(e); mkt_ctx_destroy(c); g_create_error = m; return MKT_ERR_HIP; }
-    *out = c;
+    HIPCHK(c, hipMalloc((void **)&c->d_ntt, tab.size() * 8));
+    HIPCHK(c, hipMemcpy(c->d_ntt, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     return MKT_OK;
 }
-#define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; an MKT_ARITH_EXACT context offers the transform-level entry points only (mkt_transform_*_batch, mkt_exact_polymul_batch, mkt_decompose_batch)"); } while (0)
+// the gate path of an EXACT context: CGGI with RLWE length 1 on the 32-bit ring (every true product coefficient < p / 2)
+bool exact_gate_ok(const mkt_ctx *c) { return c->p.scheme == MKT_CGGI && c->p.k == 1 && c->p.W == 32; }
+#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI (RLWE length 1, 32-bit ring) only; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
+#define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; not offered by an MKT_ARITH_EXACT context"); } while (0)
 
 }  // namespace
 
@@ -353,12 +356,12 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(nullptr, MKT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", the engine is built for gfx950 only");
 
-    if (arith_mode == MKT_ARITH_EXACT) return create_exact(*params, logN, device, out);
     auto *c = new mkt_ctx();
     c->ks = std::make_shared<KeySet>();
     c->ks->device = device;
     c->p = *params; c->sh = mkt::shape_of(*params); c->device = device;
     c->logN = logN; c->logM = logN - 1; c->M = params->N / 2;
+    c->exact = arith_mode == MKT_ARITH_EXACT;
     DevGuard dg(device);
     auto bail = [&](int code) { std::string m = c->err; mkt_ctx_destroy(c); g_create_error = m; return code; };
     if (!dg.ok) { c->err = "hipSetDevice failed"; return bail(MKT_ERR_HIP); }
@@ -394,6 +397,7 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     CK(hipMemcpy(c->ks->d_slot_row, sr.data(), sr.size() * sizeof(int), hipMemcpyHostToDevice));
 #undef CK
     int r = upload_twiddles(c);
+    if (!r && c->exact) r = upload_ntt_tables(c);
     if (!r) r = build_monomial(c);
     if (r) return bail(r);
     *out = c;
@@ -477,7 +481,7 @@ int mkt_get_monomial(mkt_ctx *c, int e, double *out_host) {
 
 int mkt_load_brk(mkt_ctx *c, int party, const void *data, int fmt) {
     if (!c || !data || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_EXACT_GATE(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     int r = upload_polys(c, data, (size_t)c->p.n * c->sh.brk_polys, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, fmt);
@@ -487,7 +491,7 @@ int mkt_load_brk(mkt_ctx *c, int party, const void *data, int fmt) {
 
 int mkt_load_ksk(mkt_ctx *c, int party, const uint32_t *data) {
     if (!c || !data || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_EXACT_GATE(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     const size_t rows = (size_t)c->sh.ksk_kr * c->p.N * c->sh.ksk_drows * c->p.f, n1 = (size_t)c->p.n + 1;
@@ -533,7 +537,7 @@ int mkt_load_crs(mkt_ctx *c, const void *a, int fmt) {
 // (keygen.hip: the seeded streams of mkt_client_party_keygen, identical words), pre-transformed in place of an upload.
 static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, const void *crs, void *brk_out, uint32_t *ksk_out) {
     if (!c || !K || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_EXACT_GATE(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     const mkt_params &p = c->p;
     if (std::memcmp(&K->p, &p, sizeof(mkt_params)) != 0 || K->party != party) return fail(c, MKT_ERR_ARG, "mkt_keygen_device: the party's keys were made for other parameters / another party index");
@@ -566,7 +570,8 @@ static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, 
     else { a.kr = c->sh.kr; a.l = p.l_gsw; a.logB = p.logB_gsw; a.zoff = 0; }
     e = mktd::launch_keygen_brk(a, unienc ? 1 : 0, c->stream);
     if (e == hipSuccess && brk_out) e = hipMemcpyAsync(brk_out, d_out, brk_polys_total * poly_bytes(c), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, brk_polys_total, 1, c->stream);
+    if (e == hipSuccess) e = c->exact ? mktd::launch_ntt_fwd(c->logN, p.W, c->d_ntt, d_out, reinterpret_cast<uint64_t *>(c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx), brk_polys_total, c->stream)
+                               : mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, brk_polys_total, 1, c->stream);
     uint32_t *ksk = c->ks->d_ksk + (size_t)party * c->ks->ksk_party_words;
     if (e == hipSuccess) e = hipMemsetAsync(ksk, 0, c->ks->ksk_party_words * sizeof(uint32_t), c->stream);
     a.zoff = mkt::is_kms(p.scheme) ? 1 : 0;      // the key switch targets the uni key of the KMS schemes
@@ -594,7 +599,7 @@ int mkt_keygen_device_export(mkt_ctx *c, int party, const mkt_client_party *K, c
 // debug / test read-back of a party's key-switching key in the host layout of mkt_load_ksk
 int mkt_get_ksk(mkt_ctx *c, int party, uint32_t *out_host) {
     if (!c || !out_host || party < 0 || party >= c->sh.nparty) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_EXACT_GATE(c);
     DevGuard dg(c->device);
     const size_t rows = (size_t)c->sh.ksk_kr * c->p.N * c->sh.ksk_drows * c->p.f, n1 = (size_t)c->p.n + 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -606,7 +611,7 @@ int mkt_get_ksk(mkt_ctx *c, int party, uint32_t *out_host) {
 
 int mkt_gate_batch(mkt_ctx *c, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem) {
     if (!c || !x || !y || !out || !mem_ok(mem) || op < MKT_NAND || op > MKT_NOR) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_EXACT_GATE(c);
     int r;
     if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
     DevGuard dg(c->device);
@@ -636,7 +641,7 @@ int mkt_not_batch(mkt_ctx *c, uint32_t *x, size_t B, int mem) {
 
 int mkt_bootstrap_batch(mkt_ctx *c, uint32_t *lwe, size_t B, int mem) {
     if (!c || !lwe || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_EXACT_GATE(c);
     int r;
     if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
     DevGuard dg(c->device);
@@ -668,7 +673,7 @@ int mkt_modswitch_batch(mkt_ctx *c, const uint32_t *lwe, uint32_t *atilde, uint3
 
 int mkt_blindrotate_batch(mkt_ctx *c, const uint32_t *atilde, void *acc, size_t B, int mem) {
     if (!c || !atilde || !acc || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_EXACT_GATE(c);
     int r;
     if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, false))) return r;
     DevGuard dg(c->device);
@@ -701,7 +706,7 @@ int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, siz
 
 int mkt_keyswitch_batch(mkt_ctx *c, const void *acc, uint32_t *out, size_t B, int mem) {
     if (!c || !acc || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_EXACT_GATE(c);
     int r;
     if ((r = check_ready(c, false, true))) return r;
     DevGuard dg(c->device);

@@ -203,6 +203,78 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_polymul_kernel(cons
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Blind rotation with EXACT products (CGGI, RLWE length 1, 32-bit ring): bootstrapping.jl:32-76 with every
+// transform-domain product replaced by the exact negacyclic product mod 2^32 -- digit transforms, row MACs (:63-68),
+// monomial multiply (:71) and inverse (:72) all over Z_p, one exact lift per CMux step.  True coefficients stay below
+// 2 * 2l * N * 2^(logB-1) * 2^31 < p / 2 for every shipped gadget.  One workgroup of N / 8 threads per rotation; the
+// accumulator lives in registers (slot e = coefficient e*NT + t).  Tables are in the transform's natural order.
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(const uint64_t *__restrict__ tab, const uint64_t *__restrict__ brk,
+                                                                              const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe,
+                                                                              int lwe_stride, int pre_switched, int n, int l, int logB, uint32_t *__restrict__ acc_io) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
+    uint64_t *psi_l = lds + N, *psii_l = psi_l + N;
+    const int t = threadIdx.x;
+    for (int i = t; i < N; i += NT) { psi_l[i] = tab[i]; psii_l[i] = tab[N + i]; }
+    __syncthreads();
+    const uint64_t ninv = tab[2 * N];
+    const size_t rot = blockIdx.x;
+    const uint32_t *at_src = lwe + rot * (size_t)lwe_stride;
+    uint32_t *accg = acc_io + rot * 2 * (size_t)N;
+    const Gadget<uint32_t> gd(l, logB);
+    uint32_t acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[c][e] = accg[c * N + e * NT + t];
+    const int msbit = 32 - LOGN - 1;
+    for (int i = 0; i < n; i++) {
+        const uint32_t v0 = at_src[i];
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+        if (at == 0) continue;                                           // :48
+        uint64_t tacc[2][8];
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) tacc[pp][e] = 0;
+        for (int c = 0; c < 2; c++) {
+            uint32_t tp[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) tp[e] = gd.prep(c ? acc[1][e] : acc[0][e]);      // :50-51 decompto!
+            for (int j = 0; j < l; j++) {
+                uint64_t z[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) { const int d = gd.digit(tp[e], j); z[e] = d >= 0 ? (uint64_t)d : GL_P - (uint64_t)(-d); }
+                ntt_forward<LOGN>(z, psi_l, lds, t);
+                const uint64_t *row = brk + (((size_t)i * 2 * l + (size_t)(c * l + j)) * 2) * N + 8 * t;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {                            // :63-68, exactly
+                    tacc[0][e] = gl_add(tacc[0][e], gl_mul(z[e], row[e]));
+                    tacc[1][e] = gl_add(tacc[1][e], gl_mul(z[e], row[N + e]));
+                }
+            }
+        }
+        const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) {
+            uint64_t s2[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) s2[e] = gl_mul(tacc[pp][e], mrow[e]);   // :71
+            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s2, psii_l, lds, t);      // :72
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[pp][e] += from_residue<uint32_t>(gl_mul(s2[e], ninv));   // :73
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) accg[c * N + e * NT + t] = acc[c][e];
+}
+
 template <typename K>
 static hipError_t ntt_set_lds(K kern, size_t bytes) {
     if (bytes > 48 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -257,6 +329,17 @@ hipError_t launch_exact_polymul(int logN, int W, const uint64_t *tab, const void
             hipLaunchKernelGGL((exact_polymul_kernel<LN, uint64_t>), dim3(grid), dim3(1 << (LN - NLR)), lds, s, tab, (const uint64_t *)a, (const uint64_t *)b, (uint64_t *)out, B); }
         else { hipError_t e = ntt_set_lds(exact_polymul_kernel<LN, uint32_t>, lds); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((exact_polymul_kernel<LN, uint32_t>), dim3(grid), dim3(1 << (LN - NLR)), lds, s, tab, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, B); }
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
+                                    int pre_switched, int n, int l, int logB, uint32_t *acc, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    MKT_NTT_DISPATCH(logN, {
+        const size_t lds = (size_t)3 * (1 << LN) * 8;
+        hipError_t e = ntt_set_lds(exact_blindrotate_kernel<LN>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((exact_blindrotate_kernel<LN>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tab, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, acc);
     });
     return hipGetLastError();
 }

@@ -289,9 +289,11 @@ def test_errors(require_gpu):
         s.gate(0, x, x)
     with pytest.raises(ValueError):       # wrong length (reference: @assert)
         s.gate(0, x[:, :-1], x[:, :-1])
-    ex = mk.Scheme(p, arith=mk.ARITH_EXACT)      # transform-level mode: the gate path says so instead of computing something else
-    with pytest.raises(mk.MktError, match="Float64-reference gate path"):
-        ex.gate(0, x, x)
+    pk = mk.KMS2party.scaled(n=8, N=256)          # EXACT evaluates CGGI gates only: other schemes say so instead of computing something else
+    ex = mk.Scheme(pk, arith=mk.ARITH_EXACT)
+    xk = np.zeros((2, pk.lwe_len), dtype=np.uint32)
+    with pytest.raises(mk.MktError, match="MKT_ARITH_EXACT evaluates gates for CGGI"):
+        ex.gate(0, xk, xk)
     ex.close()
     s.close()
 
@@ -856,3 +858,40 @@ def test_exact_mode_integer_ntt(require_gpu, N, W):
             ref = O.negacyclic(aw[b].astype(np.uint64) & np.uint64((1 << W) - 1), bw[b].astype(np.uint64), W)
             assert np.array_equal(got[b].astype(np.uint64), ref), (N, W, logB, b)
     ex.close()
+
+
+@pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=12, N=256), mk.CGGIparam.scaled(n=10, N=1024), mk.CGGI_N1024_l2.scaled(n=10),
+                               mk.CGGIparam.scaled(n=6, N=2048, l_gsw=4, logB_gsw=7)], ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-l{p.l_gsw}")
+def test_exact_mode_cggi_gates(require_gpu, p):
+    """MKT_ARITH_EXACT gate path (CGGI, 32-bit ring): blind rotation with integer-NTT products.  Accumulators and gate
+    outputs equal the exact-arithmetic restatement (tests/ref_exact.py: the oracle's integer steps + exact schoolbook
+    products) word for word, and decrypt."""
+    import ref_exact as RX
+    crs, keys = keygen(p, 71)
+    so = oracle_scheme(p, crs, keys)
+    sx = mk.Scheme(p, arith=mk.ARITH_EXACT)
+    sx.load_party(0, keys[0])
+    B = 4
+    bits = np.array([1, 0, 1, 1, 0, 1, 0, 0], dtype=bool)
+    c = encrypt_bits(p, keys, bits, seed=7100)
+    x, y = c[:B], c[B:]
+    lin = np.stack([O.gate_linear(0, x[j], y[j]) for j in range(B)])
+    at, bt = sx.modswitch(lin)
+    at[0, :3] = [0, 2 * p.N, p.N]
+    acc0 = np.stack([so.testvector(bt[j]) for j in range(B)])
+    acc_x = sx.blindrotate_(at, acc0.astype(np.uint32).copy())
+    for j in range(B):
+        assert np.array_equal(acc_x[j].astype(np.uint64).reshape(-1), RX.blindrotate(p, keys[0].brk, at[j], acc0[j])), f"exact blindrotate {j}"
+    for op in (0, 3, 5):
+        out = sx.gate(op, x, y)
+        assert np.array_equal(out, np.stack([RX.gate(p, so, keys[0].brk, op, x[j], y[j]) for j in range(B)])), f"exact gate {op}"
+        assert np.array_equal(mk.lwe_decrypt(out, keys[0], p), GATE_FUNCS[op](bits[:B], bits[B:]))
+    # one CMux step from the same accumulator: the Float64 path is the exact value or one below it per coefficient
+    # (truncating native(), arithmetic.jl:1-9); over many steps the two diverge in the words, not in the phase
+    sf = gpu_scheme(p, crs, keys)
+    one = np.zeros_like(at); one[:, 0] = at[:, 1]
+    e1 = sx.blindrotate_(one, acc0.astype(np.uint32).copy()).astype(np.int64)
+    f1 = sf.blindrotate_(one, acc0.astype(np.uint32).copy()).astype(np.int64)
+    d = (e1 - f1 + (1 << 31)) % (1 << 32) - (1 << 31)
+    assert d.min() >= 0 and d.max() <= 2
+    sx.close(); sf.close()
