@@ -220,6 +220,8 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         q.tw = c->twp(); q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.logN = c->logN; q.k = p.k;
         q.l = p.l_uni; q.logB = p.logB_uni; q.brk = c->ks->d_brk; q.brk_party_stride = c->ks->brk_party_cplx; q.pub_b = c->ks->d_pub; q.crs = c->ks->d_crs;
         q.monomial = c->ks->d_monomial; q.acc = acc; q.scratch = scratch; q.vscratch = lev;
+        q.stagger = 0;
+        if (const char *v = getenv("MKT_CCS_STAGGER")) q.stagger = atoi(v);
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_ccs_blindrotate(c->logM, p.W, q, B, c->stream));
         return MKT_OK;

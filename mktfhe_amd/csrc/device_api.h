@@ -72,6 +72,7 @@ struct CcsArgs {
     void *acc;                // [B][1+k][N] ring words, in place
     cplx *scratch;            // [B][k+1][M]
     void *vscratch;           // [B][N] ring words
+    int stagger;              // start-up delay between the workgroups that share a compute unit, in units of 64 cycles (0 = off)
 };
 
 struct KsArgs {

@@ -243,7 +243,8 @@ __device__ __forceinline__ void exchange_lane_odd_inv(cplx (&z)[NB][4], const La
 
 // which route the exchange between two windows of the schedule takes (compile time): 0 LDS, 1 in-wave 4x4, 2 odd window
 // MO >= 0: per-kernel override -- low byte = exchange-route mode (0xff = the library default MKT_LANE_EXCHANGE), bit 8 =
-// ONE staging buffer with a barrier on both sides of every LDS exchange (kernels whose LDS budget has no room for two)
+// ONE staging buffer with a barrier on both sides of every LDS exchange (kernels whose LDS budget has no room for two),
+// bit 9 = single transforms use the staging-buffer stride of paired ones (see exchange)
 template <int LOGM, int LOGR, int MO = -1>
 struct Route {
     static constexpr bool SB = MO >= 0 && (MO & 0x100) != 0;
@@ -276,7 +277,10 @@ __device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *lds, in
     else {
         constexpr bool SB = Route<LOGM, LOGR, MO>::SB;
         if (SB) __syncthreads();                     // every reader of the single buffer is done before it is rewritten
-        exchange_lds<LOGM, LOGR, NB>(z, lds + (SB ? 0 : Plan<LOGM, LOGR, NB>::buf_off(PASS)), t, LO_FROM, LO_TO);
+        // bit 9 of MO: a single transform in a kernel that also runs paired ones keeps the PAIRED buffer stride, so its
+        // two staging buffers lie inside the paired ones of the same parity and the guard logic holds across both kinds
+        constexpr bool S2 = MO >= 0 && (MO & 0x200) != 0 && NB == 1;
+        exchange_lds<LOGM, LOGR, NB>(z, lds + (SB ? 0 : S2 ? Plan<LOGM, LOGR, 2>::buf_off(PASS) : Plan<LOGM, LOGR, NB>::buf_off(PASS)), t, LO_FROM, LO_TO);
     }
 }
 

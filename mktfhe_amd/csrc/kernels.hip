@@ -19,6 +19,21 @@
 #define MKT_IN_TU(n) 1
 #endif
 
+#ifndef MKT_CCS_MO
+#define MKT_CCS_MO 0xff   // exchange-route mode of the CCS kernel's transforms (fft_device.h Route): 0xff = library default
+#endif
+#ifndef MKT_CCS_LOOPED
+#define MKT_CCS_LOOPED 1  // CCS kernel: one loop over the input polynomials of a step (each transform kind once in the code)
+#endif
+#ifndef MKT_CCS_PAIR
+#define MKT_CCS_PAIR 0    // CCS kernel: the digit transforms of a decomposition run two at a time (measured: -2..-5 %)
+#endif
+#ifndef MKT_CCS_ABL
+#define MKT_CCS_ABL 0     // development ablations (wrong results, timing only): 1 = no key-row loads
+#endif
+#ifndef MKT_CCS_PROBE
+#define MKT_CCS_PROBE 0   // development: workgroup 0 prints the s_memtime ticks its first wave spent in each phase of the CCS step
+#endif
 #ifndef MKT_CCS_PF
 #define MKT_CCS_PF 1      // CCS kernel: key rows of a digit requested before its forward transform (CCS2party +3 %, CCS8party +1 %)
 #endif
@@ -909,9 +924,10 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
 // computed first and parked in registers.
 // ------------------------------------------------------------------------------------------------
 template <int LOGM, typename WORD>
-__global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel(const CcsArgs a) {
-    using P = Plan<LOGM, LOGR>;
+__global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2))) void ccs_blindrotate_kernel(const CcsArgs a) {
+    using P = Plan<LOGM, LOGR, MKT_CCS_PAIR ? 2 : 1>;
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
+    constexpr int MO1 = (MKT_CCS_MO & 0xff) | (MKT_CCS_PAIR ? 0x200 : 0), MO2 = MKT_CCS_MO & 0xff;   // single / paired transforms
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     cplx *psi_l = lds + P::LDS_CPLX;
     const int t = threadIdx.x;
@@ -919,6 +935,9 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
     for (int i = t; i < M; i += NT) psi_l[i] = a.tw.psi[i];
     __syncthreads();
     const size_t g = blockIdx.x;
+    // the workgroups that share a compute unit (every 256th under round-robin dispatch) run the same loop in lock-step
+    // and then want the VALU and the LDS at the same moments: a start-up delay de-phases them (speed only)
+    for (int s = 0, ns = a.stagger * (int)((g >> 8) & 3); s < ns; s++) __builtin_amdgcn_s_sleep(1);
     const int k = a.k, l = a.l, n = a.n;
     WORD *acc = reinterpret_cast<WORD *>(a.acc) + g * (size_t)(k + 1) * N;
     cplx *sc = a.scratch + g * (size_t)(k + 1) * M;
@@ -932,25 +951,56 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
 #pragma unroll
     for (int e = 0; e < R; e++) rt[e] = a.tw.roots[e * NT + t];
 
+#if MKT_CCS_PROBE
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = __builtin_amdgcn_s_memtime();
+#define CCS_PROBE(K) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[K] += now_ - plast; plast = now_; }
+#else
+#define CCS_PROBE(K)
+#endif
     // u and v of one input polynomial q (:279-294): tu = sum_j dig_j * d[j]; tv = -/+ sum_j dig_j * (crs | b_{q-1})[j]
     auto uv = [&](int q, const cplx *ud, cplx (&tu)[R], cplx (&tvq)[R]) {
         WORD tp[R][2];
 #pragma unroll
-        for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(acc[(size_t)q * N + e * NT + t]); tp[e][1] = gd.prep(acc[(size_t)q * N + M + e * NT + t]); }
+        for (int e = 0; e < R; e++) {
+            if (MKT_CCS_ABL == 2) { tp[e][0] = gd.prep((WORD)(q * 2654435761u + e * NT + t)); tp[e][1] = gd.prep((WORD)(q * 40503u + t * 2246822519u + e)); continue; }
+            tp[e][0] = gd.prep(acc[(size_t)q * N + e * NT + t]); tp[e][1] = gd.prep(acc[(size_t)q * N + M + e * NT + t]);
+        }
+#if MKT_CCS_PROBE == 2
+        CCS_PROBE(1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CCS_PROBE(6)
+#endif
 #pragma unroll
         for (int e = 0; e < R; e++) { tu[e].re = tu[e].im = 0.0; tvq[e].re = tvq[e].im = 0.0; }
         const cplx *vk = q == 0 ? a.crs : a.pub_b + (size_t)(q - 1) * l * M;
-        for (int j = 0; j < l; j++) {
+        int j = 0;
+        if (MKT_CCS_PAIR) {
+            for (; j + 1 < l; j += 2) {
+                cplx z2[2][R];
+                digit_points<WORD, R>(z2[0], tp, gd, j, rt);
+                digit_points<WORD, R>(z2[1], tp, gd, j + 1, rt);
+                fft_forward<LOGM, LOGR, 2, MO2>(z2, psi_l, lds, t, xs.lx);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const cplx *kd = ud + (size_t)(j + h) * M, *kv = vk + (size_t)(j + h) * M;
+#pragma unroll
+                    for (int e = 0; e < R; e++) {
+                        tu[e] = cadd(tu[e], cmul(z2[h][e], kd[dp[e]]));
+                        const cplx pr = cmul(z2[h][e], kv[dp[e]]);
+                        tvq[e] = q == 0 ? csub(tvq[e], pr) : cadd(tvq[e], pr);
+                    }
+                }
+            }
+        }
+        for (; j < l; j++) {
             cplx z[R];
             const cplx *kd = ud + (size_t)j * M, *kv = vk + (size_t)j * M;
             cplx kdr[R], kvr[R];
             if (MKT_CCS_PF) {                                                    // key rows requested before the transform that needs them
 #pragma unroll
-                for (int e = 0; e < R; e++) { kdr[e] = kd[dp[e]]; kvr[e] = kv[dp[e]]; }
+                for (int e = 0; e < R; e++) { kdr[e] = MKT_CCS_ABL == 1 ? rt[e] : kd[dp[e]]; kvr[e] = MKT_CCS_ABL == 1 ? rt[R - 1 - e] : kv[dp[e]]; }
                 __builtin_amdgcn_sched_barrier(0);
             }
             digit_points<WORD, R>(z, tp, gd, j, rt);
-            fft_forward1<LOGM>(z, psi_l, lds, t, xs);
+            fft_forward<LOGM, LOGR, 1, MO1>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t, xs.lx);
 #pragma unroll
             for (int e = 0; e < R; e++) {
                 tu[e] = cadd(tu[e], cmul(z[e], MKT_CCS_PF ? kdr[e] : kd[dp[e]]));
@@ -964,23 +1014,38 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
         WORD tp[R][2];
 #pragma unroll
         for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(vw[e][0]); tp[e][1] = gd.prep(vw[e][1]); }
-        for (int j = 0; j < l; j++) {
+        int j = 0;
+        if (MKT_CCS_PAIR) {
+            for (; j + 1 < l; j += 2) {
+                cplx z2[2][R];
+                digit_points<WORD, R>(z2[0], tp, gd, j, rt);
+                digit_points<WORD, R>(z2[1], tp, gd, j + 1, rt);
+                fft_forward<LOGM, LOGR, 2, MO2>(z2, psi_l, lds, t, xs.lx);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const cplx *fb = uf + (size_t)(2 * (j + h)) * M, *fa = fb + M;
+#pragma unroll
+                    for (int e = 0; e < R; e++) { tb[e] = cadd(tb[e], cmul(z2[h][e], fb[dp[e]])); ta[e] = cadd(ta[e], cmul(z2[h][e], fa[dp[e]])); }
+                }
+            }
+        }
+        for (; j < l; j++) {
             cplx z[R];
             const cplx *fb = uf + (size_t)(2 * j) * M, *fa = fb + M;
             cplx fbr[R], far[R];
             if (MKT_CCS_PF) {
 #pragma unroll
-                for (int e = 0; e < R; e++) { fbr[e] = fb[dp[e]]; far[e] = fa[dp[e]]; }
+                for (int e = 0; e < R; e++) { fbr[e] = MKT_CCS_ABL == 1 ? rt[e] : fb[dp[e]]; far[e] = MKT_CCS_ABL == 1 ? rt[R - 1 - e] : fa[dp[e]]; }
                 __builtin_amdgcn_sched_barrier(0);
             }
             digit_points<WORD, R>(z, tp, gd, j, rt);
-            fft_forward1<LOGM>(z, psi_l, lds, t, xs);
+            fft_forward<LOGM, LOGR, 1, MO1>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t, xs.lx);
 #pragma unroll
             for (int e = 0; e < R; e++) { tb[e] = cadd(tb[e], cmul(z[e], MKT_CCS_PF ? fbr[e] : fb[dp[e]])); ta[e] = cadd(ta[e], cmul(z[e], MKT_CCS_PF ? far[e] : fa[dp[e]])); }
         }
     };
     auto inv_words = [&](cplx (&z)[R], WORD (&w)[R][2]) {                        // fft.jl:74-81
-        fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t, xs.lx);
+        fft_inverse<LOGM, LOGR, 1, true, MO1>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t, xs.lx);
 #pragma unroll
         for (int e = 0; e < R; e++) {
             const cplx v = cmul(z[e], a.tw.rootsinv[e * NT + t]);
@@ -997,37 +1062,55 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
             if (at == 0) continue;                                               // :261
             const cplx *uni = a.brk + (size_t)idx * a.brk_party_stride + (size_t)i * 3 * l * M;
             const cplx *ud = uni, *uf = uni + (size_t)l * M;
-            cplx ta[R], tb[R], tu[R], tvq[R];
-            WORD vw[R][2];
-            // u of the current party's mask polynomial first; its v is parked in the scratch
-            uv(np, ud, ta, tvq);
-            inv_words(tvq, vw);                                                  // :298-300
+#if MKT_CCS_LOOPED
+            // One loop over the input polynomials in the order the reference's sums need: the current party's mask
+            // polynomial first (its u opens tacc.a[idx], :279-284; its v is parked), then b (u opens tacc.b; w(v0),
+            // :313-316), then the earlier parties' mask polynomials (:317-320, j1 = q), last the parked v (j1 = np).
+            // Each transform kind appears once in the loop body: the code of a step stays small.
+            cplx ta[R], tb[R];
+            CCS_PROBE(0)
+            for (int qi = 0; qi <= np + 1; qi++) {
+                WORD vw[R][2];
+                if (qi <= np) {
+                    const int q = qi == 0 ? np : qi - 1;
+                    cplx tu[R], tvq[R];
+                    uv(q, ud, tu, tvq);
+                    if (q == np) {
 #pragma unroll
-            for (int e = 0; e < R; e++) { vsc[e * NT + t] = vw[e][0]; vsc[M + e * NT + t] = vw[e][1]; }
-            // b polynomial: u_b, v0, w(v0)
-            uv(0, ud, tb, tvq);
-            inv_words(tvq, vw);                                                  // :297
-            wpart(vw, uf, tb, ta);                                               // :313-316
-            // earlier parties' mask polynomials
-            for (int q = 1; q < np; q++) {
-                uv(q, ud, tu, tvq);
+                        for (int e = 0; e < R; e++) ta[e] = tu[e];
+                    } else if (q == 0) {
 #pragma unroll
-                for (int e = 0; e < R; e++) sc[(size_t)q * M + dp[e]] = tu[e];
-                inv_words(tvq, vw);
-                wpart(vw, uf, tb, ta);                                           // :317-320 (j1 = q)
+                        for (int e = 0; e < R; e++) tb[e] = tu[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < R; e++) sc[(size_t)q * M + dp[e]] = tu[e];
+                    }
+                    CCS_PROBE(1)
+                    inv_words(tvq, vw);                                          // :297-300
+                    if (q == np) {
+#pragma unroll
+                        for (int e = 0; e < R; e++) { vsc[e * NT + t] = vw[e][0]; vsc[M + e * NT + t] = vw[e][1]; }
+                        CCS_PROBE(2)
+                        continue;
+                    }
+                    CCS_PROBE(2)
+                } else {
+#pragma unroll
+                    for (int e = 0; e < R; e++) { vw[e][0] = vsc[e * NT + t]; vw[e][1] = vsc[M + e * NT + t]; }
+                }
+                wpart(vw, uf, tb, ta);
+                CCS_PROBE(3)
             }
+            // :322-324 mul!(monomial, tacc); ifftto!; add!  -- tacc.b and tacc.a[idx] join the others in the scratch so
+            // the loop below is uniform; the polynomials are independent, the two just stored go last
 #pragma unroll
-            for (int e = 0; e < R; e++) { vw[e][0] = vsc[e * NT + t]; vw[e][1] = vsc[M + e * NT + t]; }
-            wpart(vw, uf, tb, ta);                                               // :317-320 (j1 = np)
-            // :322-324 mul!(monomial, tacc); ifftto!; add!
+            for (int e = 0; e < R; e++) { sc[dp[e]] = tb[e]; sc[(size_t)np * M + dp[e]] = ta[e]; }
             const cplx *mono = a.monomial + (size_t)(at - 1) * M;
-            for (int q = 0; q <= np; q++) {
+            for (int qq = 0; qq <= np; qq++) {
+                const int q = qq < np - 1 ? qq + 1 : (qq == np - 1 ? 0 : np);
                 cplx s[R];
 #pragma unroll
-                for (int e = 0; e < R; e++) {
-                    const cplx x = q == 0 ? tb[e] : (q == np ? ta[e] : sc[(size_t)q * M + dp[e]]);
-                    s[e] = cmul(mono[dp[e]], x);
-                }
+                for (int e = 0; e < R; e++) s[e] = cmul(mono[dp[e]], sc[(size_t)q * M + dp[e]]);
                 WORD w[R][2];
                 inv_words(s, w);
 #pragma unroll
@@ -1036,8 +1119,69 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void ccs_blindrotate_kernel
                     acc[(size_t)q * N + M + e * NT + t] = (WORD)(acc[(size_t)q * N + M + e * NT + t] + w[e][1]);
                 }
             }
+#else
+            cplx ta[R], tb[R], tu[R], tvq[R];
+            WORD vw[R][2];
+            CCS_PROBE(0)
+            // u of the current party's mask polynomial first; its v is parked in the scratch
+            uv(np, ud, ta, tvq);
+            CCS_PROBE(1)
+            inv_words(tvq, vw);                                                  // :298-300
+#pragma unroll
+            for (int e = 0; e < R; e++) { vsc[e * NT + t] = vw[e][0]; vsc[M + e * NT + t] = vw[e][1]; }
+            CCS_PROBE(2)
+            // b polynomial: u_b, v0, w(v0)
+            uv(0, ud, tb, tvq);
+            CCS_PROBE(1)
+            inv_words(tvq, vw);                                                  // :297
+            CCS_PROBE(2)
+            wpart(vw, uf, tb, ta);                                               // :313-316
+            CCS_PROBE(3)
+            // earlier parties' mask polynomials
+            for (int q = 1; q < np; q++) {
+                uv(q, ud, tu, tvq);
+#pragma unroll
+                for (int e = 0; e < R; e++) sc[(size_t)q * M + dp[e]] = tu[e];
+                CCS_PROBE(1)
+                inv_words(tvq, vw);
+                CCS_PROBE(2)
+                wpart(vw, uf, tb, ta);                                           // :317-320 (j1 = q)
+                CCS_PROBE(3)
+            }
+#pragma unroll
+            for (int e = 0; e < R; e++) { vw[e][0] = vsc[e * NT + t]; vw[e][1] = vsc[M + e * NT + t]; }
+            wpart(vw, uf, tb, ta);                                               // :317-320 (j1 = np)
+            CCS_PROBE(4)
+            // :322-324 mul!(monomial, tacc); ifftto!; add!
+            const cplx *mono = a.monomial + (size_t)(at - 1) * M;
+            for (int q = 0; q <= np; q++) {
+                cplx s[R];
+#pragma unroll
+                for (int e = 0; e < R; e++) {
+                    const cplx x = q == 0 ? tb[e] : (q == np ? ta[e] : sc[(size_t)q * M + dp[e]]);
+                    s[e] = cmul(MKT_CCS_ABL == 3 ? rt[e] : mono[dp[e]], x);
+                }
+#if MKT_CCS_PROBE == 2
+                CCS_PROBE(5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CCS_PROBE(7)
+#endif
+                WORD w[R][2];
+                inv_words(s, w);
+#pragma unroll
+                for (int e = 0; e < R; e++) {
+                    if (MKT_CCS_ABL == 2) { acc[(size_t)q * N + e * NT + t] = w[e][0]; acc[(size_t)q * N + M + e * NT + t] = w[e][1]; continue; }
+                    acc[(size_t)q * N + e * NT + t] = (WORD)(acc[(size_t)q * N + e * NT + t] + w[e][0]);
+                    acc[(size_t)q * N + M + e * NT + t] = (WORD)(acc[(size_t)q * N + M + e * NT + t] + w[e][1]);
+                }
+            }
+#endif
+            CCS_PROBE(5)
         }
     }
+#if MKT_CCS_PROBE
+    if (g == 0 && t == 0)
+        printf("ccs probe (s_memtime ticks, wave 0 of workgroup 0): loop-head %llu  uv %llu  inverse-v %llu  w %llu  w-last %llu  monomial+inverse+add %llu  | exposed acc-load wait %llu  exposed monomial/scratch wait %llu\n",
+               pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], pt[6], pt[7]);
+#endif
 }
 
 #endif  // TU 4
@@ -1499,7 +1643,7 @@ hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hip
 hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
     MKT_DISPATCH_LOGM(logM, {
-        using P = Plan<LM, LOGR>;
+        using P = Plan<LM, LOGR, MKT_CCS_PAIR ? 2 : 1>;
         constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
         if (W == 64) {
             hipError_t e = set_lds(ccs_blindrotate_kernel<LM, uint64_t>, LB); if (e != hipSuccess) return e;

@@ -5,7 +5,7 @@ for sfx in ${LIBS:-base}; do
  if [ "$sfx" != base ]; then cp $R/mktfhe_amd/lib/libmktfhe_hip_$sfx.so $R/mktfhe_amd/lib/libmktfhe_hip.so; else cp /tmp/orig.so $R/mktfhe_amd/lib/libmktfhe_hip.so; fi
  export MKT_ROT_VARIANT=${VARIANT:-0}
  D=$R/gpurun_out/pmcab_${sfx}_${VARIANT:-0}; rm -rf $D; mkdir -p $D
- ARGS="--workload ${WL:-kms2_n1024} --steps 2 --warmup 0 --no-cpu-baseline --no-secondary --no-roofline"
+ ARGS="--workload ${WL:-kms2_n1024} --batch ${BATCH:-1024} --steps 2 --warmup 0 --no-cpu-baseline --no-secondary --no-roofline"
  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $D/a -- python3 $R/bench.py $ARGS > /dev/null 2>&1
  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_WAVES --output-format csv -d $D/b -- python3 $R/bench.py $ARGS > /dev/null 2>&1
  python3 - "$D" "$sfx" <<'PY'
