@@ -23,7 +23,10 @@
 #define MKT_CCS_MO 0xff   // exchange-route mode of the CCS kernel's transforms (fft_device.h Route): 0xff = library default
 #endif
 #ifndef MKT_CCS_LOOPED
-#define MKT_CCS_LOOPED 1  // CCS kernel: one loop over the input polynomials of a step (each transform kind once in the code)
+#define MKT_CCS_LOOPED 1  // CCS kernel: 1 = one loop over the input polynomials of a step + one over its outputs (4 transform bodies in the code); 0 = every call site inlined (10 bodies, a stack array: 17-21 % slower).  A single job loop with 3 bodies measured 2-3 % slower than 1.
+#endif
+#ifndef MKT_CCS_FPF
+#define MKT_CCS_FPF 1     // CCS kernel, output loop: monomial row loaded once, next polynomial + accumulator words requested ahead of the inverse
 #endif
 #ifndef MKT_CCS_PAIR
 #define MKT_CCS_PAIR 0    // CCS kernel: the digit transforms of a decomposition run two at a time (measured: -2..-5 %)
@@ -1106,6 +1109,31 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
 #pragma unroll
             for (int e = 0; e < R; e++) { sc[dp[e]] = tb[e]; sc[(size_t)np * M + dp[e]] = ta[e]; }
             const cplx *mono = a.monomial + (size_t)(at - 1) * M;
+#if MKT_CCS_FPF
+            // the monomial row is the same for every polynomial; the next polynomial's transform-domain sum and the
+            // accumulator words the result is added to are requested before the inverse transform that hides them
+            auto fq = [&](int qq) { return qq < np - 1 ? qq + 1 : (qq == np - 1 ? 0 : np); };
+            cplx mrow[R], xq[R];
+#pragma unroll
+            for (int e = 0; e < R; e++) { mrow[e] = mono[dp[e]]; xq[e] = sc[(size_t)fq(0) * M + dp[e]]; }
+            for (int qq = 0; qq <= np; qq++) {
+                const int q = fq(qq), qn = fq(qq < np ? qq + 1 : qq);
+                cplx s[R];
+#pragma unroll
+                for (int e = 0; e < R; e++) s[e] = cmul(mrow[e], xq[e]);
+                WORD aw[R][2];
+#pragma unroll
+                for (int e = 0; e < R; e++) { xq[e] = sc[(size_t)qn * M + dp[e]]; aw[e][0] = acc[(size_t)q * N + e * NT + t]; aw[e][1] = acc[(size_t)q * N + M + e * NT + t]; }
+                __builtin_amdgcn_sched_barrier(0);
+                WORD w[R][2];
+                inv_words(s, w);
+#pragma unroll
+                for (int e = 0; e < R; e++) {
+                    acc[(size_t)q * N + e * NT + t] = (WORD)(aw[e][0] + w[e][0]);
+                    acc[(size_t)q * N + M + e * NT + t] = (WORD)(aw[e][1] + w[e][1]);
+                }
+            }
+#else
             for (int qq = 0; qq <= np; qq++) {
                 const int q = qq < np - 1 ? qq + 1 : (qq == np - 1 ? 0 : np);
                 cplx s[R];
@@ -1119,6 +1147,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
                     acc[(size_t)q * N + M + e * NT + t] = (WORD)(acc[(size_t)q * N + M + e * NT + t] + w[e][1]);
                 }
             }
+#endif
 #else
             cplx ta[R], tb[R], tu[R], tvq[R];
             WORD vw[R][2];
@@ -1531,6 +1560,7 @@ static hipError_t launch_rot_one(const RotArgs &a, size_t nrot, hipStream_t s) {
 static inline int rot_variant(const RotArgs &a, int LM) {
     int variant = a.variant;
     if (variant == 0) variant = (LM <= 10 || a.blk_len > 1) ? 22 : 21;   // pairs of transforms up to M = 1024 (re-measured with the specialised kernels: +4 % at M = 1024) and for the block schemes; single transforms above (LDS)
+    if (a.variant == 0 && a.blk_len > 1 && LM == 9) variant = 21;        // Blockparam (M = 512, block length 3): single transforms, 5.60 vs 5.82-5.98 ms per 1024 gates
     if ((2 * a.l) % (variant % 10) != 0) variant = (variant / 10) * 10 + 1;
     return variant;
 }
