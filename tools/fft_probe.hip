@@ -14,7 +14,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 template <int LOGM, int MODE, int NB>
 __global__ __launch_bounds__((Plan<LOGM, 2>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void probe(const cplx *psi, const cplx *rows, double *out, uint32_t *gacc, int iters, int l) {
+void probe(const cplx *psi, const cplx *rows, double *out, uint32_t *gacc, int iters, int l, int rowmask) {
     using P = Plan<LOGM, 2, NB>;
     constexpr int R = P::R, NT = P::NT, M = P::M;
     cplx *lds = reinterpret_cast<cplx *>(smem);
@@ -62,7 +62,7 @@ void probe(const cplx *psi, const cplx *rows, double *out, uint32_t *gacc, int i
                         z[0][e] = cmul(v, rt[e]);
                     }
                     fft_forward<LOGM, 2, 1>(reinterpret_cast<cplx(&)[1][R]>(z[0]), psi_l, lds, t, lx);
-                    const cplx *r0 = rows + (size_t)((it * 2 * l + c * l + j) & 63) * 2 * M, *r1 = r0 + M;
+                    const cplx *r0 = rows + (size_t)((it * 2 * l + c * l + j) & rowmask) * 2 * M, *r1 = r0 + M;
                     for (int e = 0; e < R; e++) { acc0[e] = cadd(acc0[e], cmul(z[0][e], r0[dp[e]])); acc1[e] = cadd(acc1[e], cmul(z[0][e], r1[dp[e]])); }
                 }
             }
@@ -133,7 +133,7 @@ void probe(const cplx *psi, const cplx *rows, double *out, uint32_t *gacc, int i
 }
 
 template <int LOGM, int MODE, int NB>
-void run(const char *name, const cplx *psi, const cplx *rows, double *out, uint32_t *gacc, int blocks, int iters, int l, double transforms_per_iter) {
+void run(const char *name, const cplx *psi, const cplx *rows, double *out, uint32_t *gacc, int blocks, int iters, int l, double transforms_per_iter, int rowmask = 63) {
     using P2 = Plan<LOGM, 2, 2>;
     const size_t lds = P2::LDS_BYTES + (size_t)P2::M * sizeof(cplx);
     hipFuncSetAttribute(reinterpret_cast<const void *>(probe<LOGM, MODE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -141,7 +141,7 @@ void run(const char *name, const cplx *psi, const cplx *rows, double *out, uint3
     float ms = 0;
     for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((probe<LOGM, MODE, NB>), dim3(blocks), dim3(P2::NT), lds, 0, psi, rows, out, gacc, iters, l);
+        hipLaunchKernelGGL((probe<LOGM, MODE, NB>), dim3(blocks), dim3(P2::NT), lds, 0, psi, rows, out, gacc, iters, l, rowmask);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     }
     const double ntr = (double)blocks * iters * transforms_per_iter;
@@ -153,7 +153,8 @@ void run(const char *name, const cplx *psi, const cplx *rows, double *out, uint3
 
 int main() {
     constexpr int LOGM = 9, M = 1 << LOGM;
-    std::vector<cplx> h(64 * 2 * M);
+    const size_t NROWS = 4096;   // 4096 row pairs of 16 KiB = 64 MiB: a key the size of the real ones
+    std::vector<cplx> h(NROWS * 2 * M);
     for (size_t i = 0; i < h.size(); i++) { h[i].re = 0.001 * (double)(i % 977) - 0.4; h[i].im = 0.002 * (double)(i % 613) - 0.6; }
     cplx *psi, *rows; double *out; uint32_t *gacc;
     hipMalloc(&gacc, (size_t)1024 * 3 * 2 * M * 4); hipMemset(gacc, 0x5a, (size_t)1024 * 3 * 2 * M * 4);
@@ -169,6 +170,7 @@ int main() {
         run<LOGM, 2, 1>("digit loop (l = 3): digits + twist + forward + 2 MACs, register rows", psi, rows, out, gacc, blocks, iters / 2, 3, 3);
         run<LOGM, 3, 1>("digit loop (l = 3): ... rows from global memory", psi, rows, out, gacc, blocks, iters / 2, 3, 3);
         run<LOGM, 4, 1>("CMux shape: 2 x 3 digit transforms + 2 inverses + native", psi, rows, out, gacc, blocks, iters / 4, 3, 8);
+        run<LOGM, 4, 1>("CMux shape, key rows streamed from a 64 MiB table", psi, rows, out, gacc, blocks, iters / 4, 3, 8, 4095);
         run<LOGM, 5, 1>("CCS step shape, np = 1 (16 transforms), accumulator in global memory", psi, rows, out, gacc, blocks, iters / 8, 3, 16);
         run<LOGM, 6, 1>("CCS step shape, untwist factors from registers", psi, rows, out, gacc, blocks, iters / 8, 3, 16);
     }
