@@ -146,7 +146,14 @@ int build_monomial(mkt_ctx *c) {   // scheme.jl:121-146
     return MKT_OK;
 }
 
+// fft_device.h (MKT_FFT_SPECIAL): the butterflies of the first two forward / last two inverse stages are written for
+// Psi[1] = (eps, -1), Psi[2] = (c, -c), Psi[3] = (-c, -c) -- the shape of the reference's tables (fft.jl:31-37 at any size)
+static bool twiddle_shape_ok(const std::vector<double> &psi, int M) {
+    if (M < 4) return false;
+    return psi[3] == -1.0 && psi[5] == -psi[4] && psi[4] > 0.0 && psi[7] == psi[6] && psi[6] == -psi[4];
+}
 int upload_twiddles(mkt_ctx *c) {
+    if (!twiddle_shape_ok(c->ks->tw.psi, c->M)) return fail(c, MKT_ERR_ARG, "twiddle table Psi does not have the reference's shape (Psi[1] = (eps,-1), Psi[2] = (c,-c), Psi[3] = (-c,-c))");
     const size_t tb = (size_t)c->M * sizeof(cplx);
     HIPCHK(c, hipMemcpy(c->ks->d_tw, c->ks->tw.psi.data(), tb, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->ks->d_tw + c->M, c->ks->tw.psiinv.data(), tb, hipMemcpyHostToDevice));

@@ -36,6 +36,14 @@ __device__ __forceinline__ cplx cmul_conj(const cplx x, const cplx w) {
 __device__ __forceinline__ cplx cadd(const cplx x, const cplx y) { cplx r; r.re = x.re + y.re; r.im = x.im + y.im; return r; }
 __device__ __forceinline__ cplx csub(const cplx x, const cplx y) { cplx r; r.re = x.re - y.re; r.im = x.im - y.im; return r; }
 
+// The first two stages of the forward network (the last two of the inverse) only ever see three twiddles:
+//   Psi[1] = exp(-i pi/2) = (eps, -1) with eps = 0x1.452821e638d01p-257 (the cosine of the 256-bit pi / 2), Psi[2] = (c, -c), Psi[3] = (-c, -c).
+// A product by -1 is exact and x * (-c) == -(x * c) bit for bit, so these butterflies need 2 multiplications instead of 4 and
+// give the reference's bits (a - (-y) == a + y and (-y) + d == d - y in IEEE-754, signed zeros included).  The host checks that
+// the tables have this shape before they are uploaded (context.cpp: check_twiddle_shape); the reference's always do.
+#ifndef MKT_FFT_SPECIAL
+#define MKT_FFT_SPECIAL 1
+#endif
 #ifndef MKT_DPP_PAIR
 #define MKT_DPP_PAIR 1        // pairwise lane exchanges along lane bits 0..3 as two DPP reads (see swap_pair)
 #endif
@@ -304,7 +312,14 @@ __device__ __forceinline__ void fft_forward_pass(cplx (&z)[NB][1 << LOGR], const
                 const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {
-                    const cplx u = cmul(z[nb][e2], w);
+                    cplx u;
+                    const cplx x = z[nb][e2];
+                    if (MKT_FFT_SPECIAL && PASS == 0 && b == LOGM - 1) {           // w = (eps, -1): x.im * -1 and x.re * -1 are exact
+                        u.re = x.re * w.re + x.im; u.im = x.im * w.re - x.re;
+                    } else if (MKT_FFT_SPECIAL && PASS == 0 && b == LOGM - 2) {    // w = (c, -c) / (-c, -c): two of the four products are the other two, negated
+                        const double pp = x.re * w.re, qq = x.im * w.re;
+                        if (g == 0) { u.re = pp + qq; u.im = qq - pp; } else { u.re = pp - qq; u.im = pp + qq; }
+                    } else u = cmul(x, w);
                     const cplx a = z[nb][e];
                     z[nb][e] = cadd(a, u); z[nb][e2] = csub(a, u);
                 }
@@ -344,7 +359,15 @@ __device__ __forceinline__ void fft_inverse_pass(cplx (&z)[NB][1 << LOGR], const
                 for (int nb = 0; nb < NB; nb++) {
                     const cplx a = z[nb][e], u = z[nb][e2];
                     z[nb][e] = cadd(a, u);
-                    z[nb][e2] = CONJ ? cmul_conj(csub(a, u), w) : cmul(csub(a, u), w);
+                    const cplx x = csub(a, u);
+                    cplx r;
+                    if (MKT_FFT_SPECIAL && CONJ && PASS == 0 && b == LOGM - 1) {   // conj(w) = (eps, +1)
+                        r.re = x.re * w.re - x.im; r.im = x.im * w.re + x.re;
+                    } else if (MKT_FFT_SPECIAL && CONJ && PASS == 0 && b == LOGM - 2) {
+                        const double pp = x.re * w.re, qq = x.im * w.re;
+                        if (g == 0) { r.re = pp - qq; r.im = qq + pp; } else { r.re = pp + qq; r.im = qq - pp; }
+                    } else r = CONJ ? cmul_conj(x, w) : cmul(x, w);
+                    z[nb][e2] = r;
                 }
             }
         }
