@@ -33,7 +33,7 @@ void probe(const cplx *psi, const cplx *rows, double *out, uint32_t *gacc, int i
     int dp[R];
     for (int e = 0; e < R; e++) dp[e] = dev_pos(t * R + e, NT);
     const Gadget<uint32_t> gd(l, 8);
-    for (int it = 0; it < (MODE >= 5 ? 0 : iters); it++) {
+    for (int it = 0; it < ((MODE == 5 || MODE == 6) ? 0 : iters); it++) {
         if (MODE == 0) fft_forward<LOGM, 2, NB>(z, psi_l, lds, t, lx);
         if (MODE == 1) fft_inverse<LOGM, 2, NB, true>(z, psi_l, lds, t, lx);
         if (MODE == 2 || MODE == 3) {           // the digit loop of a decomposition: [digits + twist] forward, 2 multiply-adds per point
@@ -52,7 +52,7 @@ void probe(const cplx *psi, const cplx *rows, double *out, uint32_t *gacc, int i
                 }
             }
         }
-        if (MODE == 4) {                        // one whole plain CMux shape: 2 decompositions of l digits + 2 inverses (+ native)
+        if (MODE == 4 || MODE == 7) {            // one whole plain CMux shape (7: times a row picked at random from a 16 MiB table, as the monomial is): 2 decompositions of l digits + 2 inverses (+ native)
             for (int c = 0; c < 2; c++) {
                 uint32_t tp[R][2];
                 for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(w[e][0] + c); tp[e][1] = gd.prep(w[e][1] ^ c); }
@@ -65,6 +65,11 @@ void probe(const cplx *psi, const cplx *rows, double *out, uint32_t *gacc, int i
                     const cplx *r0 = rows + (size_t)((it * 2 * l + c * l + j) & rowmask) * 2 * M, *r1 = r0 + M;
                     for (int e = 0; e < R; e++) { acc0[e] = cadd(acc0[e], cmul(z[0][e], r0[dp[e]])); acc1[e] = cadd(acc1[e], cmul(z[0][e], r1[dp[e]])); }
                 }
+            }
+            if (MODE == 7) {
+                const unsigned h = (blockIdx.x * 2654435761u + (unsigned)it * 40503u) >> 7;
+                const cplx *mrow = rows + (size_t)(h & 2047) * M;          // 2048 rows of M points = 16 MiB
+                for (int e = 0; e < R; e++) { const cplx mv = mrow[dp[e]]; acc0[e] = cmul(mv, acc0[e]); acc1[e] = cmul(mv, acc1[e]); }
             }
             fft_inverse<LOGM, 2, 1, true>(reinterpret_cast<cplx(&)[1][R]>(acc0), psi_l, lds, t, lx);
             fft_inverse<LOGM, 2, 1, true>(reinterpret_cast<cplx(&)[1][R]>(acc1), psi_l, lds, t, lx);
@@ -171,6 +176,7 @@ int main() {
         run<LOGM, 3, 1>("digit loop (l = 3): ... rows from global memory", psi, rows, out, gacc, blocks, iters / 2, 3, 3);
         run<LOGM, 4, 1>("CMux shape: 2 x 3 digit transforms + 2 inverses + native", psi, rows, out, gacc, blocks, iters / 4, 3, 8);
         run<LOGM, 4, 1>("CMux shape, key rows streamed from a 64 MiB table", psi, rows, out, gacc, blocks, iters / 4, 3, 8, 4095);
+        run<LOGM, 7, 1>("CMux shape, streamed key rows + a random row of a 16 MiB table per step", psi, rows, out, gacc, blocks, iters / 4, 3, 8, 4095);
         run<LOGM, 5, 1>("CCS step shape, np = 1 (16 transforms), accumulator in global memory", psi, rows, out, gacc, blocks, iters / 8, 3, 16);
         run<LOGM, 6, 1>("CCS step shape, untwist factors from registers", psi, rows, out, gacc, blocks, iters / 8, 3, 16);
     }
