@@ -276,7 +276,7 @@ def transform_roofline(mk, torch, local, dev):
                 e["traffic_source"] = src
             out.append(e)
         s.close()
-        # the same buffers through the exact integer transform (MKT_ARITH_EXACT: Goldilocks NTT, N residues = 8 N bytes)
+        # the same buffers through the exact integer transform (MKT_ARITH_EXACT: two-prime NTT, N residue pairs = 8 N bytes)
         sx = mk.Scheme(p, device=local, arith=mk.ARITH_EXACT)
         for direction in ("forward", "inverse"):
             fn = (lambda: sx.transform_fwd(polys, out=tr)) if direction == "forward" else (lambda: sx.transform_inv(tr, out=back))
@@ -289,7 +289,7 @@ def transform_roofline(mk, torch, local, dev):
             ms, cnt = sx.kernel_ms(3)
             sx.enable_timing(False)
             achieved = nb * 16 * N / (ms / cnt * 1e-3) / 1e9
-            out.append({"bound": "hbm", "kernel": "ntt_fwd_kernel" if direction == "forward" else "ntt_inv_kernel", "arith": "EXACT (integer NTT, p = 2^64 - 2^32 + 1)",
+            out.append({"bound": "hbm", "kernel": "ntt_fwd_kernel" if direction == "forward" else "ntt_inv_kernel", "arith": "EXACT (integer NTT, residues mod 15*2^27+1 and 63*2^25+1)",
                         "direction": direction, "N": N, "ring_bits": 64, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                         "traffic": None, "algorithmic_bytes_per_launch": nb * 16 * N, "bytes_per_transform": 16 * N, "transforms_per_launch": nb,
                         "avg_launch_ms": ms / cnt})

@@ -58,7 +58,8 @@ enum { MKT_NAND = 0, MKT_AND = 1, MKT_OR = 2, MKT_XOR = 3, MKT_XNOR = 4, MKT_NOR
 /* arithmetic modes of the negacyclic transform */
 enum {
     MKT_ARITH_F64REF = 0, /* the reference's Float64 twisted FFT, operation for operation (fft.jl) */
-    MKT_ARITH_EXACT = 1   /* exact integer arithmetic: the negacyclic NTT over Z_p[X]/(X^N+1), p = 2^64 - 2^32 + 1.
+    MKT_ARITH_EXACT = 1   /* exact integer arithmetic: the negacyclic NTT over Z_P[X]/(X^N+1) in residue form, P = p1 p2 =
+                             (15 * 2^27 + 1)(63 * 2^25 + 1) = 2^61.88.
                              Transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch,
                              mkt_decompose_batch, mkt_modswitch_batch, mkt_not_batch) for every scheme; the gate path
                              (mkt_load_brk/ksk, mkt_keygen_device, mkt_gate, mkt_bootstrap, mkt_blindrotate,
@@ -159,9 +160,10 @@ int mkt_keyswitch_batch(mkt_ctx *ctx, const void *acc, uint32_t *out, size_t B, 
 int mkt_kms_phase1_batch(mkt_ctx *ctx, const uint32_t *atilde, double *levkey, size_t B, int mem);
 
 /* ---- unit-level entry points (parity tests, transform roofline) ----
- * On an MKT_ARITH_EXACT context a TransPoly is N residues mod p (uint64, the same 8 N bytes as M complex doubles), in the
- * bit-reversed order the Cooley-Tukey network with psi_rev[m + i] leaves them; forward reads ring words as SIGNED
- * integers, inverse returns the integer of least magnitude mod 2^W. */
+ * On an MKT_ARITH_EXACT context a TransPoly is N residue pairs (x mod p1) | (x mod p2) << 32 (uint64, the same 8 N bytes as
+ * M complex doubles), in the bit-reversed order the Cooley-Tukey network with psi_rev[m + i] leaves them; forward reads
+ * ring words as SIGNED integers, inverse returns the integer of least magnitude mod P (the identity for |x| < P / 2),
+ * reduced mod 2^W. */
 /* fft.jl:57-63 fftto!: p [B][N] ring words -> t [B][M] complex */
 int mkt_transform_fwd_batch(mkt_ctx *ctx, const void *p, double *t, size_t B, int mem);
 /* fft.jl:74-81 ifftto!: t [B][M] complex -> p [B][N] ring words (t is left unmodified) */
@@ -169,7 +171,7 @@ int mkt_transform_inv_batch(mkt_ctx *ctx, const double *t, void *p, size_t B, in
 /* gsw.jl:86-96 decompto!: p [B][N] -> digits [B][l][N] ring words (wrapped signed digits) */
 int mkt_decompose_batch(mkt_ctx *ctx, const void *p, void *digits, int l, int logB, size_t B, int mem);
 /* MKT_ARITH_EXACT only: out = a (*) b in Z_{2^W}[X]/(X^N+1), EXACTLY, for a gadget-digit polynomial a (signed words,
- * N * max|a_i| < 2^30) and any ring polynomial b -- the product the reference's Float64 transform approximates
+ * N * max|a_i| < 2^28) and any ring polynomial b -- the product the reference's Float64 transform approximates
  * (polynomial.jl:99-113); a, b, out: [B][N] ring words */
 int mkt_exact_polymul_batch(mkt_ctx *ctx, const void *a, const void *b, void *out, size_t B, int mem);
 /* scheme.jl:121-146: copy monomial table entry e (1..2N) to host, M complex */

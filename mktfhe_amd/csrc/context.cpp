@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <memory>
 #include <string>
 #include <vector>
@@ -56,7 +57,7 @@ struct mkt_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     std::shared_ptr<KeySet> ks;  // shared with the contexts forked from this one
-    bool exact = false;          // MKT_ARITH_EXACT: transform-level entry points only (integer NTT); d_ntt = psi_rev | psiinv_rev | N^-1
+    bool exact = false;          // MKT_ARITH_EXACT (integer NTT, two 31-bit primes); d_ntt = psi_rev | psiinv_rev | N^-1 | N^-1 2^32, with Shoup companions
     uint64_t *d_ntt = nullptr;
     // workspace
     size_t ws_gates = 0;
@@ -119,7 +120,7 @@ int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt
     void *tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, npolys * poly_bytes(c)));
     hipError_t e = hipMemcpyAsync(tmp, host, npolys * poly_bytes(c), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = c->exact ? mktd::launch_ntt_fwd(c->logN, c->p.W, c->d_ntt, tmp, reinterpret_cast<uint64_t *>(dst), npolys, c->stream)   // N residues = the bytes of M complex
+    if (e == hipSuccess) e = c->exact ? mktd::launch_ntt_fwd(c->logN, c->p.W, c->d_ntt, tmp, reinterpret_cast<uint64_t *>(dst), npolys, 1, c->stream)   // N residues = the bytes of M complex
                                : mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, 1, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
@@ -315,28 +316,45 @@ struct Staged {
 
 bool mem_ok(int mem) { return mem == MKT_MEM_DEVICE || mem == MKT_MEM_HOST; }
 
-// ---- MKT_ARITH_EXACT: Goldilocks tables on the host (128-bit arithmetic), uploaded once ----
-constexpr uint64_t GLP = 0xFFFFFFFF00000001ull;
-uint64_t gl_mulmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % GLP); }
-uint64_t gl_powmod(uint64_t a, uint64_t e) { uint64_t r = 1; while (e) { if (e & 1) r = gl_mulmod(r, a); a = gl_mulmod(a, a); e >>= 1; } return r; }
+// ---- MKT_ARITH_EXACT: tables of the two-prime negacyclic NTT (ntt_exact.hip), computed on the host, uploaded once ----
+constexpr uint32_t NTT_P[2] = {2013265921u, 2113929217u};        // 15 * 2^27 + 1, 63 * 2^25 + 1
+uint32_t ntt_mulmod(uint32_t a, uint32_t b, uint32_t p) { return (uint32_t)((uint64_t)a * b % p); }
+uint32_t ntt_powmod(uint32_t a, uint64_t e, uint32_t p) { uint32_t r = 1; while (e) { if (e & 1) r = ntt_mulmod(r, a, p); a = ntt_mulmod(a, a, p); e >>= 1; } return r; }
+uint32_t ntt_shoup(uint32_t w, uint32_t p) { return (uint32_t)(((uint64_t)w << 32) / p); }
 
-// psi_rev[N] | psiinv_rev[N] | N^-1 for the transform of size N (psi = a primitive 2N-th root of unity: 7 generates Z_p^*)
+// per point (w mod p1, companion, w mod p2, companion): psi_rev[N] | psiinv_rev[N] | N^-1 | N^-1 * 2^32, for the transform of
+// size N; psi = g^((p - 1) / 2N) with g the smallest quadratic non-residue of p (so psi^N = -1: a primitive 2N-th root of unity)
 int upload_ntt_tables(mkt_ctx *c) {
     const int N = c->p.N, logN = c->logN;
-    const uint64_t psi = gl_powmod(7, (GLP - 1) / (2 * (uint64_t)N)), psiinv = gl_powmod(psi, GLP - 2);
-    std::vector<uint64_t> tab((size_t)2 * N + 1);
-    for (int i = 0; i < N; i++) {
-        int r = 0;
-        for (int b = 0; b < logN; b++) r |= ((i >> b) & 1) << (logN - 1 - b);
-        tab[i] = gl_powmod(psi, (uint64_t)r); tab[(size_t)N + i] = gl_powmod(psiinv, (uint64_t)r);
+    std::vector<uint32_t> tab((size_t)(2 * N + 2) * 4);
+    for (int k = 0; k < 2; k++) {
+        const uint32_t p = NTT_P[k];
+        uint32_t g = 2;
+        while (ntt_powmod(g, (p - 1) / 2, p) != p - 1) g++;
+        const uint32_t psi = ntt_powmod(g, (p - 1) / (2 * (uint64_t)N), p), psiinv = ntt_powmod(psi, p - 2, p);
+        if (ntt_powmod(psi, (uint64_t)N, p) != p - 1) return fail(c, MKT_ERR_UNSUPPORTED, "no primitive 2N-th root of unity for this ring dimension");
+        for (int i = 0; i < N; i++) {
+            int r = 0;
+            for (int b = 0; b < logN; b++) r |= ((i >> b) & 1) << (logN - 1 - b);
+            const uint32_t w = ntt_powmod(psi, (uint64_t)r, p), wi = ntt_powmod(psiinv, (uint64_t)r, p);
+            tab[(size_t)i * 4 + 2 * k] = w; tab[(size_t)i * 4 + 2 * k + 1] = ntt_shoup(w, p);
+            tab[((size_t)N + i) * 4 + 2 * k] = wi; tab[((size_t)N + i) * 4 + 2 * k + 1] = ntt_shoup(wi, p);
+        }
+        const uint32_t ninv = ntt_powmod((uint32_t)N, p - 2, p), ninv_r = (uint32_t)(((uint64_t)ninv << 32) % p);
+        tab[(size_t)(2 * N) * 4 + 2 * k] = ninv; tab[(size_t)(2 * N) * 4 + 2 * k + 1] = ntt_shoup(ninv, p);
+        tab[(size_t)(2 * N + 1) * 4 + 2 * k] = ninv_r; tab[(size_t)(2 * N + 1) * 4 + 2 * k + 1] = ntt_shoup(ninv_r, p);
     }
-    tab[(size_t)2 * N] = gl_powmod((uint64_t)N, GLP - 2);
-    HIPCHK(c, hipMalloc((void **)&c->d_ntt, tab.size() * 8));
-    HIPCHK(c, hipMemcpy(c->d_ntt, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void **)&c->d_ntt, tab.size() * 4));
+    HIPCHK(c, hipMemcpy(c->d_ntt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     return MKT_OK;
 }
 // the gate path of an EXACT context: CGGI with RLWE length 1 on the 32-bit ring (every true product coefficient < p / 2)
-bool exact_gate_ok(const mkt_ctx *c) { return c->p.scheme == MKT_CGGI && c->p.k == 1 && c->p.W == 32; }
+// (every true product coefficient below P / 2 = 2^60.88: 2l polynomials of N digits of magnitude <= 2^(logB-1) against 32-bit words)
+bool exact_gate_ok(const mkt_ctx *c) {
+    if (!(c->p.scheme == MKT_CGGI && c->p.k == 1 && c->p.W == 32)) return false;
+    const double bound = 2.0 * c->p.l_gsw * (double)c->p.N * std::ldexp(1.0, c->p.logB_gsw - 1) * 4294967296.0;
+    return bound < 0.5 * (double)NTT_P[0] * (double)NTT_P[1];
+}
 #define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI (RLWE length 1, 32-bit ring) only; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
 #define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; not offered by an MKT_ARITH_EXACT context"); } while (0)
 
@@ -579,7 +597,7 @@ static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, 
     else { a.kr = c->sh.kr; a.l = p.l_gsw; a.logB = p.logB_gsw; a.zoff = 0; }
     e = mktd::launch_keygen_brk(a, unienc ? 1 : 0, c->stream);
     if (e == hipSuccess && brk_out) e = hipMemcpyAsync(brk_out, d_out, brk_polys_total * poly_bytes(c), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = c->exact ? mktd::launch_ntt_fwd(c->logN, p.W, c->d_ntt, d_out, reinterpret_cast<uint64_t *>(c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx), brk_polys_total, c->stream)
+    if (e == hipSuccess) e = c->exact ? mktd::launch_ntt_fwd(c->logN, p.W, c->d_ntt, d_out, reinterpret_cast<uint64_t *>(c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx), brk_polys_total, 1, c->stream)
                                : mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, brk_polys_total, 1, c->stream);
     uint32_t *ksk = c->ks->d_ksk + (size_t)party * c->ks->ksk_party_words;
     if (e == hipSuccess) e = hipMemsetAsync(ksk, 0, c->ks->ksk_party_words * sizeof(uint32_t), c->stream);
@@ -732,7 +750,7 @@ int mkt_transform_fwd_batch(mkt_ctx *c, const void *p, double *t, size_t B, int 
     Staged sp{c}, st{c};
     int r;
     if ((r = sp.in(p, B * poly_bytes(c), mem, true)) || (r = st.in(t, B * (size_t)c->M * sizeof(cplx), mem, false))) return r;
-    if (c->exact) { Timer tm(c, 3); HIPCHK(c, mktd::launch_ntt_fwd(c->logN, c->p.W, c->d_ntt, sp.dev, (uint64_t *)st.dev, B, c->stream)); }
+    if (c->exact) { Timer tm(c, 3); HIPCHK(c, mktd::launch_ntt_fwd(c->logN, c->p.W, c->d_ntt, sp.dev, (uint64_t *)st.dev, B, 0, c->stream)); }
     else { Timer tm(c, 3); HIPCHK(c, mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), sp.dev, (cplx *)st.dev, B, 0, c->stream)); }
     return st.out(t);
 }

@@ -120,8 +120,8 @@ hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, h
 hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s);
 bool transform_supported(int logM);
 
-// MKT_ARITH_EXACT, transform level (ntt_exact.hip): tab = psi_rev[N] | psiinv_rev[N] | N^-1, residues mod 2^64 - 2^32 + 1
-hipError_t launch_ntt_fwd(int logN, int W, const uint64_t *tab, const void *p, uint64_t *t, size_t B, hipStream_t s);
+// MKT_ARITH_EXACT (ntt_exact.hip): tab = psi_rev[N] | psiinv_rev[N] | N^-1 | N^-1 2^32, each entry (w mod p1, companion, w mod p2, companion)
+hipError_t launch_ntt_fwd(int logN, int W, const uint64_t *tab, const void *p, uint64_t *t, size_t B, int montgomery, hipStream_t s);   // montgomery: output for a resident table (keys, monomials)
 hipError_t launch_ntt_inv(int logN, int W, const uint64_t *tab, const uint64_t *t, void *p, size_t B, hipStream_t s);
 // CGGI blind rotation (RLWE length 1, 32-bit ring) with exact products; brk [n][2l][2][N], mono [2N][N] residues, natural order
 hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,

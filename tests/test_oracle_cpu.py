@@ -227,10 +227,10 @@ def test_exact_ntt_restatement_against_schoolbook():
         ref = O.negacyclic(aw, b, W)
         got = np.zeros(N, dtype=np.uint64)
         za = R.fwd(aw, W)
-        for h in range(W // 32):                                  # 32-bit pieces of b keep every true coefficient below p / 2
+        for h in range(W // 32):                                  # 32-bit pieces of b keep every true coefficient below P / 2
             piece = [(int(x) >> (32 * h)) & 0xFFFFFFFF for x in b]
             zb = R.fwd(piece, 64)
-            prod = R.inv([x * y % R.P for x, y in zip(za, zb)], 64)
+            prod = R.inv(R.pmul(za, zb), 64)
             got = (got + (np.array(prod, dtype=np.uint64) << np.uint64(32 * h))) & np.uint64((1 << W) - 1)
         assert np.array_equal(got, ref), (N, W)
         assert R.inv(R.fwd(aw, W), W) == [int(x) for x in aw]
