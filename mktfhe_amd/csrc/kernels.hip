@@ -25,6 +25,9 @@
 #ifndef MKT_CCS_LOOPED
 #define MKT_CCS_LOOPED 1  // CCS kernel: 1 = one loop over the input polynomials of a step + one over its outputs (4 transform bodies in the code); 0 = every call site inlined (10 bodies, a stack array: 17-21 % slower).  A single job loop with 3 bodies measured 2-3 % slower than 1.
 #endif
+#ifndef MKT_CCS_LT
+#define MKT_CCS_LT 1      // CCS kernel specialised for the shipped gadgets (length and base compile-time constants)
+#endif
 #ifndef MKT_CCS_FPF
 #define MKT_CCS_FPF 1     // CCS kernel, output loop: monomial row loaded once, next polynomial + accumulator words requested ahead of the inverse
 #endif
@@ -926,7 +929,8 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
 // then w with the digits of v_1..v_np (:317-320) -- which is why u for the current party's mask polynomial is
 // computed first and parked in registers.
 // ------------------------------------------------------------------------------------------------
-template <int LOGM, typename WORD>
+// LT, BT > 0: gadget length and base known at compile time (digit loops unrolled, shifts and masks immediates)
+template <int LOGM, typename WORD, int LT = 0, int BT = 0>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2))) void ccs_blindrotate_kernel(const CcsArgs a) {
     using P = Plan<LOGM, LOGR, MKT_CCS_PAIR ? 2 : 1>;
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
@@ -941,11 +945,11 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
     // the workgroups that share a compute unit (every 256th under round-robin dispatch) run the same loop in lock-step
     // and then want the VALU and the LDS at the same moments: a start-up delay de-phases them (speed only)
     for (int s = 0, ns = a.stagger * (int)((g >> 8) & 3); s < ns; s++) __builtin_amdgcn_s_sleep(1);
-    const int k = a.k, l = a.l, n = a.n;
+    const int k = a.k, l = LT ? LT : a.l, n = a.n;
     WORD *acc = reinterpret_cast<WORD *>(a.acc) + g * (size_t)(k + 1) * N;
     cplx *sc = a.scratch + g * (size_t)(k + 1) * M;
     WORD *vsc = reinterpret_cast<WORD *>(a.vscratch) + g * (size_t)N;
-    const Gadget<WORD> gd(l, a.logB);
+    const Gadget<WORD> gd(l, (LT && BT) ? BT : a.logB);
     const int msbit = 32 - a.logN - 1;
     int dp[R];
 #pragma unroll
@@ -993,6 +997,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
                 }
             }
         }
+#pragma unroll 1
         for (; j < l; j++) {
             cplx z[R];
             const cplx *kd = ud + (size_t)j * M, *kv = vk + (size_t)j * M;
@@ -1032,6 +1037,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
                 }
             }
         }
+#pragma unroll 1
         for (; j < l; j++) {
             cplx z[R];
             const cplx *fb = uf + (size_t)(2 * j) * M, *fa = fb + M;
@@ -1670,18 +1676,27 @@ hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hip
     return hipGetLastError();
 }
 
+template <int LM, typename WORD, int LT, int BT>
+static hipError_t launch_ccs_one(const CcsArgs &a, size_t B, hipStream_t s) {
+    using P = Plan<LM, LOGR, MKT_CCS_PAIR ? 2 : 1>;
+    constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
+    hipError_t e = set_lds(ccs_blindrotate_kernel<LM, WORD, LT, BT>, LB); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ccs_blindrotate_kernel<LM, WORD, LT, BT>), dim3((unsigned)B), dim3(P::NT), LB, s, a);
+    return hipGetLastError();
+}
 hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
     MKT_DISPATCH_LOGM(logM, {
-        using P = Plan<LM, LOGR, MKT_CCS_PAIR ? 2 : 1>;
-        constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
-        if (W == 64) {
-            hipError_t e = set_lds(ccs_blindrotate_kernel<LM, uint64_t>, LB); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((ccs_blindrotate_kernel<LM, uint64_t>), dim3((unsigned)B), dim3(P::NT), LB, s, a);
-        } else {
-            hipError_t e = set_lds(ccs_blindrotate_kernel<LM, uint32_t>, LB); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((ccs_blindrotate_kernel<LM, uint32_t>), dim3((unsigned)B), dim3(P::NT), LB, s, a);
+        if (W == 64) return launch_ccs_one<LM, uint64_t, 0, 0>(a, B, s);
+#if MKT_CCS_LT
+        // the shipped gadgets of the 32-bit CCS sets (params.jl:15-45): CCS2party (3, 8), CCS4party (4, 8), CCS8party (5, 6)
+        if constexpr (LM == 9 || LM == 10) {
+            if (a.l == 3 && a.logB == 8) return launch_ccs_one<LM, uint32_t, 3, 8>(a, B, s);
+            if (a.l == 4 && a.logB == 8) return launch_ccs_one<LM, uint32_t, 4, 8>(a, B, s);
+            if (a.l == 5 && a.logB == 6) return launch_ccs_one<LM, uint32_t, 5, 6>(a, B, s);
         }
+#endif
+        return launch_ccs_one<LM, uint32_t, 0, 0>(a, B, s);
     });
     return hipGetLastError();
 }
