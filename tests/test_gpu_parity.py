@@ -313,6 +313,13 @@ def test_reference_tables_and_fft_form_keys(require_gpu):
     bad = tabs[1].copy(); bad[5] += 1e-9        # Psiinv must be conj(Psi)
     assert _lib.lib().mkt_set_twiddles(sg.h, tabs[0].ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p),
                                        tabs[2].ctypes.data_as(C.c_void_p), tabs[3].ctypes.data_as(C.c_void_p)) < 0
+    # ... and have the reference's shape in the first entries, Psi[1] = (eps, -1), Psi[2] = (c, -c), Psi[3] = (-c, -c): the first
+    # two butterfly stages are written for it (fft_device.h, MKT_FFT_SPECIAL)
+    odd, oddi = tabs[0].copy(), tabs[1].copy()
+    odd[2] = complex(odd[2].real, odd[2].imag * (1 + 2.0**-52)); oddi[2] = np.conj(odd[2])
+    assert _lib.lib().mkt_set_twiddles(sg.h, odd.ctypes.data_as(C.c_void_p), oddi.ctypes.data_as(C.c_void_p),
+                                       tabs[2].ctypes.data_as(C.c_void_p), tabs[3].ctypes.data_as(C.c_void_p)) < 0
+    _lib.check(_lib.lib().mkt_set_twiddles(sg.h, *[t.ctypes.data_as(C.c_void_p) for t in tabs]), sg.h)
     sg.load_crs(f.fwd(crs.astype(np.uint64)), fmt=mk.FMT_F64_FFT)
     for i, kk in enumerate(keys):
         sg.load_party(i, brk=f.fwd(kk.brk.astype(np.uint64).reshape(-1, p.N)), ksk=kk.ksk,
