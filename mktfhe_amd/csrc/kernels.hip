@@ -1566,7 +1566,6 @@ static hipError_t launch_rot_one(const RotArgs &a, size_t nrot, hipStream_t s) {
 static inline int rot_variant(const RotArgs &a, int LM) {
     int variant = a.variant;
     if (variant == 0) variant = (LM <= 10 || a.blk_len > 1) ? 22 : 21;   // pairs of transforms up to M = 1024 (re-measured with the specialised kernels: +4 % at M = 1024) and for the block schemes; single transforms above (LDS)
-    if (a.variant == 0 && a.blk_len > 1 && LM == 9) variant = 21;        // Blockparam (M = 512, block length 3): single transforms, 5.60 vs 5.82-5.98 ms per 1024 gates
     if ((2 * a.l) % (variant % 10) != 0) variant = (variant / 10) * 10 + 1;
     return variant;
 }
