@@ -367,6 +367,12 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 #ifndef MKT_ROT_PF
 #define MKT_ROT_PF 1      // measured on MI355X (KMS k=2 N=1024, 4096 gates): 1 -> -4 %, 2 -> +0.5 % (register pressure), with ROOTS_REG -6 %
 #endif
+#ifndef MKT_ROT_AT_AHEAD
+#define MKT_ROT_AT_AHEAD 1
+#endif
+#ifndef MKT_ROT_PFQ
+#define MKT_ROT_PFQ 0     // block kernels: key bits of a block whose rows are requested before the digit's forward transform
+#endif
 #ifndef MKT_ROT_ROOTS_REG
 #define MKT_ROT_ROOTS_REG 1   // roots / rootsinv of the thread's points in registers for the whole rotation (2 * R * 4 VGPRs): 20 of the 51 table loads of a CMux gone
 #endif
@@ -462,14 +468,22 @@ void blindrotate_k1_kernel(const RotArgs a) {
 
     const int nblk = a.n / LB;
     const int msbit = 32 - a.logN - 1;
+    uint32_t at_raw[LB];                      // the mask words of the NEXT block are requested a block ahead: nothing waits for them
+#pragma unroll
+    for (int q = 0; q < LB; q++) at_raw[q] = MKT_ROT_AT_AHEAD ? at_src[q] : 0u;
     for (int blk = 0; blk < nblk; blk++) {
         uint32_t ats[LB];
         bool any = false;
 #pragma unroll
         for (int q = 0; q < LB; q++) {
-            const uint32_t v = at_src[blk * LB + q];
+            const uint32_t v = MKT_ROT_AT_AHEAD ? at_raw[q] : at_src[blk * LB + q];
             ats[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.pre_switched ? v : divbits<uint32_t>(v, msbit)));   // bootstrapping.jl:8 (wave-uniform)
             any |= ats[q] != 0;
+        }
+        if (MKT_ROT_AT_AHEAD) {
+            const int nb = blk + 1 < nblk ? blk + 1 : blk;
+#pragma unroll
+            for (int q = 0; q < LB; q++) at_raw[q] = at_src[nb * LB + q];
         }
         if (!any) continue;                                              // :48 / :145 / :413 / :638
 
@@ -494,6 +508,21 @@ void blindrotate_k1_kernel(const RotArgs a) {
         for (int g0 = 0; g0 < 2 * l; g0 += NB) {
             cplx z[NB][R];
             cplx kpf[NB][2][R];
+            // block kernels: the rows of the first PFQ key bits of the block are requested before the digit's transform (the
+            // LB * 2 accumulators leave room for PFQ * 2 rows, not for all LB * 2)
+            constexpr int PFQ = (LB > 1 && MKT_ROT_BUFLOAD) ? (MKT_ROT_PFQ < LB ? MKT_ROT_PFQ : LB) : 0;
+            cplx kq[NB][PFQ > 0 ? PFQ : 1][2][R];
+            if (PFQ > 0) {
+#pragma unroll
+                for (int h2 = 0; h2 < NB; h2++)
+#pragma unroll
+                    for (int q = 0; q < PFQ; q++) {
+                        const unsigned so_row = (unsigned)((((size_t)(blk * LB + q) * 2 * l + (size_t)(g0 + h2)) * 2) * M * sizeof(cplx));
+#pragma unroll
+                        for (int e = 0; e < R; e++) { kq[h2][q][0][e] = table_load(rs_brk, vo_dev[e], so_row); kq[h2][q][1][e] = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (PF_KEYS) {
 #pragma unroll
                 for (int h2 = 0; h2 < NB; h2++) {
@@ -528,7 +557,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
                     for (int e = 0; e < R; e++) {                        // :63-68 muladdto!(tacc, digit, row)
                         cplx kb, ka;
-                        if (PF_KEYS) { kb = kpf[h2][0][e]; ka = kpf[h2][1][e]; } else if (MKT_ROT_BUFLOAD) { kb = table_load(rs_brk, vo_dev[e], so_row); ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
+                        if (PF_KEYS) { kb = kpf[h2][0][e]; ka = kpf[h2][1][e]; } else if (PFQ > 0 && q < PFQ) { kb = kq[h2][q][0][e]; ka = kq[h2][q][1][e]; } else if (MKT_ROT_BUFLOAD) { kb = table_load(rs_brk, vo_dev[e], so_row); ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
                         tacc[q][0][e] = cadd(tacc[q][0][e], cmul(z[h2][e], kb));
                         tacc[q][1][e] = cadd(tacc[q][1][e], cmul(z[h2][e], ka));
                         if (RotOcc<LOGM, NB>::MINW >= 3) __builtin_amdgcn_sched_barrier(0);   // keep the key-row live ranges short at 3 waves/SIMD
