@@ -367,6 +367,9 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 #ifndef MKT_ROT_PF
 #define MKT_ROT_PF 1      // measured on MI355X (KMS k=2 N=1024, 4096 gates): 1 -> -4 %, 2 -> +0.5 % (register pressure), with ROOTS_REG -6 %
 #endif
+#ifndef MKT_ROT_PROBE
+#define MKT_ROT_PROBE 0   // development: workgroup 0 prints the s_memtime ticks its first wave spent in each phase of the rotation loop
+#endif
 #ifndef MKT_ROT_AT_AHEAD
 #define MKT_ROT_AT_AHEAD 1
 #endif
@@ -468,6 +471,12 @@ void blindrotate_k1_kernel(const RotArgs a) {
 
     const int nblk = a.n / LB;
     const int msbit = 32 - a.logN - 1;
+#if MKT_ROT_PROBE
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = __builtin_amdgcn_s_memtime();
+#define ROT_PROBE(K) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[K] += now_ - plast; plast = now_; }
+#else
+#define ROT_PROBE(K)
+#endif
     uint32_t at_raw[LB];                      // the mask words of the NEXT block are requested a block ahead: nothing waits for them
 #pragma unroll
     for (int q = 0; q < LB; q++) at_raw[q] = MKT_ROT_AT_AHEAD ? at_src[q] : 0u;
@@ -486,6 +495,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
             for (int q = 0; q < LB; q++) at_raw[q] = at_src[nb * LB + q];
         }
         if (!any) continue;                                              // :48 / :145 / :413 / :638
+        ROT_PROBE(0)
 
         cplx mono_pf[R];
         constexpr bool PF_MONO = (MKT_ROT_PF & 1) && LB == 1 && MKT_ROT_BUFLOAD, PF_KEYS = (MKT_ROT_PF & 2) && LB == 1 && MKT_ROT_BUFLOAD;
@@ -546,7 +556,9 @@ void blindrotate_k1_kernel(const RotArgs a) {
                     z[h2][e] = cmul(v, RREG ? rt_reg[e] : MKT_ROT_BUFLOAD ? table_load(rs_roots, vo_nat[e], 0) : a.tw.roots[e * NT + t]);
                 }
             }
+            ROT_PROBE(1)
             fft_forward<LOGM, LR, NB, MO>(z, MKT_PSI_F, lds, t, xs.lx);  // :54-59 fftto!
+            ROT_PROBE(2)
 #pragma unroll
             for (int h2 = 0; h2 < NB; h2++)
 #pragma unroll
@@ -565,6 +577,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
                 }
         }
 
+        ROT_PROBE(3)
         cplx t2[2][R];
         if (LB == 1 && !a.blk_accum) {                                   // :71 mul!(monomial[atilde], tacc)
             const cplx *mono = a.monomial + (size_t)(ats[0] - 1) * M;
@@ -587,6 +600,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
                     for (int e = 0; e < R; e++) t2[c][e] = cadd(t2[c][e], cmul(MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[q] - 1) * M * sizeof(cplx))) : mono[dev_pos(t * R + e, NT)], tacc[q][c][e]));
             }
         }
+        ROT_PROBE(4)
         if (NB == 2) {
             MKT_INV(2, t2);                                              // :72 ifftto! (b and a together)
         } else {
@@ -603,7 +617,13 @@ void blindrotate_k1_kernel(const RotArgs a) {
                 acc[c][e][1] = (WORD)(acc[c][e][1] + native<WORD>(-v.im));
             }
         }
+        ROT_PROBE(5)
     }
+#if MKT_ROT_PROBE
+    if (bid == 0 && t == 0)
+        printf("rot probe (s_memtime ticks, wave 0 of workgroup 0): head %llu  digits+twist %llu  forward %llu  row MACs %llu  monomial MACs %llu  inverse+native %llu\n",
+               pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
+#endif
 
     if (a.out_mode == 0) {
         WORD *dst = reinterpret_cast<WORD *>(a.acc_io) + rot * 2 * N;
