@@ -409,7 +409,7 @@ __device__ __forceinline__ void fft_inverse_barriers_only() {
 // Device point order of the resident TransPolys (keys, monomial table, phase-1 output): where the
 // reference-order point x = 4t+e (slot e of thread t after the forward transform) is stored.
 #ifndef MKT_DEVORDER
-#define MKT_DEVORDER 2
+#define MKT_DEVORDER 1   // measured (A/B on one device, 4096-gate batches): 1 is 0.5-1 % ahead of 2 at KMS k=2 N=1024, KMS2party, CGGIparam, 3 % at KMS2partyblock
 #endif
 #ifndef MKT_LOGR
 #define MKT_LOGR 2   // points per thread = 2^MKT_LOGR in every transform schedule (and in dev_pos)

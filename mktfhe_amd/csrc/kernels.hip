@@ -1812,7 +1812,16 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
 // product exchange between the forward and the inverse transforms.  Keys are read in the resident (LOGR = 2) device
 // point order whatever LR this kernel uses.
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ int dev_pos_lr2(int x, int M) { const int NT2 = M >> 2; return ((x & 3) >> 1) * (2 * NT2) + ((x >> 2) << 1) + (x & 1); }
+__host__ __device__ __forceinline__ int dev_pos_lr2(int x, int M) {      // dev_pos of the LOGR = 2 schedules, whatever LR this kernel runs
+    const int NT2 = M >> 2;
+#if MKT_DEVORDER == 0
+    return x;
+#elif MKT_DEVORDER == 1
+    return (x & 3) * NT2 + (x >> 2);
+#else
+    return ((x & 3) >> 1) * (2 * NT2) + ((x >> 2) << 1) + (x & 1);
+#endif
+}
 
 template <int LOGM, typename WORD, int LR, int LT>
 __global__ __launch_bounds__((2 * LT * Plan<LOGM, LR>::NT)) void blindrotate_wide_kernel(const RotArgs a) {
