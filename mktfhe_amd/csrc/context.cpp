@@ -54,6 +54,7 @@ struct mkt_ctx {
     mkt::Shape sh;
     int device = 0;
     int logM = 0, logN = 0, M = 0;
+    int dev_order = MKT_DEVORDER;   // device point order of this context's resident tables (fft_device.h dev_pos)
     hipStream_t stream = nullptr;
     std::string err;
     std::shared_ptr<KeySet> ks;  // shared with the contexts forked from this one
@@ -110,7 +111,7 @@ int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt
         const size_t nb = npolys * (size_t)c->M * sizeof(cplx);
         HIPCHK(c, hipMalloc((void **)&tmpc, nb));
         hipError_t e = hipMemcpyAsync(tmpc, host, nb, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = mktd::launch_reorder(c->logM, tmpc, dst, npolys, 1, c->stream);
+        if (e == hipSuccess) e = mktd::launch_reorder(c->logM, tmpc, dst, npolys, 1, c->dev_order, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         (void)hipFree(tmpc);
         if (e != hipSuccess) return hipfail(c, e, "key upload");
@@ -121,7 +122,7 @@ int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt
     HIPCHK(c, hipMalloc(&tmp, npolys * poly_bytes(c)));
     hipError_t e = hipMemcpyAsync(tmp, host, npolys * poly_bytes(c), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = c->exact ? mktd::launch_ntt_fwd(c->logN, c->p.W, c->d_ntt, tmp, reinterpret_cast<uint64_t *>(dst), npolys, 1, c->stream)   // N residues = the bytes of M complex
-                               : mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, 1, c->stream);
+                               : mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, c->dev_order, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) return hipfail(c, e, "key pre-transform");
@@ -211,7 +212,7 @@ mktd::RotArgs rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
     a.blk_len = mkt::is_block(p.scheme) ? p.blk_len : 1;
     a.blk_accum = mkt::is_block(p.scheme) ? 1 : 0;
     a.rows_per_gate = c->ks->rtot; a.slot_party = c->ks->d_slot_party; a.slot_row = c->ks->d_slot_row;
-    a.logB_lev = p.logB_lev;
+    a.logB_lev = p.logB_lev; a.dev_order = c->dev_order;
     if (const char *v = getenv("MKT_ROT_VARIANT")) a.variant = atoi(v);
     a.stagger = 16;   // tools/stagger.sh: 16.99 -> 15.63 ms at KMS k=2 N=1024 on one device, neutral elsewhere
     if (const char *v = getenv("MKT_ROT_STAGGER")) a.stagger = atoi(v);
@@ -228,7 +229,7 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         q.tw = c->twp(); q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.logN = c->logN; q.k = p.k;
         q.l = p.l_uni; q.logB = p.logB_uni; q.brk = c->ks->d_brk; q.brk_party_stride = c->ks->brk_party_cplx; q.pub_b = c->ks->d_pub; q.crs = c->ks->d_crs;
         q.monomial = c->ks->d_monomial; q.acc = acc; q.scratch = scratch; q.vscratch = lev;
-        q.stagger = 0;
+        q.stagger = 0; q.dev_order = c->dev_order;
         if (const char *v = getenv("MKT_CCS_STAGGER")) q.stagger = atoi(v);
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_ccs_blindrotate(c->logM, p.W, q, B, c->stream));
@@ -262,7 +263,7 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
     q.tw = c->twp(); q.lin = lin_for_tv; q.lwe_stride = c->sh.lwe_len; q.logN = c->logN;
     q.k = p.k; q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni;
     q.levkey = lev; q.rtot = c->ks->rtot; q.rlk_d = c->ks->d_rlk_d; q.rlk_f = c->ks->d_rlk_f; q.pub_b = c->ks->d_pub; q.crs = c->ks->d_crs;
-    q.acc = acc; q.scratch = scratch;
+    q.acc = acc; q.scratch = scratch; q.dev_order = c->dev_order;
     Timer tm(c, 4);
     HIPCHK(c, mktd::launch_kms_phase2(c->logM, p.W, q, B, c->stream));
     return MKT_OK;
@@ -389,6 +390,8 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     c->p = *params; c->sh = mkt::shape_of(*params); c->device = device;
     c->logN = logN; c->logM = logN - 1; c->M = params->N / 2;
     c->exact = arith_mode == MKT_ARITH_EXACT;
+    // the RLWE-length-k kernels of the plain schemes want the slot-pair order, everything else the slot-major one (fft_device.h)
+    c->dev_order = ((params->scheme == MKT_CGGI || params->scheme == MKT_LMSS) && params->k > 1) ? MKT_DEVORDER_KR : MKT_DEVORDER;
     DevGuard dg(device);
     auto bail = [&](int code) { std::string m = c->err; mkt_ctx_destroy(c); g_create_error = m; return code; };
     if (!dg.ok) { c->err = "hipSetDevice failed"; return bail(MKT_ERR_HIP); }
@@ -450,7 +453,7 @@ int mkt_ctx_fork(mkt_ctx *c, mkt_ctx **out) {
     if (!c || !out) return fail(c, MKT_ERR_ARG, "null argument");
     MKT_F64_ONLY(c);
     auto *f = new mkt_ctx();
-    f->p = c->p; f->sh = c->sh; f->device = c->device; f->logM = c->logM; f->logN = c->logN; f->M = c->M;
+    f->p = c->p; f->sh = c->sh; f->device = c->device; f->logM = c->logM; f->logN = c->logN; f->M = c->M; f->dev_order = c->dev_order;
     f->ks = c->ks;
     *out = f;
     return MKT_OK;
@@ -502,7 +505,7 @@ int mkt_get_monomial(mkt_ctx *c, int e, double *out_host) {
     HIPCHK(c, hipMemcpy(dev.data(), c->ks->d_monomial + (size_t)(e - 1) * c->M, (size_t)c->M * sizeof(cplx), hipMemcpyDeviceToHost));
     const int NT = c->M >> MKT_LOGR;              // device order -> the reference's order
     cplx *o = reinterpret_cast<cplx *>(out_host);
-    for (int x = 0; x < c->M; x++) o[x] = dev[(size_t)mktd::dev_pos(x, NT)];
+    for (int x = 0; x < c->M; x++) o[x] = dev[(size_t)mktd::dev_pos(c->dev_order, x, NT)];
     return MKT_OK;
 }
 
@@ -598,7 +601,7 @@ static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, 
     e = mktd::launch_keygen_brk(a, unienc ? 1 : 0, c->stream);
     if (e == hipSuccess && brk_out) e = hipMemcpyAsync(brk_out, d_out, brk_polys_total * poly_bytes(c), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = c->exact ? mktd::launch_ntt_fwd(c->logN, p.W, c->d_ntt, d_out, reinterpret_cast<uint64_t *>(c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx), brk_polys_total, 1, c->stream)
-                               : mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, brk_polys_total, 1, c->stream);
+                               : mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, brk_polys_total, c->dev_order, c->stream);
     uint32_t *ksk = c->ks->d_ksk + (size_t)party * c->ks->ksk_party_words;
     if (e == hipSuccess) e = hipMemsetAsync(ksk, 0, c->ks->ksk_party_words * sizeof(uint32_t), c->stream);
     a.zoff = mkt::is_kms(p.scheme) ? 1 : 0;      // the key switch targets the uni key of the KMS schemes

@@ -39,6 +39,7 @@ struct RotArgs {
     int wide;                 // latency variant: 0 automatic, 1 never, 2 always where supported (MKT_ROT_WIDE)
     unsigned block0;          // first workgroup index of this launch (a rotation batch may be issued as several launches)
     unsigned split;           // workgroups per launch (0 = the whole batch in one launch)
+    int dev_order;            // device point order of the resident tables (fft_device.h dev_pos)
 };
 
 // KMS phase 2 (bootstrapping.jl:448-558), one workgroup per ciphertext.
@@ -56,6 +57,7 @@ struct Phase2Args {
     const cplx *crs;          // [l_uni][M]
     void *acc;                // [B][1+k][N] ring words (in: test vector unless lin != NULL; out: result)
     cplx *scratch;            // [B][2*(k+1)][M]
+    int dev_order;            // device point order of the resident tables
 };
 
 // CCS blind rotation (bootstrapping.jl:234-328), one workgroup per ciphertext.
@@ -73,6 +75,7 @@ struct CcsArgs {
     cplx *scratch;            // [B][k+1][M]
     void *vscratch;           // [B][N] ring words
     int stagger;              // start-up delay between the workgroups that share a compute unit, in units of 64 cycles (0 = off)
+    int dev_order;            // device point order of the resident tables
 };
 
 struct KsArgs {
@@ -106,7 +109,7 @@ hipError_t launch_keygen_brk(const KeygenArgs &a, int unienc, hipStream_t s);
 hipError_t launch_keygen_ksk(const KeygenArgs &a, uint32_t *ksk, int n1p, int kk, int dr, int is_block, hipStream_t s);
 
 hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, hipStream_t s);
-hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, int to_device, hipStream_t s);
+hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, int to_device, int order, hipStream_t s);
 hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void *p, size_t B, hipStream_t s);
 hipError_t launch_decompose(int W, const void *p, void *digits, int N, int l, int logB, size_t B, hipStream_t s);
 hipError_t launch_gate_linear(int op, const uint32_t *x, const uint32_t *y, uint32_t *out, int len, size_t B, hipStream_t s);

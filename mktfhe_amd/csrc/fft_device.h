@@ -408,21 +408,23 @@ __device__ __forceinline__ void fft_inverse_barriers_only() {
 
 // Device point order of the resident TransPolys (keys, monomial table, phase-1 output): where the
 // reference-order point x = 4t+e (slot e of thread t after the forward transform) is stored.
+// order 1: slot-major -- every 16-byte load of a wave is one contiguous KiB (the k = 1 rotation kernels, CCS, KMS phase 2:
+//          0.5-1 % ahead of order 2, 3-6 % at KMS2partyblock);
+// order 2: slot pairs, 32 B per lane (the RLWE-length-k kernels: order 1 runs them 60 % slower).
+// A context picks one for all its resident tables (context.cpp); API-visible TransPolys are in the reference's order.
 #ifndef MKT_DEVORDER
-#define MKT_DEVORDER 1   // measured (A/B on one device, 4096-gate batches): 1 is 0.5-1 % ahead of 2 at KMS k=2 N=1024, KMS2party, CGGIparam, 3 % at KMS2partyblock
+#define MKT_DEVORDER 1
+#endif
+#ifndef MKT_DEVORDER_KR
+#define MKT_DEVORDER_KR 2
 #endif
 #ifndef MKT_LOGR
 #define MKT_LOGR 2   // points per thread = 2^MKT_LOGR in every transform schedule (and in dev_pos)
 #endif
-__host__ __device__ __forceinline__ int dev_pos(int x, int NT) {
+__host__ __device__ __forceinline__ int dev_pos(int order, int x, int NT) {
     constexpr int LR = MKT_LOGR, RM = (1 << LR) - 1;
-#if MKT_DEVORDER == 0
-    (void)NT; return x;                                            // reference order: 16*R B per lane
-#elif MKT_DEVORDER == 1
-    return (x & RM) * NT + (x >> LR);                              // slot-major: 16 B per lane, wave-contiguous
-#else
-    return ((x & RM) >> 1) * (2 * NT) + ((x >> LR) << 1) + (x & 1); // slot pairs: 32 B per lane
-#endif
+    if (order == 1) return (x & RM) * NT + (x >> LR);
+    return ((x & RM) >> 1) * (2 * NT) + ((x >> LR) << 1) + (x & 1);
 }
 
 // ---- ring words ----

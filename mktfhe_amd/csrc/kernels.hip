@@ -168,7 +168,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
                 cplx *o = out + b * M;
 #pragma unroll
                 for (int e = 0; e < R; e++)   // device point order for resident tables; else the reference's TransPoly order
-                    stream_store_c(&o[dev_order ? dev_pos(t * R + e, NT) : (contig ? e * NT + t : t * R + e)], z[u][e]);
+                    stream_store_c(&o[dev_order ? dev_pos(dev_order, t * R + e, NT) : (contig ? e * NT + t : t * R + e)], z[u][e]);
             }
         }
     }
@@ -244,11 +244,11 @@ __global__ void decompose_kernel(const WORD *__restrict__ p, WORD *__restrict__ 
 
 // natural <-> device point order of TransPolys (F64_FFT key upload, table read-back)
 template <int LOGM>
-__global__ void reorder_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, size_t npolys, int to_device) {
+__global__ void reorder_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, size_t npolys, int to_device, int order) {
     constexpr int M = 1 << LOGM, R = 1 << LOGR, NT = M / R;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npolys * M; i += (size_t)gridDim.x * blockDim.x) {
         const size_t b = i / M; const int x = (int)(i % M);
-        if (to_device) out[b * M + dev_pos(x, NT)] = in[i]; else out[i] = in[b * M + dev_pos(x, NT)];
+        if (to_device) out[b * M + dev_pos(order, x, NT)] = in[i]; else out[i] = in[b * M + dev_pos(order, x, NT)];
     }
 }
 
@@ -441,7 +441,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
     const __amdgpu_buffer_rsrc_t rs_rinv = table_rsrc(a.tw.rootsinv, (size_t)M * sizeof(cplx));
     unsigned vo_dev[R], vo_nat[R];            // per-lane byte offsets: device point order (tables), e*NT + t (twists)
 #pragma unroll
-    for (int e = 0; e < R; e++) { vo_dev[e] = (unsigned)dev_pos(t * R + e, NT) * 16u; vo_nat[e] = (unsigned)(e * NT + t) * 16u; }
+    for (int e = 0; e < R; e++) { vo_dev[e] = (unsigned)dev_pos(MKT_DEVORDER, t * R + e, NT) * 16u; vo_nat[e] = (unsigned)(e * NT + t) * 16u; }
     // LT, BT > 0: gadget length and base known at compile time -- every digit shift / mask is an immediate
     const Gadget<WORD> gd(LT ? LT : a.l, (LT && BT) ? BT : a.logB);
     const int l = LT ? LT : a.l;   // LT > 0: gadget length known at compile time, the digit loop unrolls fully
@@ -569,7 +569,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
                     for (int e = 0; e < R; e++) {                        // :63-68 muladdto!(tacc, digit, row)
                         cplx kb, ka;
-                        if (PF_KEYS) { kb = kpf[h2][0][e]; ka = kpf[h2][1][e]; } else if (PFQ > 0 && q < PFQ) { kb = kq[h2][q][0][e]; ka = kq[h2][q][1][e]; } else if (MKT_ROT_BUFLOAD) { kb = table_load(rs_brk, vo_dev[e], so_row); ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); } else { kb = krow[dev_pos(t * R + e, NT)]; ka = krow[M + dev_pos(t * R + e, NT)]; }
+                        if (PF_KEYS) { kb = kpf[h2][0][e]; ka = kpf[h2][1][e]; } else if (PFQ > 0 && q < PFQ) { kb = kq[h2][q][0][e]; ka = kq[h2][q][1][e]; } else if (MKT_ROT_BUFLOAD) { kb = table_load(rs_brk, vo_dev[e], so_row); ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); } else { kb = krow[dev_pos(MKT_DEVORDER, t * R + e, NT)]; ka = krow[M + dev_pos(MKT_DEVORDER, t * R + e, NT)]; }
                         tacc[q][0][e] = cadd(tacc[q][0][e], cmul(z[h2][e], kb));
                         tacc[q][1][e] = cadd(tacc[q][1][e], cmul(z[h2][e], ka));
                         if (RotOcc<LOGM, NB>::MINW >= 3) __builtin_amdgcn_sched_barrier(0);   // keep the key-row live ranges short at 3 waves/SIMD
@@ -584,7 +584,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int e = 0; e < R; e++) { cplx mv; mv = PF_MONO ? mono_pf[e] : MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[0] - 1) * M * sizeof(cplx))) : mono[dev_pos(t * R + e, NT)]; t2[c][e] = cmul(mv, tacc[0][c][e]); }
+                for (int e = 0; e < R; e++) { cplx mv; mv = PF_MONO ? mono_pf[e] : MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[0] - 1) * M * sizeof(cplx))) : mono[dev_pos(MKT_DEVORDER, t * R + e, NT)]; t2[c][e] = cmul(mv, tacc[0][c][e]); }
         } else {                                                         // :157 / :648 tacc2 += monomial * tacc
 #pragma unroll
             for (int c = 0; c < 2; c++)
@@ -597,7 +597,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; c++)
 #pragma unroll
-                    for (int e = 0; e < R; e++) t2[c][e] = cadd(t2[c][e], cmul(MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[q] - 1) * M * sizeof(cplx))) : mono[dev_pos(t * R + e, NT)], tacc[q][c][e]));
+                    for (int e = 0; e < R; e++) t2[c][e] = cadd(t2[c][e], cmul(MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[q] - 1) * M * sizeof(cplx))) : mono[dev_pos(MKT_DEVORDER, t * R + e, NT)], tacc[q][c][e]));
             }
         }
         ROT_PROBE(4)
@@ -643,7 +643,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
             fft_forward<LOGM, LR, 1, MO>(z, MKT_PSI_F, lds, t, xs.lx);
             cplx *o = a.tout + (rot * 2 + c) * M;
 #pragma unroll
-            for (int e = 0; e < R; e++) o[a.tout_natural ? t * R + e : dev_pos(t * R + e, NT)] = z[0][e];
+            for (int e = 0; e < R; e++) o[a.tout_natural ? t * R + e : dev_pos(MKT_DEVORDER, t * R + e, NT)] = z[0][e];
         }
     }
 }
@@ -678,7 +678,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(
     const int l = a.l;
     int dp[R];
 #pragma unroll
-    for (int e = 0; e < R; e++) dp[e] = dev_pos(t * R + e, NT);
+    for (int e = 0; e < R; e++) dp[e] = dev_pos(MKT_DEVORDER_KR, t * R + e, NT);   // compile-time: the offsets of the 4 points fold into the addressing
     WORD *accg = reinterpret_cast<WORD *>(a.acc_io) + rot * (size_t)NP * N;
     WORD acc[NP][R][2];
 #pragma unroll
@@ -861,7 +861,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
     const Gadget<WORD> glev(a.l_lev, a.logB_lev), guni(a.l_uni, a.logB_uni);
     int dp[R];                     // device point order of this thread's slots
 #pragma unroll
-    for (int e = 0; e < R; e++) dp[e] = dev_pos(t * R + e, NT);
+    for (int e = 0; e < R; e++) dp[e] = dev_pos(MKT_DEVORDER, t * R + e, NT);
 
     cplx rt[R];
 #pragma unroll
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
     const int msbit = 32 - a.logN - 1;
     int dp[R];
 #pragma unroll
-    for (int e = 0; e < R; e++) dp[e] = dev_pos(t * R + e, NT);
+    for (int e = 0; e < R; e++) dp[e] = dev_pos(MKT_DEVORDER, t * R + e, NT);
     cplx rt[R];
 #pragma unroll
     for (int e = 0; e < R; e++) rt[e] = a.tw.roots[e * NT + t];
@@ -1498,10 +1498,10 @@ hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx 
     return hipSuccess;
 }
 
-hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, int to_device, hipStream_t s) {
+hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, int to_device, int order, hipStream_t s) {
     if (!npolys) return hipSuccess;
     MKT_DISPATCH_LOGM(logM, {
-        hipLaunchKernelGGL((reorder_kernel<LM>), dim3(blocks_for(npolys << LM, 256)), dim3(256), 0, s, in, out, npolys, to_device);
+        hipLaunchKernelGGL((reorder_kernel<LM>), dim3(blocks_for(npolys << LM, 256)), dim3(256), 0, s, in, out, npolys, to_device, order);
     });
     return hipGetLastError();
 }
@@ -1812,15 +1812,10 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
 // product exchange between the forward and the inverse transforms.  Keys are read in the resident (LOGR = 2) device
 // point order whatever LR this kernel uses.
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ int dev_pos_lr2(int x, int M) {      // dev_pos of the LOGR = 2 schedules, whatever LR this kernel runs
+__host__ __device__ __forceinline__ int dev_pos_lr2(int order, int x, int M) {      // dev_pos of the LOGR = 2 schedules, whatever LR this kernel runs
     const int NT2 = M >> 2;
-#if MKT_DEVORDER == 0
-    return x;
-#elif MKT_DEVORDER == 1
-    return (x & 3) * NT2 + (x >> 2);
-#else
+    if (order == 1) return (x & 3) * NT2 + (x >> 2);
     return ((x & 3) >> 1) * (2 * NT2) + ((x >> 2) << 1) + (x & 1);
-#endif
 }
 
 template <int LOGM, typename WORD, int LR, int LT>
@@ -1849,7 +1844,7 @@ __global__ __launch_bounds__((2 * LT * Plan<LOGM, LR>::NT)) void blindrotate_wid
     cplx rt[R], ri[R];
     int kp[R];                                // resident-table position of the point slot e holds after a forward transform
 #pragma unroll
-    for (int e = 0; e < R; e++) { rt[e] = a.tw.roots[e * NT + t]; ri[e] = a.tw.rootsinv[e * NT + t]; kp[e] = dev_pos_lr2(t * R + e, M); }
+    for (int e = 0; e < R; e++) { rt[e] = a.tw.roots[e * NT + t]; ri[e] = a.tw.rootsinv[e * NT + t]; kp[e] = dev_pos_lr2(MKT_DEVORDER, t * R + e, M); }
 
     WORD acc[R][2];                           // this group's polynomial (c) of the accumulator
     if (a.init_mode == 0) {
