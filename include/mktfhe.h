@@ -63,7 +63,7 @@ enum {
                              Transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch,
                              mkt_decompose_batch, mkt_modswitch_batch, mkt_not_batch) for every scheme; the gate path
                              (mkt_load_brk/ksk, mkt_keygen_device, mkt_gate, mkt_bootstrap, mkt_blindrotate,
-                             mkt_keyswitch) for MKT_CGGI with a 32-bit ring, whose ciphertexts are valid but NOT the
+                             mkt_keyswitch) for MKT_CGGI and MKT_LMSS (RLWE length 1, 32-bit ring), whose ciphertexts are valid but NOT the
                              reference's words (no Float64 truncation); other schemes return MKT_ERR_UNSUPPORTED
                              there */
 };

@@ -235,10 +235,10 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         HIPCHK(c, mktd::launch_ccs_blindrotate(c->logM, p.W, q, B, c->stream));
         return MKT_OK;
     }
-    if (c->exact) {          // CGGI, RLWE length 1, 32-bit ring (exact_gate_ok): every product exact mod 2^32
+    if (c->exact) {          // CGGI / LMSS, RLWE length 1, 32-bit ring (exact_gate_ok): every product exact mod 2^32
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_exact_blindrotate(c->logN, c->d_ntt, reinterpret_cast<const uint64_t *>(c->ks->d_brk), reinterpret_cast<const uint64_t *>(c->ks->d_monomial),
-                                                 lwe, stride, pre, p.n, p.l_gsw, p.logB_gsw, (uint32_t *)acc, B, c->stream));
+                                                 lwe, stride, pre, p.n, p.l_gsw, p.logB_gsw, mkt::is_block(p.scheme) ? p.blk_len : 1, (uint32_t *)acc, B, c->stream));
         return MKT_OK;
     }
     if (!mkt::is_kms(p.scheme)) {
@@ -352,11 +352,13 @@ int upload_ntt_tables(mkt_ctx *c) {
 // the gate path of an EXACT context: CGGI with RLWE length 1 on the 32-bit ring (every true product coefficient < p / 2)
 // (every true product coefficient below P / 2 = 2^60.88: 2l polynomials of N digits of magnitude <= 2^(logB-1) against 32-bit words)
 bool exact_gate_ok(const mkt_ctx *c) {
-    if (!(c->p.scheme == MKT_CGGI && c->p.k == 1 && c->p.W == 32)) return false;
-    const double bound = 2.0 * c->p.l_gsw * (double)c->p.N * std::ldexp(1.0, c->p.logB_gsw - 1) * 4294967296.0;
+    const bool lmss = c->p.scheme == MKT_LMSS;
+    if (!((c->p.scheme == MKT_CGGI || lmss) && c->p.k == 1 && c->p.W == 32)) return false;
+    if (lmss && c->p.blk_len != 3) return false;             // the block length the kernel is instantiated for (params.jl:8-13)
+    const double bound = (lmss ? 2.0 * c->p.blk_len : 1.0) * 2.0 * c->p.l_gsw * (double)c->p.N * std::ldexp(1.0, c->p.logB_gsw - 1) * 4294967296.0;
     return bound < 0.5 * (double)NTT_P[0] * (double)NTT_P[1];
 }
-#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI (RLWE length 1, 32-bit ring) only; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
+#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1, 32-bit ring, block length 3) only; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
 #define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; not offered by an MKT_ARITH_EXACT context"); } while (0)
 
 }  // namespace

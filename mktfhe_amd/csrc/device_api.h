@@ -128,7 +128,7 @@ hipError_t launch_ntt_fwd(int logN, int W, const uint64_t *tab, const void *p, u
 hipError_t launch_ntt_inv(int logN, int W, const uint64_t *tab, const uint64_t *t, void *p, size_t B, hipStream_t s);
 // CGGI blind rotation (RLWE length 1, 32-bit ring) with exact products; brk [n][2l][2][N], mono [2N][N] residues, natural order
 hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
-                                    int pre_switched, int n, int l, int logB, uint32_t *acc, size_t B, hipStream_t s);
+                                    int pre_switched, int n, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s);
 hipError_t launch_exact_polymul(int logN, int W, const uint64_t *tab, const void *a, const void *b, void *out, size_t B, hipStream_t s);
 
 }  // namespace mktd

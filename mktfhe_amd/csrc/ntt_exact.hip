@@ -269,14 +269,15 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_polymul_kernel(cons
 
 
 // ------------------------------------------------------------------------------------------------
-// Blind rotation with EXACT products (CGGI, RLWE length 1, 32-bit ring): bootstrapping.jl:32-76 with every
-// transform-domain product replaced by the exact negacyclic product mod 2^32 -- digit transforms, row MACs (:63-68),
-// monomial multiply (:71) and inverse (:72) all over Z_P, one exact lift per CMux step.  True coefficients stay below
-// 2 * 2l * N * 2^(logB-1) * 2^31 < P / 2 (checked on the host for the context's gadget).  One workgroup of N / 8 threads
-// per rotation; the accumulator lives in registers (slot e = coefficient e*NT + t).  Key and monomial tables are in the
-// transform's natural order, Montgomery form.
+// Blind rotation with EXACT products (CGGI and LMSS, RLWE length 1, 32-bit ring): bootstrapping.jl:32-76 / :114-165 with
+// every transform-domain product replaced by the exact negacyclic product mod 2^32 -- digit transforms, row MACs
+// (:63-68 / :146-154), monomial multiply (:71 / :157) and inverse (:72 / :162) all over Z_P, one exact lift per CMux step
+// (per block of LB key bits for LMSS: one decomposition, LB accumulators, tacc2 = sum of monomial * tacc, :131-163).  True
+// coefficients stay below 2 * LB * 2l * N * 2^(logB-1) * 2^31 < P / 2 (checked on the host for the context's gadget).
+// One workgroup of N / 8 threads per rotation; the accumulator lives in registers (slot e = coefficient e*NT + t).  Key
+// and monomial tables are in the transform's natural order, Montgomery form.
 // ------------------------------------------------------------------------------------------------
-template <int LOGN>
+template <int LOGN, int LB>
 __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk,
                                                                               const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe,
                                                                               int lwe_stride, int pre_switched, int n, int l, int logB, uint32_t *__restrict__ acc_io) {
@@ -296,41 +297,59 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[c][e] = accg[c * N + e * NT + t];
     const int msbit = 32 - LOGN - 1;
-    for (int i = 0; i < n; i++) {
-        const uint32_t v0 = at_src[i];
-        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
-        if (at == 0) continue;                                           // :48
-        Pt tacc[2][8];
+    for (int blk = 0; blk < n / LB; blk++) {
+        uint32_t ats[LB];
+        bool any = false;
 #pragma unroll
-        for (int pp = 0; pp < 2; pp++)
+        for (int q = 0; q < LB; q++) {
+            const uint32_t v0 = at_src[blk * LB + q];
+            ats[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+            any |= ats[q] != 0;
+        }
+        if (!any) continue;                                              // :48 / :145 (an all-zero block adds 0)
+        Pt tacc[LB][2][8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) { tacc[pp][e].a = 0; tacc[pp][e].b = 0; }
+        for (int q = 0; q < LB; q++)
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) { tacc[q][pp][e].a = 0; tacc[q][pp][e].b = 0; }
         for (int c = 0; c < 2; c++) {
             uint32_t tp[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) tp[e] = gd.prep(c ? acc[1][e] : acc[0][e]);      // :50-51 decompto!
+            for (int e = 0; e < 8; e++) tp[e] = gd.prep(c ? acc[1][e] : acc[0][e]);      // :50-51 / :131-132 decompto!
             for (int j = 0; j < l; j++) {
                 Pt z[8];
 #pragma unroll
                 for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(tp[e], j));
                 ntt_forward<LOGN>(z, tw[0], lds, t);
-                const uint64_t *row = brk + (((size_t)i * 2 * l + (size_t)(c * l + j)) * 2) * N + 8 * t;
 #pragma unroll
-                for (int e = 0; e < 8; e++) {                            // :63-68, exactly
-                    tacc[0][e] = pt_add(tacc[0][e], pt_mont(z[e], unpack(row[e])));
-                    tacc[1][e] = pt_add(tacc[1][e], pt_mont(z[e], unpack(row[N + e])));
+                for (int q = 0; q < LB; q++) {
+                    if (ats[q] == 0) continue;
+                    const uint64_t *row = brk + (((size_t)(blk * LB + q) * 2 * l + (size_t)(c * l + j)) * 2) * N + 8 * t;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {                        // :63-68 / :146-154, exactly
+                        tacc[q][0][e] = pt_add(tacc[q][0][e], pt_mont(z[e], unpack(row[e])));
+                        tacc[q][1][e] = pt_add(tacc[q][1][e], pt_mont(z[e], unpack(row[N + e])));
+                    }
                 }
             }
         }
-        const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
 #pragma unroll
         for (int pp = 0; pp < 2; pp++) {
             Pt s2[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) s2[e] = pt_mont(tacc[pp][e], unpack(mrow[e]));   // :71
-            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s2, tw[1], lds, t);            // :72
+            for (int e = 0; e < 8; e++) { s2[e].a = 0; s2[e].b = 0; }
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[pp][e] += (uint32_t)crt_signed(pt_shoup(s2[e], k.ninv));   // :73
+            for (int q = 0; q < LB; q++) {
+                if (ats[q] == 0) continue;
+                const uint64_t *mrow = mono + (size_t)(ats[q] - 1) * N + 8 * t;
+#pragma unroll
+                for (int e = 0; e < 8; e++) s2[e] = pt_add(s2[e], pt_mont(tacc[q][pp][e], unpack(mrow[e])));   // :71 / :157
+            }
+            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s2, tw[1], lds, t);            // :72 / :162
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[pp][e] += (uint32_t)crt_signed(pt_shoup(s2[e], k.ninv));   // :73 / :163
         }
     }
 #pragma unroll
@@ -399,13 +418,19 @@ hipError_t launch_exact_polymul(int logN, int W, const uint64_t *tab, const void
 }
 
 hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
-                                    int pre_switched, int n, int l, int logB, uint32_t *acc, size_t B, hipStream_t s) {
+                                    int pre_switched, int n, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
+    if (blk_len != 1 && blk_len != 3) return hipErrorInvalidValue;
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
     MKT_NTT_DISPATCH(logN, {
         const size_t lds = lds_bytes<LN>(2);
-        hipError_t e = ntt_set_lds(exact_blindrotate_kernel<LN>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((exact_blindrotate_kernel<LN>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, acc);
+        if (blk_len == 1) {
+            hipError_t e = ntt_set_lds(exact_blindrotate_kernel<LN, 1>, lds); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((exact_blindrotate_kernel<LN, 1>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, acc);
+        } else {
+            hipError_t e = ntt_set_lds(exact_blindrotate_kernel<LN, 3>, lds); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((exact_blindrotate_kernel<LN, 3>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, acc);
+        }
     });
     return hipGetLastError();
 }

@@ -1,6 +1,6 @@
-"""Exact-arithmetic restatement of the CGGI gate bootstrap (test infrastructure; checker of the MKT_ARITH_EXACT gate path):
-bootstrapping.jl:4-76 with every transform-domain product replaced by the exact negacyclic product mod 2^W (the
-oracle's schoolbook), i.e. what the reference's Float64 pipeline approximates.  Mod-switch, test vector, gadget
+"""Exact-arithmetic restatement of the CGGI and LMSS gate bootstraps (test infrastructure; checker of the MKT_ARITH_EXACT
+gate path): bootstrapping.jl:4-76 / :114-165 with every transform-domain product replaced by the exact negacyclic product
+mod 2^W (the oracle's schoolbook), i.e. what the reference's Float64 pipeline approximates.  Mod-switch, test vector, gadget
 decomposition and key switch are the integer steps of the oracle itself."""
 import numpy as np
 
@@ -41,8 +41,34 @@ def blindrotate(p, brk, atilde, acc):
     return acc.reshape(-1)
 
 
+def blindrotate_lmss(p, brk, atilde, acc):
+    """LMSS (bootstrapping.jl:114-165): one decomposition per block of blk_len key bits, every key bit of the block multiplies
+    the SAME digits into its own rows, the block adds sum_q (X^a_q - 1) * product_q"""
+    N, W, l, L = p.N, p.W, p.l_gsw, p.blk_len
+    mask = np.uint64((1 << W) - 1)
+    acc = acc.reshape(2, N).astype(np.uint64).copy()
+    brk = brk.reshape(p.n, 2 * l, 2, N).astype(np.uint64)
+    for blk in range(p.n // L):
+        dig = [O.decomp_poly(acc[c], l, p.logB_gsw, W) for c in range(2)]   # :131-132
+        add = np.zeros((2, N), dtype=np.uint64)
+        for q in range(L):
+            i = blk * L + q
+            a = int(atilde[i])
+            if a == 0:
+                continue                                                   # :145
+            for pp in range(2):
+                t = np.zeros(N, dtype=np.uint64)
+                for c in range(2):
+                    for j in range(l):                                     # :146-154
+                        t = (t + O.negacyclic(dig[c][j], brk[i, c * l + j, pp], W)) & mask
+                add[pp] = (add[pp] + monomial_minus_one(t, a, N, W)) & mask       # :157
+        acc = (acc + add) & mask                                           # :162-163
+    return acc.reshape(-1)
+
+
 def gate(p, so, brk, op, x, y):
     lin = O.gate_linear(op, x, y)
     at, bt = so.modswitch(lin)
-    acc = blindrotate(p, brk, at, so.testvector(bt))
+    rot = blindrotate_lmss if p.blk_len > 1 else blindrotate
+    acc = rot(p, brk, at, so.testvector(bt))
     return so.keyswitch(acc)

@@ -868,10 +868,12 @@ def test_exact_mode_integer_ntt(require_gpu, N, W):
 
 
 @pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=12, N=256), mk.CGGIparam.scaled(n=10, N=1024), mk.CGGI_N1024_l2.scaled(n=10),
-                               mk.CGGIparam.scaled(n=6, N=2048, l_gsw=4, logB_gsw=7)], ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-l{p.l_gsw}")
+                               mk.CGGIparam.scaled(n=6, N=2048, l_gsw=4, logB_gsw=7),
+                               mk.Blockparam.scaled(n=12, N=256, blk_d=4), mk.Blockparam.scaled(n=9, N=1024, blk_d=3)],
+                         ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-l{p.l_gsw}")
 def test_exact_mode_cggi_gates(require_gpu, p):
-    """MKT_ARITH_EXACT gate path (CGGI, 32-bit ring): blind rotation with integer-NTT products.  Accumulators and gate
-    outputs equal the exact-arithmetic restatement (tests/ref_exact.py: the oracle's integer steps + exact schoolbook
+    """MKT_ARITH_EXACT gate path (CGGI and LMSS, 32-bit ring): blind rotation with integer-NTT products.  Accumulators and
+    gate outputs equal the exact-arithmetic restatement (tests/ref_exact.py: the oracle's integer steps + exact schoolbook
     products) word for word, and decrypt."""
     import ref_exact as RX
     crs, keys = keygen(p, 71)
@@ -888,7 +890,8 @@ def test_exact_mode_cggi_gates(require_gpu, p):
     acc0 = np.stack([so.testvector(bt[j]) for j in range(B)])
     acc_x = sx.blindrotate_(at, acc0.astype(np.uint32).copy())
     for j in range(B):
-        assert np.array_equal(acc_x[j].astype(np.uint64).reshape(-1), RX.blindrotate(p, keys[0].brk, at[j], acc0[j])), f"exact blindrotate {j}"
+        rot = RX.blindrotate_lmss if p.blk_len > 1 else RX.blindrotate
+        assert np.array_equal(acc_x[j].astype(np.uint64).reshape(-1), rot(p, keys[0].brk, at[j], acc0[j])), f"exact blindrotate {j}"
     for op in (0, 3, 5):
         out = sx.gate(op, x, y)
         assert np.array_equal(out, np.stack([RX.gate(p, so, keys[0].brk, op, x[j], y[j]) for j in range(B)])), f"exact gate {op}"

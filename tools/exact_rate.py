@@ -11,7 +11,7 @@ ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=3)
 args = ap.parse_args()
 B = args.batch
-for p in (mk.CGGIparam, mk.CGGI_N1024_l2):
+for p in (mk.CGGIparam, mk.CGGI_N1024_l2, mk.Blockparam):
     keys = mk.PartyKeys(p, deterministic_seed=1)
     rng = np.random.default_rng(5)
     bits = rng.integers(0, 2, 2 * B).astype(bool)
