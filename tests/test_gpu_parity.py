@@ -896,6 +896,11 @@ def test_exact_mode_cggi_gates(require_gpu, p):
         out = sx.gate(op, x, y)
         assert np.array_equal(out, np.stack([RX.gate(p, so, keys[0].brk, op, x[j], y[j]) for j in range(B)])), f"exact gate {op}"
         assert np.array_equal(mk.lwe_decrypt(out, keys[0], p), GATE_FUNCS[op](bits[:B], bits[B:]))
+    # keys generated on the device from the secrets (mkt_keygen_device on an EXACT context: the same words, uploaded as residues)
+    sd = mk.Scheme(p, arith=mk.ARITH_EXACT)
+    sd.keygen_device(0, keys[0])
+    assert np.array_equal(sd.gate(0, x, y), sx.gate(0, x, y))
+    sd.close()
     # one CMux step from the same accumulator: the Float64 path is the exact value or one below it per coefficient
     # (truncating native(), arithmetic.jl:1-9); over many steps the two diverge in the words, not in the phase
     sf = gpu_scheme(p, crs, keys)
