@@ -236,6 +236,31 @@ def test_exact_ntt_restatement_against_schoolbook():
         assert R.inv(R.fwd(aw, W), W) == [int(x) for x in aw]
 
 
+@pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=9, N=128), mk.Blockparam.scaled(n=9, N=128, blk_d=3)], ids=lambda p: p.name)
+def test_exact_gate_restatement_decrypts(p):
+    """tests/ref_exact.py (the checker of the MKT_ARITH_EXACT gate path on the GPU): gates bootstrapped with exact products
+    decrypt to the plaintext gate, and one CMux step / block differs from the oracle's Float64 step by 0..2 per coefficient
+    (the truncating native(), arithmetic.jl:1-9)"""
+    import ref_exact as RX
+    crs, keys = keygen(p, 33)
+    so = oracle_scheme(p, crs, keys)
+    bits = np.array([1, 0, 1, 1, 0, 1, 0, 0], dtype=bool)
+    c = encrypt_bits(p, keys, bits, seed=3300)
+    for op in (0, 3):
+        out = np.stack([RX.gate(p, so, keys[0].brk, op, c[j], c[4 + j]) for j in range(4)])
+        assert np.array_equal(mk.lwe_decrypt(out, keys[0], p), GATE_FUNCS[op](bits[:4], bits[4:]))
+    lin = O.gate_linear(0, c[0], c[4])
+    at, bt = so.modswitch(lin)
+    L = max(p.blk_len, 1)
+    one = np.zeros_like(at); one[:L] = at[:L]                      # the first step (block) only
+    acc0 = so.testvector(bt)
+    rot = RX.blindrotate_lmss if p.blk_len > 1 else RX.blindrotate
+    ex = rot(p, keys[0].brk, one, acc0).astype(np.int64)
+    fl = so.blindrotate(one, acc0.copy()).astype(np.int64).reshape(-1)
+    d = (ex - fl + (1 << 31)) % (1 << 32) - (1 << 31)
+    assert d.min() >= 0 and d.max() <= 2 * L
+
+
 def test_monomial_table_semantics():
     N = 64
     f = O.Ffter(N, 32)
