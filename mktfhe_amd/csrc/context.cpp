@@ -781,7 +781,7 @@ int mkt_decompose_batch(mkt_ctx *c, const void *p, void *digits, int l, int logB
     return sd.out(digits);
 }
 
-// MKT_ARITH_EXACT: out = a (*) b in Z_{2^W}[X]/(X^N + 1), exact, for a gadget-digit polynomial a (signed, |a_i| < 2^20) and any b
+// MKT_ARITH_EXACT: out = a (*) b in Z_{2^W}[X]/(X^N + 1), exact, for a gadget-digit polynomial a (signed, N * max|a_i| < 2^28: true coefficients below P / 2) and any b
 int mkt_exact_polymul_batch(mkt_ctx *c, const void *a, const void *b, void *out, size_t B, int mem) {
     if (!c || !a || !b || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
     if (!c->exact) return fail(c, MKT_ERR_UNSUPPORTED, "mkt_exact_polymul_batch needs an MKT_ARITH_EXACT context");

@@ -406,7 +406,7 @@ class Scheme:
         return ko
 
     def exact_polymul(self, a, b):
-        """MKT_ARITH_EXACT contexts: a (*) b mod (X^N + 1, 2^W), exactly, for digit polynomials a (signed, small) and ring
+        """MKT_ARITH_EXACT contexts: a (*) b mod (X^N + 1, 2^W), exactly, for digit polynomials a (signed, N * max|a| < 2^28) and ring
         polynomials b; host arrays (..., N)"""
         aa = np.ascontiguousarray(a, dtype=self.params.ring_dtype)
         bb = np.ascontiguousarray(b, dtype=self.params.ring_dtype)
