@@ -10,7 +10,7 @@
 
 // The file is compiled once per translation unit MKT_TU (Makefile) so the template instantiations build in parallel:
 //   0 transforms, small kernels, key switch, dispatchers      3 / 5 blind rotation of the block schemes (LMSS, KMS_block), 32- / 64-bit ring
-//   1 blind rotation, 32-bit ring, plain schemes              4 general-k rotation, KMS phase 2, CCS
+//   1 blind rotation, 32-bit ring, plain schemes              4 KMS phase 2, CCS; 7 general-k rotation (CGGI / LMSS with k > 1)
 //   2 blind rotation, 64-bit ring, plain schemes              6 blind rotation, latency variant (one rotation over 2l thread groups)
 // MKT_TU undefined = everything in one unit.
 #ifdef MKT_TU
@@ -650,7 +650,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 
 #endif  // TU 1-3, 5
 
-#if MKT_IN_TU(4)
+#if MKT_IN_TU(7)
 // ------------------------------------------------------------------------------------------------
 // CGGI / LMSS blind rotation with RLWE length KR > 1 (bootstrapping.jl:32-76, :114-165 with k = KR): the general-k
 // form of the kernel above for the plain single-key schemes; no shipped parameter set uses it (params.jl:1-13 have
@@ -839,7 +839,9 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(
 #pragma unroll
         for (int e = 0; e < R; e++) { accg[c * N + e * NT + t] = acc[c][e][0]; accg[c * N + M + e * NT + t] = acc[c][e][1]; }
 }
+#endif  // TU 7
 
+#if MKT_IN_TU(4)
 // ------------------------------------------------------------------------------------------------
 // KMS phase 2 (bootstrapping.jl:448-558): k sequential merges, one workgroup per ciphertext.
 // < 1 % of the bootstrap's transforms; polynomials stream through a per-ciphertext scratch area,
@@ -1682,7 +1684,7 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
 }
 #endif  // TU 0
 
-#if MKT_IN_TU(4)
+#if MKT_IN_TU(7)
 template <int LM, typename WORD, int KR, bool BLK, int BL = 0>
 static hipError_t launch_kr_one(const RotArgs &a, size_t nrot, hipStream_t s) {
     using P = Plan<LM, LOGR>;
@@ -1708,7 +1710,9 @@ hipError_t launch_blindrotate_kr(int logM, int W, int kr, const RotArgs &a, size
     });
     return hipSuccess;
 }
+#endif  // TU 7
 
+#if MKT_IN_TU(4)
 hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
     MKT_DISPATCH_LOGM(logM, {

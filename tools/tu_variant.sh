@@ -5,8 +5,9 @@ cd $(dirname $0)/../mktfhe_amd/csrc
 mkdir -p /tmp/mkt_tuv
 OBJ=$(ls build/*.o); NEW=""
 for TU in $TUS; do
+  TF=$(grep "^TUFLAGS_$TU *=" Makefile | sed 's/^[^=]*= *//')        # the unit's own flags (Makefile)
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-cuda-compat -Wno-pass-failed -Wno-unused-function \
-      $EXTRA -DMKT_TU=$TU -c kernels.hip -o /tmp/mkt_tuv/kernels_tu${TU}_$SFX.o || touch /tmp/mkt_tuv/failed_$SFX ) &
+      $TF $EXTRA -DMKT_TU=$TU -c kernels.hip -o /tmp/mkt_tuv/kernels_tu${TU}_$SFX.o || touch /tmp/mkt_tuv/failed_$SFX ) &
   OBJ=$(echo "$OBJ" | grep -v kernels_tu$TU.o); NEW="$NEW /tmp/mkt_tuv/kernels_tu${TU}_$SFX.o"
 done; wait
 [ -e /tmp/mkt_tuv/failed_$SFX ] && { rm -f /tmp/mkt_tuv/failed_$SFX; echo "compile failed"; exit 1; }
