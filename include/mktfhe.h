@@ -133,7 +133,9 @@ int mkt_load_crs(mkt_ctx *ctx, const void *a, int fmt);
  *      TRUST: this call hands party `party`'s SECRET keys to the GPU of this context.  It is a party-local operation:
  *      a party runs it on its own machine / GPU and ships the resulting evaluation keys (key blob) to the evaluator.
  *      An evaluator context that runs it for every party holds all k secrets -- acceptable only in tests and
- *      benchmarks.  The secret buffers are zeroed on the device before they are freed. ---- */
+ *      benchmarks.  The secret buffers are zeroed on the device before they are freed and the host-side copies of the
+ *      party's stream key are wiped; the copy of that key carried in the kernel-argument segment of the keygen launches
+ *      lives in runtime-owned memory the library cannot erase (it is overwritten by later launches). ---- */
 int mkt_keygen_device(mkt_ctx *ctx, int party, const mkt_client_party *keys, const void *crs);
 /* the same, and the keys are also copied to the host: brk_out in the MKT_FMT_INT_COEFF layout of mkt_load_brk, ksk_out
  * in the layout of mkt_load_ksk -- what a party ships to the evaluator after generating its keys on its own GPU */

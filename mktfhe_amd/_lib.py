@@ -91,9 +91,11 @@ def lib():
         # When PyTorch is part of the process it brings its own copy of the HIP runtime (same SONAME).  Whichever copy is
         # mapped first serves both; mapped in the other order (this library, then torch) the runtime this library was
         # bound to sees no device.  So torch, if installed, goes first.
+        # A torch install that cannot load (missing ROCm libraries: OSError / RuntimeError) must not take the host-only
+        # client API (CRS, keygen, encrypt, decrypt) down with it.
         try:
             import torch  # noqa: F401
-        except ImportError:
+        except Exception:  # noqa: BLE001
             pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():

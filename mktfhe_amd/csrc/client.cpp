@@ -8,6 +8,7 @@
 // form; the device pre-transforms them (mkt_load_* with MKT_FMT_INT_COEFF).
 #include <cmath>
 #include <cstring>
+#include <string.h>   // explicit_bzero
 #include <functional>
 #include <thread>
 
@@ -55,6 +56,7 @@ int seed_to_key(const uint8_t *seed, uint32_t key[8]) {
         seed = tmp;
     }
     std::memcpy(key, seed, 32);
+    explicit_bzero(tmp, sizeof tmp);
     return MKT_OK;
 }
 
@@ -131,6 +133,7 @@ int mkt_client_random_seed(uint8_t out[32]) {
     uint32_t key[8];
     if (seed_to_key(nullptr, key)) return MKT_ERR_STATE;
     std::memcpy(out, key, 32);
+    explicit_bzero(key, sizeof key);
     return MKT_OK;
 }
 
@@ -162,6 +165,7 @@ int mkt_client_crs(const mkt_params *params, const uint8_t *seed, void *crs_out)
         uint64_t v = rng.next() & m;
         if (p.W == 64) ((uint64_t *)crs_out)[i] = v; else ((uint32_t *)crs_out)[i] = (uint32_t)v;
     }
+    explicit_bzero(key, sizeof key);
     return MKT_OK;
 }
 
@@ -360,6 +364,7 @@ int mkt_client_lwe_encrypt(const mkt_params *params, const mkt_client_party *K, 
     for (int i = 0; i < p.n; i++) { a[i] = (uint32_t)r.next(); dot += a[i] * K->lwekey[i]; }
     uint32_t mu = (uint32_t)(2 * (bit ? 1 : 0) - 1);
     out[sh.lwe_len - 1] = e + (0u - dot + (mu << 29));
+    explicit_bzero(key, sizeof key);
     return MKT_OK;
 }
 

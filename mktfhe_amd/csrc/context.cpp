@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string.h>   // explicit_bzero
 #include <cmath>
 #include <memory>
 #include <string>
@@ -56,6 +57,7 @@ struct mkt_ctx {
     int logM = 0, logN = 0, M = 0;
     int dev_order = MKT_DEVORDER;   // device point order of this context's resident tables (fft_device.h dev_pos)
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;   // a fork's own non-blocking stream (destroyed with the context); `stream` may be re-pointed by mkt_set_stream
     std::string err;
     std::shared_ptr<KeySet> ks;  // shared with the contexts forked from this one
     bool exact = false;          // MKT_ARITH_EXACT (integer NTT, two 31-bit primes); d_ntt = psi_rev | psiinv_rev | N^-1 | N^-1 2^32, with Shoup companions
@@ -443,6 +445,7 @@ int mkt_ctx_destroy(mkt_ctx *c) {
     clear_spans(c);
     void *ptrs[] = {c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch, c->d_ntt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); (void)hipStreamDestroy(c->own_stream); }
     delete c;                      // drops this context's reference to the key set; the last one frees it
     return MKT_OK;
 }
@@ -457,6 +460,14 @@ int mkt_ctx_fork(mkt_ctx *c, mkt_ctx **out) {
     auto *f = new mkt_ctx();
     f->p = c->p; f->sh = c->sh; f->device = c->device; f->logM = c->logM; f->logN = c->logN; f->M = c->M; f->dev_order = c->dev_order;
     f->ks = c->ks;
+    // the fork's own stream: non-blocking, so forks driven from several host threads neither serialise on the NULL stream
+    // nor against each other; mkt_set_stream may re-point the context at a caller's stream later
+    {
+        DevGuard dg(c->device);
+        hipError_t e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete f; return hipfail(c, e, "hipStreamCreateWithFlags(fork)"); }
+        f->stream = f->own_stream;
+    }
     *out = f;
     return MKT_OK;
 }
@@ -490,6 +501,8 @@ int mkt_set_twiddles(mkt_ctx *c, const double *psi, const double *psiinv, const 
     for (int i = 1; i < c->M; i++)
         if (std::memcmp(&psi[2 * i], &psiinv[2 * i], 8) != 0 || psiinv[2 * i + 1] != -psi[2 * i + 1])
             return fail(c, MKT_ERR_ARG, "mkt_set_twiddles: Psiinv is not the conjugate of Psi");
+    if (!twiddle_shape_ok(std::vector<double>(psi, psi + nd), c->M))   // checked BEFORE the host tables are replaced: a refused call leaves the context as it was
+        return fail(c, MKT_ERR_ARG, "twiddle table Psi does not have the reference's shape (Psi[1] = (eps,-1), Psi[2] = (c,-c), Psi[3] = (-c,-c))");
     c->ks->tw.psi.assign(psi, psi + nd); c->ks->tw.psiinv.assign(psiinv, psiinv + nd);
     c->ks->tw.roots.assign(roots, roots + nd); c->ks->tw.rootsinv.assign(rootsinv, rootsinv + nd);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -610,6 +623,7 @@ static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, 
     if (e == hipSuccess) e = mktd::launch_keygen_ksk(a, ksk, c->ks->n1p, c->sh.ksk_kr, c->sh.ksk_drows, mkt::is_block(p.scheme) ? 1 : 0, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     cleanup();
+    explicit_bzero(&a, sizeof a);            // the host copy of the party's stream key (the kernel-argument copy: see the TRUST note in mktfhe.h)
     if (e != hipSuccess) return hipfail(c, e, "device keygen");
     c->ks->brk_loaded[party] = 1; c->ks->ksk_loaded[party] = 1;
     if (ksk_out) return mkt_get_ksk(c, party, ksk_out);

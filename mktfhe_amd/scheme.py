@@ -36,10 +36,10 @@ def _arg(x, dtype, writable=False, scheme=None):
     with Scheme.set_stream, the engine enqueues on torch's CURRENT stream of that device, so its kernels are ordered
     with the producer and the consumer of the tensor like any torch op."""
     if _is_torch(x):
-        if scheme is not None:
-            scheme._follow_torch(x)
         if not x.is_cuda:
             raise ValueError("torch tensors must live on the GPU; pass numpy arrays for host memory")
+        if scheme is not None:
+            scheme._follow_torch(x)
         if not x.is_contiguous():
             raise ValueError("tensor must be contiguous")
         if x.element_size() != np.dtype(dtype).itemsize:
@@ -212,7 +212,7 @@ class Scheme:
         per concurrent caller, as concurrent bootstrapping! calls share one read-only scheme object in the reference.
         From then on the keys are immutable on every sharer."""
         f = object.__new__(Scheme)
-        f.params, f.device, f._user_stream = self.params, self.device, False
+        f.params, f.device, f.arith, f._user_stream = self.params, self.device, self.arith, False
         h = C.c_void_p()
         self._ck(_lib.lib().mkt_ctx_fork(self.h, C.byref(h)))
         f.h = h

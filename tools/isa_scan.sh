@@ -1,7 +1,7 @@
 # usage: bash tools/isa_scan.sh [LOGM=9]  -- every kernel of kernels.hip at one transform size: VGPRs, spills, stack bytes, instruction count
 LM=${1:-9}
 cd $(dirname $0)/../mktfhe_amd/csrc
-for TU in 0 1 2 3 4 5 6; do
+for TU in 0 1 2 3 4 5 6 7; do
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-cuda-compat -Wno-pass-failed -Wno-unused-function \
       -DMKT_TU=$TU -DMKT_ONLY_LOGM=$LM --cuda-device-only -S kernels.hip -o /tmp/isa_scan_$TU.s 2>/dev/null ) &
 done; wait
