@@ -220,6 +220,7 @@ mktd::RotArgs rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
     if (const char *v = getenv("MKT_ROT_STAGGER")) a.stagger = atoi(v);
     if (const char *v = getenv("MKT_ROT_SPLIT")) a.split = (unsigned)atoi(v);
     if (const char *v = getenv("MKT_ROT_WIDE")) a.wide = atoi(v);
+    if (const char *v = getenv("MKT_ROT_BLKG")) a.blk_group = atoi(v);
     return a;
 }
 

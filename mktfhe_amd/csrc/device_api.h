@@ -40,6 +40,7 @@ struct RotArgs {
     unsigned block0;          // first workgroup index of this launch (a rotation batch may be issued as several launches)
     unsigned split;           // workgroups per launch (0 = the whole batch in one launch)
     int dev_order;            // device point order of the resident tables (fft_device.h dev_pos)
+    int blk_group;            // block schemes: rotations per workgroup -- 0 automatic, 1 one (blindrotate_k1_kernel<LB>), 2 / 4 (rot_block.hip)
 };
 
 // KMS phase 2 (bootstrapping.jl:448-558), one workgroup per ciphertext.
@@ -117,6 +118,9 @@ hipError_t launch_negate(uint32_t *x, size_t words, hipStream_t s);
 hipError_t launch_modswitch(const uint32_t *lwe, uint32_t *atilde, uint32_t *btilde, int len, int logN, size_t B, hipStream_t s);
 hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int logN, int kacc, void *acc, size_t B, hipStream_t s);
 hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s);
+bool blockg_supported(int logM, int G);
+hipError_t launch_rot_blockg_u32(int logM, int G, const RotArgs &a, size_t nslots, hipStream_t s);
+hipError_t launch_rot_blockg_u64(int logM, int G, const RotArgs &a, size_t nslots, hipStream_t s);
 hipError_t launch_blindrotate_kr(int logM, int W, int kr, const RotArgs &a, size_t nrot, hipStream_t s);
 hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hipStream_t s);
 hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, hipStream_t s);

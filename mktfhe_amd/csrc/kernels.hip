@@ -1,10 +1,7 @@
 // HIP kernels of the gate-bootstrapping hot path for gfx950 (CDNA4, wave64).
 // Hand-written for MI355X only; no portability layers.  All floating point is IEEE double with
 // contraction off (one rounding per reference operation); see fft_device.h for the mapping.
-#include "device_api.h"
-#include "fft_device.h"
-
-#include <cstdlib>
+#include "kernel_common.h"
 
 #pragma clang fp contract(off)
 
@@ -45,23 +42,6 @@
 #endif
 
 namespace mktd {
-
-constexpr int LOGR = MKT_LOGR;  // points per thread (4 by default)
-
-extern __shared__ __attribute__((aligned(16))) unsigned char mkt_smem[];
-
-// per-thread exchange state: lane facts for the in-wave exchanges
-struct XS { LaneX lx; };
-__device__ __forceinline__ XS make_xs() { XS x; x.lx = make_lanex(); return x; }
-
-template <int LOGM>
-__device__ __forceinline__ void fft_forward1(cplx (&z)[1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t, XS &xs) {
-    fft_forward<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][1 << LOGR]>(z), psi, lds, t, xs.lx);
-}
-template <int LOGM>
-__device__ __forceinline__ void fft_inverse1(cplx (&z)[1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t, XS &xs) {
-    fft_inverse<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][1 << LOGR]>(z), psiinv, lds, t, xs.lx);
-}
 
 #if MKT_IN_TU(0)
 // ------------------------------------------------------------------------------------------------
@@ -304,32 +284,6 @@ __global__ void testvector_kernel(const uint32_t *__restrict__ lin, int lwe_stri
 
 #endif  // TU 0
 
-// ------------------------------------------------------------------------------------------------
-// digit -> transform helper: z[e] = (d(c_idx) - i*d(c_{idx+M})) * roots[idx]   (fft.jl:57-63)
-// ------------------------------------------------------------------------------------------------
-template <typename WORD, int R>
-__device__ __forceinline__ void digit_points(cplx (&z)[R], const WORD (&tp)[R][2], const Gadget<WORD> &gd, int j, const cplx (&rt)[R]) {
-#pragma unroll
-    for (int e = 0; e < R; e++) {
-        const int d0 = gd.digit(tp[e][0], j), d1 = gd.digit(tp[e][1], j);
-        cplx v; v.re = (double)d0; v.im = (double)(-d1);
-        z[e] = cmul(v, rt[e]);
-    }
-}
-
-// inverse transform of a transform-domain accumulator followed by native() (fft.jl:74-81)
-template <int LOGM, typename WORD>
-__device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)[1 << LOGR][2], const TwPtrs &tw, cplx *lds, int t, XS &xs) {
-    using P = Plan<LOGM, LOGR>;
-    fft_inverse1<LOGM>(z, tw.psiinv, lds, t, xs);
-#pragma unroll
-    for (int e = 0; e < P::R; e++) {
-        const cplx v = cmul(z[e], tw.rootsinv[e * P::NT + t]);
-        w[e][0] = native<WORD>(v.re);
-        w[e][1] = native<WORD>(-v.im);
-    }
-}
-
 #if MKT_IN_TU(1) || MKT_IN_TU(2) || MKT_IN_TU(3) || MKT_IN_TU(5)
 // ------------------------------------------------------------------------------------------------
 // Blind rotation, RLWE length 1.  bootstrapping.jl:32-76 (CGGI), :114-165 (LMSS), :389-443 and
@@ -379,17 +333,6 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
 #ifndef MKT_ROT_ROOTS_REG
 #define MKT_ROT_ROOTS_REG 1   // roots / rootsinv of the thread's points in registers for the whole rotation (2 * R * 4 VGPRs): 20 of the 51 table loads of a CMux gone
 #endif
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void *p, size_t bytes) {
-    const unsigned long long a = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0,
-                                             (int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
-}
-__device__ __forceinline__ cplx table_load(__amdgpu_buffer_rsrc_t rs, unsigned voff_bytes, unsigned soff_bytes) {
-    auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff_bytes, (int)soff_bytes, 0);
-    cplx r; __builtin_memcpy(&r, &v, 16); return r;
-}
-
 // Occupancy the register allocator is told to hit EXACTLY (amdgpu_waves_per_eu(min, max)): 3 waves/SIMD pays at
 // M >= 1024 with single transforms; elsewhere LDS admits 2 and the allocator should then use all 256 VGPRs --
 // builds that stopped at ~186 or chose <= 168 for a third wave LDS cannot host ran up to 25 % slower
@@ -1431,42 +1374,8 @@ __global__ __launch_bounds__(KS_LANES * WAVES) void keyswitch_mg_kernel(const Ks
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static inline int blocks_for(size_t total, int threads) {
-    size_t b = (total + threads - 1) / threads;
-    if (b > 2048) b = 2048;
-    if (b < 1) b = 1;
-    return (int)b;
-}
-
-template <typename K>
-static hipError_t set_lds(K kern, size_t bytes) {
-    if (bytes > 48 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return hipSuccess;
-}
-
 #if MKT_IN_TU(0)
 bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
-#endif
-
-#ifdef MKT_ONLY_LOGM   // development builds: instantiate one transform size only (seconds instead of a minute per unit)
-#define MKT_DISPATCH_LOGM(logM, ...)                 \
-    switch (logM) {                                  \
-    case MKT_ONLY_LOGM: { constexpr int LM = MKT_ONLY_LOGM; __VA_ARGS__; } break; \
-    default: return hipErrorInvalidValue;            \
-    }
-#else
-#define MKT_DISPATCH_LOGM(logM, ...)                 \
-    switch (logM) {                                  \
-    case 4:  { constexpr int LM = 4;  __VA_ARGS__; } break; \
-    case 5:  { constexpr int LM = 5;  __VA_ARGS__; } break; \
-    case 6:  { constexpr int LM = 6;  __VA_ARGS__; } break; \
-    case 7:  { constexpr int LM = 7;  __VA_ARGS__; } break; \
-    case 8:  { constexpr int LM = 8;  __VA_ARGS__; } break; \
-    case 9:  { constexpr int LM = 9;  __VA_ARGS__; } break; \
-    case 10: { constexpr int LM = 10; __VA_ARGS__; } break; \
-    case 11: { constexpr int LM = 11; __VA_ARGS__; } break; \
-    default: return hipErrorInvalidValue;            \
-    }
 #endif
 
 #if MKT_IN_TU(0)
@@ -1679,7 +1588,19 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
     // 2x MORE at M = 1024 where the groups need 8 points per thread), 1 = never, 2 = always where supported
     if (a.wide != 1 && wide_supported(logM, a.l, a.blk_len) && (a.wide == 2 || (nrot <= 256 && logM <= 9)))
         return launch_blindrotate_wide(logM, W, a, nrot, s);
-    if (a.blk_len > 1) return W == 64 ? launch_rot_block_u64(logM, a, nrot, s) : launch_rot_block_u32(logM, a, nrot, s);
+    if (a.blk_len > 1) {
+        // block schemes: G rotations of one slot per workgroup (rot_block.hip) once the batch fills the chip that way
+        // automatic: four rotations per workgroup where that workgroup exists (M <= 512) and the batch still fills the
+        // chip with one workgroup per compute unit (measured: Blockparam 5.54 -> 5.39 ms per 1024 gates; one rotation per
+        // workgroup below that, and at M = 1024 where only two rotations fit and run 15 % slower)
+        int G = a.blk_group;
+        if (G == 0) G = (blockg_supported(logM, 4) && logM == 9 && nrot >= 1024) ? 4 : 1;
+        if (G > 1 && blockg_supported(logM, G) && a.blk_len >= 2 && a.blk_len <= 4) {
+            const size_t nslots = (size_t)a.rows_per_gate;
+            return W == 64 ? launch_rot_blockg_u64(logM, G, a, nslots, s) : launch_rot_blockg_u32(logM, G, a, nslots, s);
+        }
+        return W == 64 ? launch_rot_block_u64(logM, a, nrot, s) : launch_rot_block_u32(logM, a, nrot, s);
+    }
     return W == 64 ? launch_rot_plain_u64(logM, a, nrot, s) : launch_rot_plain_u32(logM, a, nrot, s);
 }
 #endif  // TU 0

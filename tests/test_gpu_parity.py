@@ -202,6 +202,28 @@ def test_stages_small(require_gpu, p):
     _stage_check(p)
 
 
+# The block-binary rotation has two kernels: one rotation per workgroup (blindrotate_k1_kernel<LB>) and G = 2 / 4
+# rotations of one slot per workgroup (rot_block.hip: digit transforms shared through LDS, each key element loaded once
+# per G rotations).  MKT_ROT_BLKG forces the grouping; every stage and gate must give the oracle's words under each, at
+# batch sizes that leave ragged workgroups (B = 5, and the 3- / 6-ciphertext batches inside _stage_check).
+BLOCK_SETS = [
+    mk.Blockparam.scaled(n=30, N=256, blk_d=10),
+    mk.Blockparam.scaled(n=24, N=1024, blk_d=8),                       # the shipped shape (M = 512, l = 3, 2^9) at reduced n
+    mk.Blockparam.scaled(n=24, N=64, blk_d=12, blk_len=2),             # thread groups smaller than a wave
+    mk.Blockparam.scaled(n=24, N=512, blk_d=6, blk_len=4),
+    mk.KMS2partyblock.scaled(n=24, N=256, blk_d=8),
+    mk.KMS2partyblock.scaled(n=12, N=2048, blk_d=4),                   # the shipped 64-bit shape (M = 1024, l = 3, 2^12)
+    mk.KMS4partyblock.scaled(n=6, N=512, blk_d=2),
+]
+
+
+@pytest.mark.parametrize("G", ["1", "2", "4", "12", "14"])
+@pytest.mark.parametrize("p", BLOCK_SETS, ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-b{p.blk_len}")
+def test_block_rotation_groupings_are_bit_identical(require_gpu, p, G, monkeypatch):
+    monkeypatch.setenv("MKT_ROT_BLKG", G)
+    _stage_check(p, B=5, seed=3)
+
+
 FULL = [mk.CGGIparam, mk.CGGI_N1024_l2, mk.Blockparam, mk.Blockparam_k2, mk.KMS2party, mk.KMS2partyblock, mk.KMS2party_N1024_l2, mk.CCS2party]
 
 
