@@ -1597,7 +1597,8 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
         if (G == 0) G = (blockg_supported(logM, 4) && logM == 9 && nrot >= 1024) ? 4 : 1;
         if (G > 1 && blockg_supported(logM, G) && a.blk_len >= 2 && a.blk_len <= 4) {
             const size_t nslots = (size_t)a.rows_per_gate;
-            return W == 64 ? launch_rot_blockg_u64(logM, G, a, nslots, s) : launch_rot_blockg_u32(logM, G, a, nslots, s);
+            const hipError_t e = W == 64 ? launch_rot_blockg_u64(logM, G, a, nslots, s) : launch_rot_blockg_u32(logM, G, a, nslots, s);
+            if (e != hipErrorInvalidValue) return e;     // a shape the grouped kernels do not cover (LDS budget): one rotation per workgroup below
         }
         return W == 64 ? launch_rot_block_u64(logM, a, nrot, s) : launch_rot_block_u32(logM, a, nrot, s);
     }

@@ -629,6 +629,227 @@ void blindrotate_blk_pair_kernel(const RotArgs a, int wg_per_slot) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One rotation per workgroup, ONE THREAD GROUP PER POLYNOMIAL of the accumulator (b, a).  Group c owns polynomial c:
+// its words live in that group's registers for the whole rotation, the group decomposes and transforms its l digits
+// (both groups at the same time), accumulates the LB key bits' products that end in polynomial c (:146-154: the rows'
+// own polynomial c), sums them over the key bits with the monomials (:157) and runs the inverse transform and the
+// update of polynomial c (:162-163) -- all without leaving the group.  Only the digit transforms cross: the b digits
+// through a two-slot exchange buffer as they are produced, the a digits parked in LDS until the b digits are done,
+// because every sum runs over the digits in the reference's order (b digits first).
+// Per thread: LB * 4 transform-domain accumulators instead of LB * 2 * 4, one polynomial's words, LB * 4 key elements per
+// digit -- room to request every digit's key elements a whole step ahead and to keep the twist factors in registers.
+// LDS: Psi | 2 x FFT staging | b-digit exchange [2][M] | a-digit store [l][M].
+// ------------------------------------------------------------------------------------------------
+template <int LOGM, typename WORD, int LB, int LT, int BT>
+__global__ __launch_bounds__((2 * Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void blindrotate_blk_split_kernel(const RotArgs a) {
+    using P = Plan<LOGM, LOGR, 1>;
+#ifdef MKT_BLK_MO
+    constexpr int MO = MKT_BLK_MO;
+#else
+    constexpr int MO = !(LOGM & 1) ? 1 : -1;
+#endif
+    constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
+    static_assert(MKT_DEVORDER == 1, "a thread's stored positions assume the slot-major device point order");
+    cplx *psi_l = reinterpret_cast<cplx *>(mkt_smem);
+    cplx *stg_all = psi_l + M;
+    cplx *bx = stg_all + (size_t)2 * P::LDS_CPLX;
+    cplx *ax = bx + (size_t)2 * M;
+    const int tid = threadIdx.x, grp = tid / NT, t = tid % NT;     // grp = the polynomial this thread's group owns
+    cplx *stg = stg_all + (size_t)grp * P::LDS_CPLX;
+    XS xs = make_xs();
+    for (int i = tid; i < M; i += 2 * NT) psi_l[i] = a.tw.psi[i];
+    __syncthreads();
+
+    const unsigned bid = blockIdx.x + a.block0;
+    if (a.stagger > 0 && ((bid >> 8) & 1)) {
+        for (int s = 0; s < a.stagger; s++) __builtin_amdgcn_s_sleep(8);
+    }
+    const size_t gate = bid % (size_t)a.ngates;
+    const int slot = (int)(bid / (size_t)a.ngates);
+    const size_t rot = gate * (size_t)a.rows_per_gate + slot;
+    const int party = __builtin_amdgcn_readfirstlane(a.slot_party[slot]), row = __builtin_amdgcn_readfirstlane(a.slot_row[slot]);
+    typedef const __attribute__((address_space(4))) uint32_t *cu32p;
+    const cu32p at_k = (cu32p)(unsigned long long)(a.lwe + gate * (size_t)a.lwe_stride + (size_t)party * a.n);
+    const cplx *brk = a.brk + (size_t)party * a.brk_party_stride;
+    const __amdgpu_buffer_rsrc_t rs_brk = table_rsrc(brk, (size_t)a.brk_party_stride * sizeof(cplx));
+    const __amdgpu_buffer_rsrc_t rs_mono = table_rsrc(a.monomial, (size_t)2 * N * M * sizeof(cplx));
+    unsigned vo[R];                               // byte offsets of this thread's points in a resident row: point 4t+e at e*NT + t
+#pragma unroll
+    for (int e = 0; e < R; e++) vo[e] = (unsigned)(e * NT + t) * 16u;
+    const Gadget<WORD> gd(LT ? LT : a.l, (LT && BT) ? BT : a.logB);
+    const int l = LT ? LT : a.l;
+    cplx rt[R], ri[R];                            // twist / untwist factors of this thread's points
+#pragma unroll
+    for (int e = 0; e < R; e++) { rt[e] = a.tw.roots[e * NT + t]; ri[e] = a.tw.rootsinv[e * NT + t]; }
+
+    WORD acc[R][2];                               // polynomial grp: words (e*NT + t) and (e*NT + t + M)
+    if (a.init_mode == 0) {
+        const WORD *src = reinterpret_cast<const WORD *>(a.acc_io) + rot * 2 * N + (size_t)grp * N;
+#pragma unroll
+        for (int e = 0; e < R; e++) { acc[e][0] = src[e * NT + t]; acc[e][1] = src[M + e * NT + t]; }
+    } else {                                      // bootstrapping.jl:609-612
+#pragma unroll
+        for (int e = 0; e < R; e++) { acc[e][0] = 0; acc[e][1] = 0; }
+        if (grp == 0 && t == 0) acc[0][0] = (WORD)1 << (W - (row + 1) * a.logB_lev);
+    }
+
+    const int nblk = a.n / LB;
+    const int msbit = 32 - a.logN - 1;
+    uint32_t at_next[LB];
+#pragma unroll
+    for (int q = 0; q < LB; q++) at_next[q] = at_k[q];
+
+    cplx K[LB][R];                                // key elements of one digit: rows (key bit q, digit g), polynomial grp
+    auto load_keys = [&](int kb, int g) {
+#pragma unroll
+        for (int q = 0; q < LB; q++) {
+            const unsigned so_row = (unsigned)(((((size_t)(kb * LB + q) * 2 * l + (size_t)g) * 2) + (size_t)grp) * M * sizeof(cplx));
+#pragma unroll
+            for (int e = 0; e < R; e++) K[q][e] = table_load(rs_brk, vo[e], so_row);
+        }
+    };
+    int kblk = -1;
+
+    for (int blk = 0; blk < nblk; blk++) {
+        uint32_t ats[LB];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < LB; q++) {
+            const uint32_t v = at_next[q];
+            ats[q] = a.pre_switched ? v : divbits<uint32_t>(v, msbit);           // bootstrapping.jl:8
+            any |= ats[q] != 0;
+        }
+        {
+            const int nb = blk + 1 < nblk ? blk + 1 : blk;
+#pragma unroll
+            for (int q = 0; q < LB; q++) at_next[q] = at_k[nb * LB + q];
+        }
+        if (!any) continue;                       // :145 / :638
+        if (kblk != blk) load_keys(blk, 0);
+
+        cplx tacc[LB][R];
+#pragma unroll
+        for (int q = 0; q < LB; q++)
+#pragma unroll
+            for (int e = 0; e < R; e++) { tacc[q][e].re = 0.0; tacc[q][e].im = 0.0; }
+        auto mac = [&](const cplx (&zd)[R]) {
+#pragma unroll
+            for (int q = 0; q < LB; q++)
+#pragma unroll
+                for (int e = 0; e < R; e++) tacc[q][e] = cadd(tacc[q][e], cmul(zd[e], K[q][e]));   // :146-154 muladdto!
+        };
+
+        // rounds: both groups transform digit j of their own polynomial; the b digit is consumed at once (g = j), the a
+        // digit is parked (g = l + j comes after every b digit)
+#pragma unroll 1
+        for (int j = 0; j < l; j++) {
+            cplx z[1][R];
+#pragma unroll
+            for (int e = 0; e < R; e++) {                                // :131-140 decompto!, fft.jl:57-63 twist
+                const int d0 = gd.digit(gd.prep(acc[e][0]), j), d1 = gd.digit(gd.prep(acc[e][1]), j);
+                cplx v; v.re = (double)d0; v.im = (double)(-d1);
+                z[0][e] = cmul(v, rt[e]);
+            }
+            fft_forward<LOGM, LOGR, 1, MO>(z, psi_l, stg, t, xs.lx);
+            cplx *dst = grp == 0 ? bx + (size_t)(j & 1) * M : ax + (size_t)j * M;
+#pragma unroll
+            for (int e = 0; e < R; e++) dst[e * NT + t] = z[0][e];
+            __syncthreads();
+            cplx zb[R];
+#pragma unroll
+            for (int e = 0; e < R; e++) zb[e] = bx[(size_t)(j & 1) * M + e * NT + t];
+            mac(zb);
+            __builtin_amdgcn_sched_barrier(0);
+            load_keys(blk, j + 1);                                       // the next b digit, or the first a digit (g = l)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cplx mv[LB][R];
+#pragma unroll 1
+        for (int j = 0; j < l - 1; j++) {                                // a digits 0 .. l-2 from the store
+            cplx za[R];
+#pragma unroll
+            for (int e = 0; e < R; e++) za[e] = ax[(size_t)j * M + e * NT + t];
+            mac(za);
+            __builtin_amdgcn_sched_barrier(0);
+            load_keys(blk, l + j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            cplx za[R];
+#pragma unroll
+            for (int e = 0; e < R; e++) za[e] = ax[(size_t)(l - 1) * M + e * NT + t];
+            __syncthreads();                      // every read of the exchange buffers and of the store is done: the next block may refill them
+#pragma unroll
+            for (int q = 0; q < LB; q++) {                               // :157 monomial rows, in flight during the last multiply-adds
+                const unsigned so_m = (unsigned)((size_t)(ats[q] ? ats[q] - 1 : 0) * M * sizeof(cplx));
+#pragma unroll
+                for (int e = 0; e < R; e++) mv[q][e] = table_load(rs_mono, vo[e], so_m);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mac(za);
+        }
+        // :157 / :648 tacc2 += monomial[atilde_q] * tacc[q], q ascending from zero -- already in the inverse transform's ownership
+        cplx s[1][R];
+#pragma unroll
+        for (int e = 0; e < R; e++) { s[0][e].re = 0.0; s[0][e].im = 0.0; }
+#pragma unroll
+        for (int q = 0; q < LB; q++) {
+            if (ats[q] == 0) continue;
+#pragma unroll
+            for (int e = 0; e < R; e++) s[0][e] = cadd(s[0][e], cmul(mv[q][e], tacc[q][e]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk + 1 < nblk) { load_keys(blk + 1, 0); kblk = blk + 1; }   // hidden behind the inverse transform
+        __builtin_amdgcn_sched_barrier(0);
+        fft_inverse<LOGM, LOGR, 1, true, MO>(s, psi_l, stg, t, xs.lx);   // :162-163 ifftto!, add!
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            const cplx v = cmul(s[0][e], ri[e]);                         // fft.jl:76-80 untwist + native
+            acc[e][0] = (WORD)(acc[e][0] + native<WORD>(v.re));
+            acc[e][1] = (WORD)(acc[e][1] + native<WORD>(-v.im));
+        }
+    }
+
+    if (a.out_mode == 0) {
+        WORD *dst = reinterpret_cast<WORD *>(a.acc_io) + rot * 2 * N + (size_t)grp * N;
+#pragma unroll
+        for (int e = 0; e < R; e++) { dst[e * NT + t] = acc[e][0]; dst[M + e * NT + t] = acc[e][1]; }
+    } else {                                      // :657 fftto!(tacc, acc): each group its own polynomial
+        cplx z[1][R];
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            cplx v; v.re = word_to_f64<WORD>(acc[e][0]); v.im = word_to_f64<WORD>((WORD)((WORD)0 - acc[e][1]));
+            z[0][e] = cmul(v, rt[e]);
+        }
+        fft_forward<LOGM, LOGR, 1, MO>(z, psi_l, stg, t, xs.lx);
+        cplx *o = a.tout + (rot * 2 + grp) * M;
+#pragma unroll
+        for (int e = 0; e < R; e++) o[a.tout_natural ? t * R + e : dev_pos(MKT_DEVORDER, t * R + e, NT)] = z[0][e];
+    }
+}
+
+template <int LM, typename WORD, int LB, int LT, int BT>
+static hipError_t launch_blk_split_lt(const RotArgs &a, size_t nrot, hipStream_t s) {
+    using P = Plan<LM, LOGR, 1>;
+    if (2 * P::NT > 1024) return hipErrorInvalidValue;
+    const size_t lds_bytes = ((size_t)P::M + (size_t)2 * P::LDS_CPLX + (size_t)2 * P::M + (size_t)a.l * P::M) * sizeof(cplx);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = set_lds(blindrotate_blk_split_kernel<LM, WORD, LB, LT, BT>, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((blindrotate_blk_split_kernel<LM, WORD, LB, LT, BT>), dim3((unsigned)nrot), dim3(2 * P::NT), lds_bytes, s, a);
+    return hipGetLastError();
+}
+template <int LM, typename WORD, int LB>
+static hipError_t launch_blk_split(const RotArgs &a, size_t nrot, hipStream_t s) {
+    if constexpr (2 * (1 << LM) / 4 > 1024) { return hipErrorInvalidValue; } else {
+        if constexpr (LB == 3 && LM == 9 && sizeof(WORD) == 4) { if (a.l == 3 && a.logB == 9) return launch_blk_split_lt<LM, WORD, LB, 3, 9>(a, nrot, s); }
+        if constexpr (LB == 3 && LM == 10 && sizeof(WORD) == 8) { if (a.l == 3 && a.logB == 12) return launch_blk_split_lt<LM, WORD, LB, 3, 12>(a, nrot, s); }
+        return launch_blk_split_lt<LM, WORD, LB, 0, 0>(a, nrot, s);
+    }
+}
+
 template <int LM, typename WORD, int LB, int G, int LT, int BT>
 static hipError_t launch_blk_pair_lt(const RotArgs &a, size_t nslots, hipStream_t s) {
     using P = Plan<LM, LOGR, 2>;
@@ -685,6 +906,7 @@ static hipError_t launch_blk_lb(const RotArgs &a, size_t nslots, bool pair, hipS
 #if MKT_BLK_WORD == 32
 // G rotations per workgroup (2 or 4) supported at this size?  (workgroup of G * M / 4 threads, LDS budget)
 bool blockg_supported(int logM, int G) {
+    if (G == 21) return logM >= 4 && logM <= 11;       // the launcher checks the LDS budget for the gadget length at hand
     G %= 10;
     if (logM < 4 || logM > 11 || (G != 2 && G != 4)) return false;
     const size_t M = (size_t)1 << logM;
@@ -701,6 +923,18 @@ bool blockg_supported(int logM, int G) {
 // G = 2 / 4: rotations per workgroup, single digit transforms; G = 12 / 14: the same with paired transforms
 hipError_t MKT_BLK_FN(int logM, int G, const RotArgs &a, size_t nslots, hipStream_t s) {
     if (!a.ngates || !nslots) return hipSuccess;
+    if (G == 21) {                        // one rotation per workgroup, one thread group per polynomial
+        const size_t nrot = a.ngates * nslots;
+        MKT_DISPATCH_LOGM(logM, {
+            switch (a.blk_len) {
+            case 2: return launch_blk_split<LM, MKT_BLK_T, 2>(a, nrot, s);
+            case 3: return launch_blk_split<LM, MKT_BLK_T, 3>(a, nrot, s);
+            case 4: return launch_blk_split<LM, MKT_BLK_T, 4>(a, nrot, s);
+            default: return hipErrorInvalidValue;
+            }
+        });
+        return hipSuccess;
+    }
     const bool pair = G >= 10;
     G %= 10;
     MKT_DISPATCH_LOGM(logM, {
