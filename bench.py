@@ -8,6 +8,11 @@ configs[1]: KMS multi-key k=2, N=1024, batch=1024 (synthetic shape, l_gsw=2 -- S
 
   python bench.py [--gpus N --steps K --warmup W] [--workload NAME --batch B]
 
+--scaling weak (default): --batch gates PER GPU; --scaling strong: --batch gates IN TOTAL, contiguous shards per rank
+(mktfhe_amd.distributed.shard_slices) -- BASELINE.json configs[2] / [3] are fixed-total batches:
+  python bench.py --gpus 8 --workload kms4party --batch 65536 --scaling strong
+  python bench.py --gpus 8 --workload ccs8_n2048 --batch 8192 --scaling strong
+
 --gpus N > 1 without a torch.distributed.run environment: this process -- before it touches the GPU -- starts N
 fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one GPU each), waits for
 them, relays rank 0's JSON line and exits non-zero if any rank failed.  Under torch.distributed.run it is a rank.
@@ -50,6 +55,18 @@ WORKLOADS = {
     "ccs8party": ("CCS8party", "CCS8party k=8, N=1024 (src/tfhe/params.jl:31-37)"),
     "ccs8_n2048": ("CCS8party_N2048", "CCS k=8, N=2048 (BASELINE.json configs[3], synthetic shape)"),
 }
+
+# Parameter sets whose own output noise leaves less than 6 sigma of decryption margin, with the per-gate failure probability
+# that noise predicts for gates on all-party ciphertexts (tools/noise_theory.py: input phase error of a NAND = sqrt(2) x the
+# output sigma of the previous level; profiles/r03_noise_theory_vs_measured.md).  Every other set must decrypt every gate.
+NOISY_SETS = {"KMS2party_N1024_l2": 1.5e-3, "KMS2party": 1.5e-5, "KMS2partyblock": 5e-6, "KMS8party": 1e-3,
+              "CCS2party": 4.6e-3, "CCS4party": 0.20, "CCS8party": 0.033, "CCS16party": 0.37}
+
+
+def allowed_wrong(pname, checked):
+    rate = NOISY_SETS.get(pname)
+    return 0 if rate is None else int(3 * rate * checked) + 3
+
 
 # no-FMA f64 vector peak: 256 CUs x 4 SIMDs x 16 lanes/clk (a wave64 v_add_f64 / v_mul_f64 issues over 4 cycles) x
 # 2.4 GHz = 39.3 TFLOP/s (half of the 78.6 TFLOP/s FMA datasheet figure; MI355X_MICROARCH.md: FP32 vector 157.3)
@@ -105,6 +122,10 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # MKT_BENCH_PIN=1: each rank sees only its own GPU (HIP_VISIBLE_DEVICES = rank; the rank then uses device 0).  Off by
+        # default: RCCL wants every peer visible for its topology search.
+        if os.environ.get("MKT_BENCH_PIN") == "1" and os.environ.get("MKT_BENCH_SHARE_GPU") != "1":
+            env.update(HIP_VISIBLE_DEVICES=str(r), MKT_BENCH_DEVICE="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0 = procs[0].communicate()[0].decode()
@@ -208,12 +229,26 @@ def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, w
     ks_ms, _ = sch.kernel_ms(2)
     p2_ms, _ = sch.kernel_ms(4)
     sch.enable_timing(False)
+    mine = elapsed
     elapsed = D.max_over_ranks(elapsed, device=red_dev)
+    per_rank = [1e3 * mine / max(steps, 1)]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        t[dist.get_rank()] = per_rank[0]
+        dist.all_reduce(t)
+        per_rank = [float(v) for v in t.cpu()]
     res = out.cpu().numpy().view(np.uint32)
     want = ~(bits[:B] & bits[B:])
     got = mk.lwe_decrypt(res, keys if p.multikey else keys[0], p)
     errs = int(np.count_nonzero(got != want))
-    return dict(elapsed=elapsed, rot_ms=rot_ms, rot_n=rot_n, ks_ms=ks_ms, p2_ms=p2_ms, res=res, decrypt_errors=errs)
+    if world > 1:                                   # wrong decryptions of the whole job, not of rank 0's shard
+        e = torch.tensor([errs, B], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(e)
+        errs_all, checked_all = int(e[0]), int(e[1])
+    else:
+        errs_all, checked_all = errs, B
+    return dict(elapsed=elapsed, rot_ms=rot_ms, rot_n=rot_n, ks_ms=ks_ms, p2_ms=p2_ms, res=res, decrypt_errors=errs,
+                decrypt_errors_all=errs_all, decrypt_checked_all=checked_all, per_rank_ms=per_rank)
 
 
 def rot_roofline(mk, p, B, t, workload):
@@ -306,6 +341,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--workload", default="kms2_n1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch gates per GPU; strong: --batch gates in total, sharded over the ranks")
     ap.add_argument("--inputs", default="mixed", choices=["mixed", "fresh"], help="mixed: every ciphertext involves all k parties (default); fresh: single-party first-level encryptions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the transform legs (roofline_transform)")
@@ -327,6 +363,8 @@ def main():
     share = os.environ.get("MKT_BENCH_SHARE_GPU") == "1"
     if share:
         local, backend = 0, os.environ.get("MKT_BENCH_BACKEND", "gloo")
+    if "MKT_BENCH_DEVICE" in os.environ:            # a rank pinned to one visible device (MKT_BENCH_PIN)
+        local = int(os.environ["MKT_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     D.init_process_group(backend, device=dev)     # "nccl" is RCCL on ROCm; rendezvous + timing barrier only
@@ -340,6 +378,11 @@ def main():
     pname, desc = WORKLOADS[args.workload]
     p = getattr(mk, pname)
     B = args.batch
+    if args.scaling == "strong":                    # this rank's contiguous shard of the fixed total batch
+        lo, hi = D.shard_slices(args.batch, world)[rank]
+        B = hi - lo
+        if B == 0:
+            raise SystemExit(f"rank {rank}: empty shard (batch {args.batch} over {world} ranks)")
     need_host_keys = rank == 0 and world == 1 and not args.no_cpu_baseline
     crs, keys, sch = make_scheme(mk, p, local, need_host_keys)
     bits, x, y = make_inputs(mk, torch, p, keys, sch, B, rank, dev, args.inputs)
@@ -350,17 +393,23 @@ def main():
 
     line = None
     if rank == 0:
-        gates = world * B * args.steps
+        total_batch = args.batch if args.scaling == "strong" else world * B
+        gates = total_batch * args.steps
         line = {
             "metric": "NAND gate-bootstraps/sec", "value": gates / t["elapsed"], "unit": "gates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t["elapsed"] / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "params": pname, "parties": p.k, "N": p.N, "n": p.n, "ring_bits": p.W,
-                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "op": "NAND", "inputs": args.inputs, "arith": "F64REF", "sharding": "gates across GPUs, keys replicated"},
-            "ranks_seen": ranks_seen,
-            # wrong decryptions, where present, are the parameter set's own noise: the oracle makes the identical
-            # errors (`oracle_bitexact` is the parity gate); the flag only guards against gross failure
-            "decrypt_ok": t["decrypt_errors"] <= max(B // 50, 1), "decrypt_errors": t["decrypt_errors"], "decrypt_checked": B,
+                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": "NAND", "inputs": args.inputs, "arith": "F64REF", "sharding": "gates across GPUs, keys replicated"},
+            "ranks_seen": ranks_seen, "per_rank_ms_per_step": t["per_rank_ms"],
+            # Wrong decryptions are the parameter set's own output noise (profiles/r03_noise_theory_vs_measured.md: predicted
+            # from the schemes' variance formulas, measured on this engine; the oracle produces the identical words --
+            # `oracle_bitexact` is the parity gate).  Sets whose margin is >= 6 sigma must decrypt EVERY gate; the noisy ones
+            # (margin / sigma in NOISY_SETS) report their measured failure rate and are held to 3x the predicted one.
+            "decrypt_ok": t["decrypt_errors_all"] <= allowed_wrong(pname, t["decrypt_checked_all"]),
+            "decrypt_errors": t["decrypt_errors_all"], "decrypt_checked": t["decrypt_checked_all"],
+            "decrypt_failure_rate_measured": t["decrypt_errors_all"] / max(t["decrypt_checked_all"], 1),
+            "decrypt_failure_rate_predicted": NOISY_SETS.get(pname, 0.0),
             "kernels_ms_per_step": {"blindrotate": t["rot_ms"] / max(args.steps, 1), "kms_phase2": t["p2_ms"] / max(args.steps, 1),
                                     "keyswitch": t["ks_ms"] / max(args.steps, 1)},
         }
