@@ -16,31 +16,6 @@
 #define MKT_IN_TU(n) 1
 #endif
 
-#ifndef MKT_CCS_MO
-#define MKT_CCS_MO 0xff   // exchange-route mode of the CCS kernel's transforms (fft_device.h Route): 0xff = library default
-#endif
-#ifndef MKT_CCS_LOOPED
-#define MKT_CCS_LOOPED 1  // CCS kernel: 1 = one loop over the input polynomials of a step + one over its outputs (4 transform bodies in the code); 0 = every call site inlined (10 bodies, a stack array: 17-21 % slower).  A single job loop with 3 bodies measured 2-3 % slower than 1.
-#endif
-#ifndef MKT_CCS_LT
-#define MKT_CCS_LT 1      // CCS kernel specialised for the shipped gadgets (length and base compile-time constants)
-#endif
-#ifndef MKT_CCS_FPF
-#define MKT_CCS_FPF 1     // CCS kernel, output loop: monomial row loaded once, next polynomial + accumulator words requested ahead of the inverse
-#endif
-#ifndef MKT_CCS_PAIR
-#define MKT_CCS_PAIR 0    // CCS kernel: the digit transforms of a decomposition run two at a time (measured: -2..-5 %)
-#endif
-#ifndef MKT_CCS_ABL
-#define MKT_CCS_ABL 0     // development ablations (wrong results, timing only): 1 = no key-row loads
-#endif
-#ifndef MKT_CCS_PROBE
-#define MKT_CCS_PROBE 0   // development: workgroup 0 prints the s_memtime ticks its first wave spent in each phase of the CCS step
-#endif
-#ifndef MKT_CCS_PF
-#define MKT_CCS_PF 1      // CCS kernel: key rows of a digit requested before its forward transform (CCS2party +3 %, CCS8party +1 %)
-#endif
-
 namespace mktd {
 
 #if MKT_IN_TU(0)
@@ -49,40 +24,23 @@ namespace mktd {
 // ------------------------------------------------------------------------------------------------
 // Batched transforms HBM -> HBM.  Loads are contiguous across the wave (8 B or 4 B per lane), software-pipelined one
 // polynomial ahead in registers.  The reference-order output (point 4t+e) is either stored as 64 B per lane
-// (MKT_FFT_CONTIG_STORE 0) or brought to thread-contiguous ownership by one more staging exchange and stored as
-// contiguous 16 B/lane wave accesses (1).  tools/membench.hip measures the pattern ceilings on this part:
+// (measured slower: gone) or brought to thread-contiguous ownership by one more staging exchange and stored as
+// contiguous 16 B/lane wave accesses (shipped).  tools/membench.hip measures the pattern ceilings on this part:
 // copy 4.6-5.4 TB/s, contiguous stores 5.0-5.2, 64 B-strided stores 4.2-4.8.
-#ifndef MKT_FFT_TW_LDS
-#define MKT_FFT_TW_LDS 1
-#endif
-#ifndef MKT_FFT_CONTIG_STORE
-#define MKT_FFT_CONTIG_STORE 1
-#endif
-
-// NBT polynomials per workgroup iteration share the twiddle reads and the barriers (2 pays up to M = 512)
-#ifndef MKT_FFT_NT
-#define MKT_FFT_NT 3      // bit 0: nontemporal coefficient loads, bit 1: nontemporal result stores (streamed once: +10-16 % on MI355X)
-#endif
-#ifndef MKT_FFT_PF
-#define MKT_FFT_PF 2      // polynomial groups in flight per workgroup ahead of the one being transformed
-#endif
+// Shipped settings (each measured): Psi resident in LDS, contiguous 16 B/lane stores through one more staging
+// exchange, nontemporal loads and stores (+10-16 %), the coefficients of the next two polynomial groups in flight.
+constexpr int FFT_PF = 2;
 typedef double __attribute__((ext_vector_type(2))) mkt_d2;
-template <typename T> __device__ __forceinline__ T stream_load(const T *p) {
-    if (MKT_FFT_NT & 1) return __builtin_nontemporal_load(p);
-    return *p;
-}
+template <typename T> __device__ __forceinline__ T stream_load(const T *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ cplx stream_load_c(const cplx *p) {
-    if (MKT_FFT_NT & 1) { mkt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const mkt_d2 *>(p)); return cplx{v.x, v.y}; }
-    return *p;
+    mkt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const mkt_d2 *>(p));
+    return cplx{v.x, v.y};
 }
 __device__ __forceinline__ void stream_store_c(cplx *p, cplx z) {
-    if (MKT_FFT_NT & 2) { mkt_d2 v = {z.re, z.im}; __builtin_nontemporal_store(v, reinterpret_cast<mkt_d2 *>(p)); }
-    else *p = z;
+    mkt_d2 v = {z.re, z.im};
+    __builtin_nontemporal_store(v, reinterpret_cast<mkt_d2 *>(p));
 }
-template <typename T> __device__ __forceinline__ void stream_store(T *p, T v) {
-    if (MKT_FFT_NT & 2) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
+template <typename T> __device__ __forceinline__ void stream_store(T *p, T v) { __builtin_nontemporal_store(v, p); }
 
 template <int LOGM, typename WORD, int NBT>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(TwPtrs tw, const WORD *__restrict__ p,
@@ -92,19 +50,15 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
     XS xs = make_xs();
-#if MKT_FFT_TW_LDS
     cplx *psi_l = lds + P::LDS_CPLX;          // the twiddle table stays in LDS for all polynomials of this workgroup
     for (int i = t; i < M; i += NT) psi_l[i] = tw.psi[i];
     __syncthreads();
     const cplx *psi_f = psi_l;
-#else
-    const cplx *psi_f = tw.psi;
-#endif
     cplx rt[R];
 #pragma unroll
     for (int e = 0; e < R; e++) rt[e] = tw.roots[e * NT + t];
     // software pipeline: the coefficients of this workgroup's next PF polynomial groups are in flight while one is transformed
-    constexpr int PF = MKT_FFT_PF;
+    constexpr int PF = FFT_PF;
     WORD c0[PF][NBT][R], c1[PF][NBT][R];
     const size_t groups = (B + NBT - 1) / NBT;
     auto load = [&](int d, size_t gi) {
@@ -135,7 +89,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_fwd_kernel(T
                 }
             if (g + (size_t)PF * gridDim.x < groups) load(d, g + (size_t)PF * gridDim.x);
             fft_forward<LOGM, LOGR, NBT>(z, psi_f, lds, t, xs.lx);
-            const bool contig = !dev_order && MKT_FFT_CONTIG_STORE && P::NPASS > 1;
+            const bool contig = !dev_order && P::NPASS > 1;
             if (contig) {
                 __syncthreads();
                 exchange_lds<LOGM, LOGR, NBT>(z, lds + P::buf_off(P::NPASS - 1), t, 0, P::lo(0));
@@ -165,13 +119,11 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_inv_kernel(T
     cplx ri[R];
 #pragma unroll
     for (int e = 0; e < R; e++) ri[e] = tw.rootsinv[e * NT + t];
-    constexpr bool CONTIG = MKT_FFT_CONTIG_STORE && P::NPASS > 1;
-#if MKT_FFT_TW_LDS
+    constexpr bool CONTIG = P::NPASS > 1;
     cplx *psi_l = lds + P::LDS_CPLX;          // psiinv[i] == conj(psi[i]) entrywise: one resident table serves both directions
     for (int i = t; i < M; i += NT) psi_l[i] = tw.psi[i];
     __syncthreads();
-#endif
-    constexpr int PF = MKT_FFT_PF;
+    constexpr int PF = FFT_PF;
     cplx zn[PF][R];
     auto load = [&](int d, size_t b) {
 #pragma unroll
@@ -194,11 +146,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void transform_inv_kernel(T
                 exchange_lds<LOGM, LOGR, 1>(reinterpret_cast<cplx(&)[1][R]>(z), lds + P::buf_off(P::NPASS), t, P::lo(0), 0);
                 __syncthreads();
             }
-#if MKT_FFT_TW_LDS
             fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t, xs.lx);
-#else
-            fft_inverse1<LOGM>(z, tw.psiinv, lds, t, xs);
-#endif
             WORD *pp = p + b * N;
 #pragma unroll
             for (int e = 0; e < R; e++) {
@@ -289,57 +237,16 @@ __global__ void testvector_kernel(const uint32_t *__restrict__ lin, int lwe_stri
 // Blind rotation, RLWE length 1.  bootstrapping.jl:32-76 (CGGI), :114-165 (LMSS), :389-443 and
 // :599-659 (KMS / KMS_block phase 1).  One workgroup per rotation; the accumulator (2 polynomials)
 // and the transform-domain accumulator stay in registers for all n CMux steps; LDS only stages the
-// in-transform exchanges.  LB = block length (1 for the plain schemes).
+// in-transform exchanges and holds a copy of Psi.  LB = block length (1 for the plain schemes).
+// Built and measured slower, so gone: key rows requested before the group's forward transform (+0.5 %:
+// 64 more live registers), flat instead of buffer-descriptor loads (+5 %), twiddles from global memory (+21 %), three
+// waves per SIMD at M = 512 (same time, lower clock), one key bit's rows requested ahead in the block kernels (+3 % at
+// Blockparam, superseded by rot_block.hip).
 // ------------------------------------------------------------------------------------------------
-#ifndef MKT_ROT_LT5
-#define MKT_ROT_LT5 1     // ... and the l = 4, 5, 6 shapes of the larger KMS sets (params.jl:55-125)
-#endif
-#ifndef MKT_ROT_LT3
-#define MKT_ROT_LT3 1     // specialise the shipped l = 3 shapes too (CGGIparam, Blockparam, KMS2party, KMS2partyblock)
-#endif
-#ifndef MKT_ROT_BT
-#define MKT_ROT_BT 1     // also specialise the gadget base where the length is specialised (l = 2, logB = 16 on the 64-bit ring)
-#endif
-#ifndef MKT_ROT_LT
-#define MKT_ROT_LT 1
-#endif
-#ifndef MKT_TW_LDS
-#define MKT_TW_LDS 1   // forward twiddle table resident in LDS (A/B: 17.0 vs 20.6 ms at KMS k=2 N=1024)
-#endif
-#ifndef MKT_ROT_MINW
-#define MKT_ROT_MINW 2
-#endif
-// Key rows, monomial rows and the twist tables are read through buffer descriptors: SGPR base + 32-bit per-lane
-// offset + SGPR row offset, so a load costs no address arithmetic on the VALU (flat loads needed a 64-bit add each:
-// ~100 of the ~2000 VALU instructions of a CMux).
-#ifndef MKT_ROT_BUFLOAD
-#define MKT_ROT_BUFLOAD 1
-#endif
-// Software prefetch of the rotation loop's table reads (bit mask): 1 = the monomial row of this step is requested at the
-// top of the step (its index only depends on the LWE mask word) instead of right before its use; 2 = the key rows of a
-// digit group are requested before the group's forward transform instead of during its last pass.
-#ifndef MKT_ROT_PF
-#define MKT_ROT_PF 1      // measured on MI355X (KMS k=2 N=1024, 4096 gates): 1 -> -4 %, 2 -> +0.5 % (register pressure), with ROOTS_REG -6 %
-#endif
-#ifndef MKT_ROT_PROBE
-#define MKT_ROT_PROBE 0   // development: workgroup 0 prints the s_memtime ticks its first wave spent in each phase of the rotation loop
-#endif
-#ifndef MKT_ROT_AT_AHEAD
-#define MKT_ROT_AT_AHEAD 1
-#endif
-#ifndef MKT_ROT_PFQ
-#define MKT_ROT_PFQ 0     // block kernels: key bits of a block whose rows are requested before the digit's forward transform
-#endif
-#ifndef MKT_ROT_ROOTS_REG
-#define MKT_ROT_ROOTS_REG 1   // roots / rootsinv of the thread's points in registers for the whole rotation (2 * R * 4 VGPRs): 20 of the 51 table loads of a CMux gone
-#endif
 // Occupancy the register allocator is told to hit EXACTLY (amdgpu_waves_per_eu(min, max)): 3 waves/SIMD pays at
 // M >= 1024 with single transforms; elsewhere LDS admits 2 and the allocator should then use all 256 VGPRs --
 // builds that stopped at ~186 or chose <= 168 for a third wave LDS cannot host ran up to 25 % slower
-#ifndef MKT_ROT_OCC9
-#define MKT_ROT_OCC9 MKT_ROT_MINW   // waves/SIMD asked for at M = 512 with single transforms (3 was measured slower)
-#endif
-template <int LOGM, int NB> struct RotOcc { static constexpr int MINW = (LOGM >= 10 && NB == 1 && MKT_LOGR == 2) ? 3 : ((LOGM == 9 && NB == 1) ? MKT_ROT_OCC9 : MKT_ROT_MINW); };
+template <int LOGM, int NB> struct RotOcc { static constexpr int MINW = (LOGM >= 10 && NB == 1 && MKT_LOGR == 2) ? 3 : 2; };
 
 template <int LOGM, typename WORD, int LB, int LR, int NB, int LT, int BT>
 __global__ __launch_bounds__((Plan<LOGM, LR>::NT)) __attribute__((amdgpu_waves_per_eu(RotOcc<LOGM, NB>::MINW, RotOcc<LOGM, NB>::MINW)))
@@ -359,17 +266,11 @@ void blindrotate_k1_kernel(const RotArgs a) {
     if (a.stagger > 0 && ((bid >> 8) & 1)) {
         for (int s = 0; s < a.stagger; s++) __builtin_amdgcn_s_sleep(8);
     }
-#if MKT_TW_LDS
-    // the forward twiddle table stays resident in LDS behind the staging buffers; the inverse uses its conjugate
+    // the forward twiddle table stays resident in LDS behind the staging buffers (17.0 vs 20.6 ms from global memory at
+    // KMS k=2 N=1024); the inverse multiplies by its conjugate
     cplx *psi_l = lds + P::LDS_CPLX;
     for (int i = t; i < M; i += NT) psi_l[i] = a.tw.psi[i];
     __syncthreads();
-#define MKT_PSI_F psi_l
-#define MKT_INV(NBV, ZZ) fft_inverse<LOGM, LR, NBV, true, MO>(ZZ, psi_l, lds, t, xs.lx)
-#else
-#define MKT_PSI_F a.tw.psi
-#define MKT_INV(NBV, ZZ) fft_inverse<LOGM, LR, NBV, false, MO>(ZZ, a.tw.psiinv, lds, t, xs.lx)
-#endif
     // workgroups are dealt slot-major (all ciphertexts' rotations of one party/row are adjacent), so the workgroups
     // resident at any time stream the SAME party's key rows through L2; results are stored ciphertext-major
     const size_t gate = bid % (size_t)a.ngates;
@@ -378,6 +279,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
     const int party = __builtin_amdgcn_readfirstlane(a.slot_party[slot]), row = __builtin_amdgcn_readfirstlane(a.slot_row[slot]);
     const uint32_t *at_src = a.lwe + gate * (size_t)a.lwe_stride + (size_t)party * a.n;
     const cplx *brk = a.brk + (size_t)party * a.brk_party_stride;
+    // key, monomial and twist tables are read through buffer descriptors (kernel_common.h table_load)
     const __amdgpu_buffer_rsrc_t rs_brk = table_rsrc(brk, (size_t)a.brk_party_stride * sizeof(cplx));
     const __amdgpu_buffer_rsrc_t rs_mono = table_rsrc(a.monomial, (size_t)2 * N * M * sizeof(cplx));
     const __amdgpu_buffer_rsrc_t rs_roots = table_rsrc(a.tw.roots, (size_t)M * sizeof(cplx));
@@ -389,8 +291,10 @@ void blindrotate_k1_kernel(const RotArgs a) {
     const Gadget<WORD> gd(LT ? LT : a.l, (LT && BT) ? BT : a.logB);
     const int l = LT ? LT : a.l;   // LT > 0: gadget length known at compile time, the digit loop unrolls fully
 
-    constexpr bool RREG = MKT_ROT_ROOTS_REG && LB == 1;   // the block kernels have no registers to spare (measured: -12 % at KMS2partyblock)
-    cplx rt_reg[R], ri_reg[R];                // RREG: the twist / untwist factors of this thread's points stay in registers
+    // plain kernels: the twist / untwist factors of this thread's points stay in registers (20 of the 51 table loads of a
+    // CMux gone); the block kernels have no registers to spare (measured: -12 % at KMS2partyblock) and reload them
+    constexpr bool RREG = LB == 1;
+    cplx rt_reg[R], ri_reg[R];
 #pragma unroll
     for (int e = 0; e < R; e++) {
         if (RREG) { rt_reg[e] = a.tw.roots[e * NT + t]; ri_reg[e] = a.tw.rootsinv[e * NT + t]; }
@@ -414,34 +318,28 @@ void blindrotate_k1_kernel(const RotArgs a) {
 
     const int nblk = a.n / LB;
     const int msbit = 32 - a.logN - 1;
-#if MKT_ROT_PROBE
-    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = __builtin_amdgcn_s_memtime();
-#define ROT_PROBE(K) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[K] += now_ - plast; plast = now_; }
-#else
-#define ROT_PROBE(K)
-#endif
     uint32_t at_raw[LB];                      // the mask words of the NEXT block are requested a block ahead: nothing waits for them
 #pragma unroll
-    for (int q = 0; q < LB; q++) at_raw[q] = MKT_ROT_AT_AHEAD ? at_src[q] : 0u;
+    for (int q = 0; q < LB; q++) at_raw[q] = at_src[q];
     for (int blk = 0; blk < nblk; blk++) {
         uint32_t ats[LB];
         bool any = false;
 #pragma unroll
         for (int q = 0; q < LB; q++) {
-            const uint32_t v = MKT_ROT_AT_AHEAD ? at_raw[q] : at_src[blk * LB + q];
-            ats[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.pre_switched ? v : divbits<uint32_t>(v, msbit)));   // bootstrapping.jl:8 (wave-uniform)
+            ats[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.pre_switched ? at_raw[q] : divbits<uint32_t>(at_raw[q], msbit)));   // bootstrapping.jl:8 (wave-uniform)
             any |= ats[q] != 0;
         }
-        if (MKT_ROT_AT_AHEAD) {
+        {
             const int nb = blk + 1 < nblk ? blk + 1 : blk;
 #pragma unroll
             for (int q = 0; q < LB; q++) at_raw[q] = at_src[nb * LB + q];
         }
         if (!any) continue;                                              // :48 / :145 / :413 / :638
-        ROT_PROBE(0)
 
+        // plain kernels: the monomial row of the step is requested here (its index only depends on the mask word), not
+        // right before the multiply where its Infinity-Cache latency was fully exposed (-4 %)
+        constexpr bool PF_MONO = LB == 1;
         cplx mono_pf[R];
-        constexpr bool PF_MONO = (MKT_ROT_PF & 1) && LB == 1 && MKT_ROT_BUFLOAD, PF_KEYS = (MKT_ROT_PF & 2) && LB == 1 && MKT_ROT_BUFLOAD;
         if (PF_MONO) {
 #pragma unroll
             for (int e = 0; e < R; e++) mono_pf[e] = table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[0] - 1) * M * sizeof(cplx)));
@@ -460,31 +358,6 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll (LT ? 2 * LT : 1)
         for (int g0 = 0; g0 < 2 * l; g0 += NB) {
             cplx z[NB][R];
-            cplx kpf[NB][2][R];
-            // block kernels: the rows of the first PFQ key bits of the block are requested before the digit's transform (the
-            // LB * 2 accumulators leave room for PFQ * 2 rows, not for all LB * 2)
-            constexpr int PFQ = (LB > 1 && MKT_ROT_BUFLOAD) ? (MKT_ROT_PFQ < LB ? MKT_ROT_PFQ : LB) : 0;
-            cplx kq[NB][PFQ > 0 ? PFQ : 1][2][R];
-            if (PFQ > 0) {
-#pragma unroll
-                for (int h2 = 0; h2 < NB; h2++)
-#pragma unroll
-                    for (int q = 0; q < PFQ; q++) {
-                        const unsigned so_row = (unsigned)((((size_t)(blk * LB + q) * 2 * l + (size_t)(g0 + h2)) * 2) * M * sizeof(cplx));
-#pragma unroll
-                        for (int e = 0; e < R; e++) { kq[h2][q][0][e] = table_load(rs_brk, vo_dev[e], so_row); kq[h2][q][1][e] = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); }
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (PF_KEYS) {
-#pragma unroll
-                for (int h2 = 0; h2 < NB; h2++) {
-                    const unsigned so_row = (unsigned)((((size_t)blk * 2 * l + (size_t)(g0 + h2)) * 2) * M * sizeof(cplx));
-#pragma unroll
-                    for (int e = 0; e < R; e++) { kpf[h2][0][e] = table_load(rs_brk, vo_dev[e], so_row); kpf[h2][1][e] = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
             for (int h2 = 0; h2 < NB; h2++) {
                 const int g = g0 + h2;
@@ -493,26 +366,21 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
                 for (int e = 0; e < R; e++) {                            // :50-51 decompto!, fft.jl:57-63 twist
                     const WORD w0 = isa ? acc[1][e][0] : acc[0][e][0], w1 = isa ? acc[1][e][1] : acc[0][e][1];
-                    int d0, d1;
-                    d0 = gd.digit(gd.prep(w0), j); d1 = gd.digit(gd.prep(w1), j);
+                    const int d0 = gd.digit(gd.prep(w0), j), d1 = gd.digit(gd.prep(w1), j);
                     cplx v; v.re = (double)d0; v.im = (double)(-d1);
-                    z[h2][e] = cmul(v, RREG ? rt_reg[e] : MKT_ROT_BUFLOAD ? table_load(rs_roots, vo_nat[e], 0) : a.tw.roots[e * NT + t]);
+                    z[h2][e] = cmul(v, RREG ? rt_reg[e] : table_load(rs_roots, vo_nat[e], 0));
                 }
             }
-            ROT_PROBE(1)
-            fft_forward<LOGM, LR, NB, MO>(z, MKT_PSI_F, lds, t, xs.lx);  // :54-59 fftto!
-            ROT_PROBE(2)
+            fft_forward<LOGM, LR, NB, MO>(z, psi_l, lds, t, xs.lx);      // :54-59 fftto!
 #pragma unroll
             for (int h2 = 0; h2 < NB; h2++)
 #pragma unroll
                 for (int q = 0; q < LB; q++) {
                     if (LB > 1 && ats[q] == 0) continue;
-                    const cplx *krow = brk + (((size_t)(blk * LB + q) * 2 * l + (size_t)(g0 + h2)) * 2) * M;
                     const unsigned so_row = (unsigned)((((size_t)(blk * LB + q) * 2 * l + (size_t)(g0 + h2)) * 2) * M * sizeof(cplx));
 #pragma unroll
                     for (int e = 0; e < R; e++) {                        // :63-68 muladdto!(tacc, digit, row)
-                        cplx kb, ka;
-                        if (PF_KEYS) { kb = kpf[h2][0][e]; ka = kpf[h2][1][e]; } else if (PFQ > 0 && q < PFQ) { kb = kq[h2][q][0][e]; ka = kq[h2][q][1][e]; } else if (MKT_ROT_BUFLOAD) { kb = table_load(rs_brk, vo_dev[e], so_row); ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx))); } else { kb = krow[dev_pos(MKT_DEVORDER, t * R + e, NT)]; ka = krow[M + dev_pos(MKT_DEVORDER, t * R + e, NT)]; }
+                        const cplx kb = table_load(rs_brk, vo_dev[e], so_row), ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx)));
                         tacc[q][0][e] = cadd(tacc[q][0][e], cmul(z[h2][e], kb));
                         tacc[q][1][e] = cadd(tacc[q][1][e], cmul(z[h2][e], ka));
                         if (RotOcc<LOGM, NB>::MINW >= 3) __builtin_amdgcn_sched_barrier(0);   // keep the key-row live ranges short at 3 waves/SIMD
@@ -520,14 +388,12 @@ void blindrotate_k1_kernel(const RotArgs a) {
                 }
         }
 
-        ROT_PROBE(3)
         cplx t2[2][R];
         if (LB == 1 && !a.blk_accum) {                                   // :71 mul!(monomial[atilde], tacc)
-            const cplx *mono = a.monomial + (size_t)(ats[0] - 1) * M;
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int e = 0; e < R; e++) { cplx mv; mv = PF_MONO ? mono_pf[e] : MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[0] - 1) * M * sizeof(cplx))) : mono[dev_pos(MKT_DEVORDER, t * R + e, NT)]; t2[c][e] = cmul(mv, tacc[0][c][e]); }
+                for (int e = 0; e < R; e++) t2[c][e] = cmul(mono_pf[e], tacc[0][c][e]);
         } else {                                                         // :157 / :648 tacc2 += monomial * tacc
 #pragma unroll
             for (int c = 0; c < 2; c++)
@@ -536,23 +402,21 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
             for (int q = 0; q < LB; q++) {
                 if (ats[q] == 0) continue;
-                const cplx *mono = a.monomial + (size_t)(ats[q] - 1) * M;
 #pragma unroll
                 for (int c = 0; c < 2; c++)
 #pragma unroll
-                    for (int e = 0; e < R; e++) t2[c][e] = cadd(t2[c][e], cmul(MKT_ROT_BUFLOAD ? table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[q] - 1) * M * sizeof(cplx))) : mono[dev_pos(MKT_DEVORDER, t * R + e, NT)], tacc[q][c][e]));
+                    for (int e = 0; e < R; e++) t2[c][e] = cadd(t2[c][e], cmul(table_load(rs_mono, vo_dev[e], (unsigned)((size_t)(ats[q] - 1) * M * sizeof(cplx))), tacc[q][c][e]));
             }
         }
-        ROT_PROBE(4)
         if (NB == 2) {
-            MKT_INV(2, t2);                                              // :72 ifftto! (b and a together)
+            fft_inverse<LOGM, LR, 2, true, MO>(t2, psi_l, lds, t, xs.lx);                                   // :72 ifftto! (b and a together)
         } else {
-            MKT_INV(1, reinterpret_cast<cplx(&)[1][R]>(t2[0]));
-            MKT_INV(1, reinterpret_cast<cplx(&)[1][R]>(t2[1]));
+            fft_inverse<LOGM, LR, 1, true, MO>(reinterpret_cast<cplx(&)[1][R]>(t2[0]), psi_l, lds, t, xs.lx);
+            fft_inverse<LOGM, LR, 1, true, MO>(reinterpret_cast<cplx(&)[1][R]>(t2[1]), psi_l, lds, t, xs.lx);
         }
 #pragma unroll
         for (int e = 0; e < R; e++) {
-            const cplx ri = RREG ? ri_reg[e] : MKT_ROT_BUFLOAD ? table_load(rs_rinv, vo_nat[e], 0) : a.tw.rootsinv[e * NT + t];
+            const cplx ri = RREG ? ri_reg[e] : table_load(rs_rinv, vo_nat[e], 0);
 #pragma unroll
             for (int c = 0; c < 2; c++) {                                // fft.jl:76-80 untwist + native; :73 add!
                 const cplx v = cmul(t2[c][e], ri);
@@ -560,13 +424,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
                 acc[c][e][1] = (WORD)(acc[c][e][1] + native<WORD>(-v.im));
             }
         }
-        ROT_PROBE(5)
     }
-#if MKT_ROT_PROBE
-    if (bid == 0 && t == 0)
-        printf("rot probe (s_memtime ticks, wave 0 of workgroup 0): head %llu  digits+twist %llu  forward %llu  row MACs %llu  monomial MACs %llu  inverse+native %llu\n",
-               pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
-#endif
 
     if (a.out_mode == 0) {
         WORD *dst = reinterpret_cast<WORD *>(a.acc_io) + rot * 2 * N;
@@ -583,7 +441,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
                 cplx v; v.re = word_to_f64<WORD>(acc[c][e][0]); v.im = word_to_f64<WORD>((WORD)((WORD)0 - acc[c][e][1]));
                 z[0][e] = cmul(v, a.tw.roots[e * NT + t]);
             }
-            fft_forward<LOGM, LR, 1, MO>(z, MKT_PSI_F, lds, t, xs.lx);
+            fft_forward<LOGM, LR, 1, MO>(z, psi_l, lds, t, xs.lx);
             cplx *o = a.tout + (rot * 2 + c) * M;
 #pragma unroll
             for (int e = 0; e < R; e++) o[a.tout_natural ? t * R + e : dev_pos(MKT_DEVORDER, t * R + e, NT)] = z[0][e];
@@ -926,9 +784,9 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
 // LT, BT > 0: gadget length and base known at compile time (digit loops unrolled, shifts and masks immediates)
 template <int LOGM, typename WORD, int LT = 0, int BT = 0>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2))) void ccs_blindrotate_kernel(const CcsArgs a) {
-    using P = Plan<LOGM, LOGR, MKT_CCS_PAIR ? 2 : 1>;
+    using P = Plan<LOGM, LOGR, 1>;
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
-    constexpr int MO1 = (MKT_CCS_MO & 0xff) | (MKT_CCS_PAIR ? 0x200 : 0), MO2 = MKT_CCS_MO & 0xff;   // single / paired transforms
+    constexpr int MO1 = 0xff;                                  // library-default exchange routes
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     cplx *psi_l = lds + P::LDS_CPLX;
     const int t = threadIdx.x;
@@ -952,61 +810,30 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
 #pragma unroll
     for (int e = 0; e < R; e++) rt[e] = a.tw.roots[e * NT + t];
 
-#if MKT_CCS_PROBE
-    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = __builtin_amdgcn_s_memtime();
-#define CCS_PROBE(K) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[K] += now_ - plast; plast = now_; }
-#else
-#define CCS_PROBE(K)
-#endif
     // u and v of one input polynomial q (:279-294): tu = sum_j dig_j * d[j]; tv = -/+ sum_j dig_j * (crs | b_{q-1})[j]
     auto uv = [&](int q, const cplx *ud, cplx (&tu)[R], cplx (&tvq)[R]) {
         WORD tp[R][2];
 #pragma unroll
         for (int e = 0; e < R; e++) {
-            if (MKT_CCS_ABL == 2) { tp[e][0] = gd.prep((WORD)(q * 2654435761u + e * NT + t)); tp[e][1] = gd.prep((WORD)(q * 40503u + t * 2246822519u + e)); continue; }
             tp[e][0] = gd.prep(acc[(size_t)q * N + e * NT + t]); tp[e][1] = gd.prep(acc[(size_t)q * N + M + e * NT + t]);
         }
-#if MKT_CCS_PROBE == 2
-        CCS_PROBE(1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CCS_PROBE(6)
-#endif
 #pragma unroll
         for (int e = 0; e < R; e++) { tu[e].re = tu[e].im = 0.0; tvq[e].re = tvq[e].im = 0.0; }
         const cplx *vk = q == 0 ? a.crs : a.pub_b + (size_t)(q - 1) * l * M;
-        int j = 0;
-        if (MKT_CCS_PAIR) {
-            for (; j + 1 < l; j += 2) {
-                cplx z2[2][R];
-                digit_points<WORD, R>(z2[0], tp, gd, j, rt);
-                digit_points<WORD, R>(z2[1], tp, gd, j + 1, rt);
-                fft_forward<LOGM, LOGR, 2, MO2>(z2, psi_l, lds, t, xs.lx);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const cplx *kd = ud + (size_t)(j + h) * M, *kv = vk + (size_t)(j + h) * M;
-#pragma unroll
-                    for (int e = 0; e < R; e++) {
-                        tu[e] = cadd(tu[e], cmul(z2[h][e], kd[dp[e]]));
-                        const cplx pr = cmul(z2[h][e], kv[dp[e]]);
-                        tvq[e] = q == 0 ? csub(tvq[e], pr) : cadd(tvq[e], pr);
-                    }
-                }
-            }
-        }
 #pragma unroll 1
-        for (; j < l; j++) {
+        for (int j = 0; j < l; j++) {
             cplx z[R];
             const cplx *kd = ud + (size_t)j * M, *kv = vk + (size_t)j * M;
-            cplx kdr[R], kvr[R];
-            if (MKT_CCS_PF) {                                                    // key rows requested before the transform that needs them
+            cplx kdr[R], kvr[R];                                                 // key rows requested before the transform that needs them (+1..3 %)
 #pragma unroll
-                for (int e = 0; e < R; e++) { kdr[e] = MKT_CCS_ABL == 1 ? rt[e] : kd[dp[e]]; kvr[e] = MKT_CCS_ABL == 1 ? rt[R - 1 - e] : kv[dp[e]]; }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int e = 0; e < R; e++) { kdr[e] = kd[dp[e]]; kvr[e] = kv[dp[e]]; }
+            __builtin_amdgcn_sched_barrier(0);
             digit_points<WORD, R>(z, tp, gd, j, rt);
             fft_forward<LOGM, LOGR, 1, MO1>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t, xs.lx);
 #pragma unroll
             for (int e = 0; e < R; e++) {
-                tu[e] = cadd(tu[e], cmul(z[e], MKT_CCS_PF ? kdr[e] : kd[dp[e]]));
-                const cplx pr = cmul(z[e], MKT_CCS_PF ? kvr[e] : kv[dp[e]]);
+                tu[e] = cadd(tu[e], cmul(z[e], kdr[e]));
+                const cplx pr = cmul(z[e], kvr[e]);
                 tvq[e] = q == 0 ? csub(tvq[e], pr) : cadd(tvq[e], pr);          // :290 mulsubto!, :293 muladdto!
             }
         }
@@ -1016,35 +843,18 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
         WORD tp[R][2];
 #pragma unroll
         for (int e = 0; e < R; e++) { tp[e][0] = gd.prep(vw[e][0]); tp[e][1] = gd.prep(vw[e][1]); }
-        int j = 0;
-        if (MKT_CCS_PAIR) {
-            for (; j + 1 < l; j += 2) {
-                cplx z2[2][R];
-                digit_points<WORD, R>(z2[0], tp, gd, j, rt);
-                digit_points<WORD, R>(z2[1], tp, gd, j + 1, rt);
-                fft_forward<LOGM, LOGR, 2, MO2>(z2, psi_l, lds, t, xs.lx);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const cplx *fb = uf + (size_t)(2 * (j + h)) * M, *fa = fb + M;
-#pragma unroll
-                    for (int e = 0; e < R; e++) { tb[e] = cadd(tb[e], cmul(z2[h][e], fb[dp[e]])); ta[e] = cadd(ta[e], cmul(z2[h][e], fa[dp[e]])); }
-                }
-            }
-        }
 #pragma unroll 1
-        for (; j < l; j++) {
+        for (int j = 0; j < l; j++) {
             cplx z[R];
             const cplx *fb = uf + (size_t)(2 * j) * M, *fa = fb + M;
             cplx fbr[R], far[R];
-            if (MKT_CCS_PF) {
 #pragma unroll
-                for (int e = 0; e < R; e++) { fbr[e] = MKT_CCS_ABL == 1 ? rt[e] : fb[dp[e]]; far[e] = MKT_CCS_ABL == 1 ? rt[R - 1 - e] : fa[dp[e]]; }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int e = 0; e < R; e++) { fbr[e] = fb[dp[e]]; far[e] = fa[dp[e]]; }
+            __builtin_amdgcn_sched_barrier(0);
             digit_points<WORD, R>(z, tp, gd, j, rt);
             fft_forward<LOGM, LOGR, 1, MO1>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t, xs.lx);
 #pragma unroll
-            for (int e = 0; e < R; e++) { tb[e] = cadd(tb[e], cmul(z[e], MKT_CCS_PF ? fbr[e] : fb[dp[e]])); ta[e] = cadd(ta[e], cmul(z[e], MKT_CCS_PF ? far[e] : fa[dp[e]])); }
+            for (int e = 0; e < R; e++) { tb[e] = cadd(tb[e], cmul(z[e], fbr[e])); ta[e] = cadd(ta[e], cmul(z[e], far[e])); }
         }
     };
     auto inv_words = [&](cplx (&z)[R], WORD (&w)[R][2]) {                        // fft.jl:74-81
@@ -1065,13 +875,11 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
             if (at == 0) continue;                                               // :261
             const cplx *uni = a.brk + (size_t)idx * a.brk_party_stride + (size_t)i * 3 * l * M;
             const cplx *ud = uni, *uf = uni + (size_t)l * M;
-#if MKT_CCS_LOOPED
             // One loop over the input polynomials in the order the reference's sums need: the current party's mask
             // polynomial first (its u opens tacc.a[idx], :279-284; its v is parked), then b (u opens tacc.b; w(v0),
             // :313-316), then the earlier parties' mask polynomials (:317-320, j1 = q), last the parked v (j1 = np).
             // Each transform kind appears once in the loop body: the code of a step stays small.
             cplx ta[R], tb[R];
-            CCS_PROBE(0)
             for (int qi = 0; qi <= np + 1; qi++) {
                 WORD vw[R][2];
                 if (qi <= np) {
@@ -1088,28 +896,23 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
 #pragma unroll
                         for (int e = 0; e < R; e++) sc[(size_t)q * M + dp[e]] = tu[e];
                     }
-                    CCS_PROBE(1)
                     inv_words(tvq, vw);                                          // :297-300
                     if (q == np) {
 #pragma unroll
                         for (int e = 0; e < R; e++) { vsc[e * NT + t] = vw[e][0]; vsc[M + e * NT + t] = vw[e][1]; }
-                        CCS_PROBE(2)
                         continue;
                     }
-                    CCS_PROBE(2)
                 } else {
 #pragma unroll
                     for (int e = 0; e < R; e++) { vw[e][0] = vsc[e * NT + t]; vw[e][1] = vsc[M + e * NT + t]; }
                 }
                 wpart(vw, uf, tb, ta);
-                CCS_PROBE(3)
             }
             // :322-324 mul!(monomial, tacc); ifftto!; add!  -- tacc.b and tacc.a[idx] join the others in the scratch so
             // the loop below is uniform; the polynomials are independent, the two just stored go last
 #pragma unroll
             for (int e = 0; e < R; e++) { sc[dp[e]] = tb[e]; sc[(size_t)np * M + dp[e]] = ta[e]; }
             const cplx *mono = a.monomial + (size_t)(at - 1) * M;
-#if MKT_CCS_FPF
             // the monomial row is the same for every polynomial; the next polynomial's transform-domain sum and the
             // accumulator words the result is added to are requested before the inverse transform that hides them
             auto fq = [&](int qq) { return qq < np - 1 ? qq + 1 : (qq == np - 1 ? 0 : np); };
@@ -1133,84 +936,8 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
                     acc[(size_t)q * N + M + e * NT + t] = (WORD)(aw[e][1] + w[e][1]);
                 }
             }
-#else
-            for (int qq = 0; qq <= np; qq++) {
-                const int q = qq < np - 1 ? qq + 1 : (qq == np - 1 ? 0 : np);
-                cplx s[R];
-#pragma unroll
-                for (int e = 0; e < R; e++) s[e] = cmul(mono[dp[e]], sc[(size_t)q * M + dp[e]]);
-                WORD w[R][2];
-                inv_words(s, w);
-#pragma unroll
-                for (int e = 0; e < R; e++) {
-                    acc[(size_t)q * N + e * NT + t] = (WORD)(acc[(size_t)q * N + e * NT + t] + w[e][0]);
-                    acc[(size_t)q * N + M + e * NT + t] = (WORD)(acc[(size_t)q * N + M + e * NT + t] + w[e][1]);
-                }
-            }
-#endif
-#else
-            cplx ta[R], tb[R], tu[R], tvq[R];
-            WORD vw[R][2];
-            CCS_PROBE(0)
-            // u of the current party's mask polynomial first; its v is parked in the scratch
-            uv(np, ud, ta, tvq);
-            CCS_PROBE(1)
-            inv_words(tvq, vw);                                                  // :298-300
-#pragma unroll
-            for (int e = 0; e < R; e++) { vsc[e * NT + t] = vw[e][0]; vsc[M + e * NT + t] = vw[e][1]; }
-            CCS_PROBE(2)
-            // b polynomial: u_b, v0, w(v0)
-            uv(0, ud, tb, tvq);
-            CCS_PROBE(1)
-            inv_words(tvq, vw);                                                  // :297
-            CCS_PROBE(2)
-            wpart(vw, uf, tb, ta);                                               // :313-316
-            CCS_PROBE(3)
-            // earlier parties' mask polynomials
-            for (int q = 1; q < np; q++) {
-                uv(q, ud, tu, tvq);
-#pragma unroll
-                for (int e = 0; e < R; e++) sc[(size_t)q * M + dp[e]] = tu[e];
-                CCS_PROBE(1)
-                inv_words(tvq, vw);
-                CCS_PROBE(2)
-                wpart(vw, uf, tb, ta);                                           // :317-320 (j1 = q)
-                CCS_PROBE(3)
-            }
-#pragma unroll
-            for (int e = 0; e < R; e++) { vw[e][0] = vsc[e * NT + t]; vw[e][1] = vsc[M + e * NT + t]; }
-            wpart(vw, uf, tb, ta);                                               // :317-320 (j1 = np)
-            CCS_PROBE(4)
-            // :322-324 mul!(monomial, tacc); ifftto!; add!
-            const cplx *mono = a.monomial + (size_t)(at - 1) * M;
-            for (int q = 0; q <= np; q++) {
-                cplx s[R];
-#pragma unroll
-                for (int e = 0; e < R; e++) {
-                    const cplx x = q == 0 ? tb[e] : (q == np ? ta[e] : sc[(size_t)q * M + dp[e]]);
-                    s[e] = cmul(MKT_CCS_ABL == 3 ? rt[e] : mono[dp[e]], x);
-                }
-#if MKT_CCS_PROBE == 2
-                CCS_PROBE(5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CCS_PROBE(7)
-#endif
-                WORD w[R][2];
-                inv_words(s, w);
-#pragma unroll
-                for (int e = 0; e < R; e++) {
-                    if (MKT_CCS_ABL == 2) { acc[(size_t)q * N + e * NT + t] = w[e][0]; acc[(size_t)q * N + M + e * NT + t] = w[e][1]; continue; }
-                    acc[(size_t)q * N + e * NT + t] = (WORD)(acc[(size_t)q * N + e * NT + t] + w[e][0]);
-                    acc[(size_t)q * N + M + e * NT + t] = (WORD)(acc[(size_t)q * N + M + e * NT + t] + w[e][1]);
-                }
-            }
-#endif
-            CCS_PROBE(5)
         }
     }
-#if MKT_CCS_PROBE
-    if (g == 0 && t == 0)
-        printf("ccs probe (s_memtime ticks, wave 0 of workgroup 0): loop-head %llu  uv %llu  inverse-v %llu  w %llu  w-last %llu  monomial+inverse+add %llu  | exposed acc-load wait %llu  exposed monomial/scratch wait %llu\n",
-               pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], pt[6], pt[7]);
-#endif
 }
 
 #endif  // TU 4
@@ -1257,14 +984,8 @@ __global__ void ks_init_kernel(const KsArgs a, size_t B) {
 // reads another lane's data, so there are no barriers).  3 row loads per (j,t) instead of 0.75*G is what matters:
 // the gather is bound by L2 / Infinity-Cache bandwidth.  Partial sums over slabs meet in u32 atomics; wrap-around
 // addition is order independent, so the result is deterministic.
-#ifndef MKT_KS_WAVES
-#define MKT_KS_WAVES 4
-#endif
 constexpr int KS_LANES = 64, KS_CHUNK_WORDS = 4 * KS_LANES, KS_STAGES = 2;
-#ifndef MKT_KS_BATCH
-#define MKT_KS_BATCH 8
-#endif
-constexpr int KS_BATCH = (MKT_KS_BATCH);
+constexpr int KS_BATCH = 8;
 
 // WAVES > 1: the waves of a workgroup (each with its own G ciphertexts) share one staged table -- every row is fetched
 // from L2 / Infinity Cache once per WAVES*G ciphertexts; one barrier per stage.  The two stage buffers alternate on a
@@ -1382,7 +1103,7 @@ bool transform_supported(int logM) { return logM >= 4 && logM <= 11; }
 template <int LM, typename WORD, int NBT>
 static hipError_t launch_fwd_one(TwPtrs tw, const void *p, cplx *t, size_t B, int dev_order, int gmax, hipStream_t s) {
     using P = Plan<LM, LOGR, NBT>;
-    constexpr size_t LB = P::LDS_BYTES + (MKT_FFT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
+    constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
     const size_t groups = (B + NBT - 1) / NBT;
     const int grid = (int)(groups < (size_t)gmax ? groups : (size_t)gmax);
     hipError_t e = set_lds(transform_fwd_kernel<LM, WORD, NBT>, LB);
@@ -1425,11 +1146,11 @@ hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void 
     MKT_DISPATCH_LOGM(logM, {
         using P = Plan<LM, LOGR>;
         if (W == 64) {
-            constexpr size_t LB = P::LDS_BYTES + (MKT_FFT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
+            constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
             hipError_t e = set_lds(transform_inv_kernel<LM, uint64_t>, LB); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((transform_inv_kernel<LM, uint64_t>), dim3(grid), dim3(P::NT), LB, s, tw, t, (uint64_t *)p, B);
         } else {
-            constexpr size_t LB = P::LDS_BYTES + (MKT_FFT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
+            constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
             hipError_t e = set_lds(transform_inv_kernel<LM, uint32_t>, LB); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((transform_inv_kernel<LM, uint32_t>), dim3(grid), dim3(P::NT), LB, s, tw, t, (uint32_t *)p, B);
         }
@@ -1478,7 +1199,7 @@ hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int log
 template <int LM, typename WORD, int LB, int LR, int NB, int LT, int BT = 0>
 static hipError_t launch_rot_lt(const RotArgs &a, size_t nrot, hipStream_t s) {
     using P = Plan<LM, LR, NB>;
-    const size_t lds_bytes = P::LDS_BYTES + (MKT_TW_LDS ? (size_t)P::M * sizeof(cplx) : 0);
+    const size_t lds_bytes = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
     hipError_t e = set_lds(blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT, BT>, lds_bytes);
     if (e != hipSuccess) return e;
     if (a.split == 0 || a.split >= nrot) {
@@ -1497,26 +1218,24 @@ static hipError_t launch_rot_lt(const RotArgs &a, size_t nrot, hipStream_t s) {
 template <int LM, typename WORD, int LB, int LR, int NB>
 static hipError_t launch_rot_one(const RotArgs &a, size_t nrot, hipStream_t s) {
     if constexpr (LM < LR) { return hipErrorInvalidValue; } else {
-#if MKT_ROT_LT
         // gadget length known at compile time (fully unrolled digit loop): measured +8 % at M = 512, l = 2
         // (15.2 -> 14.0 ms, KMS k=2 N=1024)
         if constexpr (LB == 1 && LM == 9) {
-            if (MKT_ROT_BT && a.l == 2 && a.logB == 16 && sizeof(WORD) == 8) return launch_rot_lt<LM, WORD, LB, LR, NB, 2, 16>(a, nrot, s);
+            if (a.l == 2 && a.logB == 16 && sizeof(WORD) == 8) return launch_rot_lt<LM, WORD, LB, LR, NB, 2, 16>(a, nrot, s);
             if (a.l == 2) return launch_rot_lt<LM, WORD, LB, LR, NB, 2>(a, nrot, s);
         }
         // the shipped l = 3 shapes: CGGIparam / Blockparam (logB 9, 32-bit ring, N = 1024) and KMS2party / KMS2partyblock
         // (logB 12, 64-bit ring, N = 2048): +5..7 % once the gadget base is a constant too (the early l = 3 unrolling
         // without it had been slower)
         if constexpr ((LB == 1 || LB == 3) && LM == 9 && sizeof(WORD) == 4) {
-            if (MKT_ROT_LT3 && a.l == 3 && a.logB == 9) return launch_rot_lt<LM, WORD, LB, LR, NB, 3, 9>(a, nrot, s);
+            if (a.l == 3 && a.logB == 9) return launch_rot_lt<LM, WORD, LB, LR, NB, 3, 9>(a, nrot, s);
         }
         if constexpr ((LB == 1 || LB == 3) && LM == 10 && sizeof(WORD) == 8) {
-            if (MKT_ROT_LT3 && a.l == 3 && a.logB == 12) return launch_rot_lt<LM, WORD, LB, LR, NB, 3, 12>(a, nrot, s);
-            if (MKT_ROT_LT5 && a.l == 5 && a.logB == 8) return launch_rot_lt<LM, WORD, LB, LR, NB, 5, 8>(a, nrot, s);    // KMS4party, KMS16party (+7 %)
-            if (MKT_ROT_LT5 && a.l == 4 && a.logB == 9) return launch_rot_lt<LM, WORD, LB, LR, NB, 4, 9>(a, nrot, s);    // KMS8party
-            if (MKT_ROT_LT5 && a.l == 6 && a.logB == 7) return launch_rot_lt<LM, WORD, LB, LR, NB, 6, 7>(a, nrot, s);    // KMS32party
+            if (a.l == 3 && a.logB == 12) return launch_rot_lt<LM, WORD, LB, LR, NB, 3, 12>(a, nrot, s);
+            if (a.l == 5 && a.logB == 8) return launch_rot_lt<LM, WORD, LB, LR, NB, 5, 8>(a, nrot, s);    // KMS4party, KMS16party (+7 %)
+            if (a.l == 4 && a.logB == 9) return launch_rot_lt<LM, WORD, LB, LR, NB, 4, 9>(a, nrot, s);    // KMS8party
+            if (a.l == 6 && a.logB == 7) return launch_rot_lt<LM, WORD, LB, LR, NB, 6, 7>(a, nrot, s);    // KMS32party
         }
-#endif
         return launch_rot_lt<LM, WORD, LB, LR, NB, 0>(a, nrot, s);
     }
 }
@@ -1588,6 +1307,18 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
     // 2x MORE at M = 1024 where the groups need 8 points per thread), 1 = never, 2 = always where supported
     if (a.wide != 1 && wide_supported(logM, a.l, a.blk_len) && (a.wide == 2 || (nrot <= 256 && logM <= 9)))
         return launch_blindrotate_wide(logM, W, a, nrot, s);
+    // A batch is run in rounds of one chip-fill (256 CUs x 4 two-wave workgroups at M = 512), and a round costs one
+    // rotation's serial latency however few workgroups it holds.  A last round of at most one rotation per CU goes to the
+    // latency variant instead (3.2 instead of 5.9 ms at KMS k = 2, N = 1024); same (ciphertext, slot) numbering via block0.
+    constexpr size_t FILL = 1024;
+    if (a.wide == 0 && a.blk_len == 1 && logM == 9 && a.split == 0 && nrot > FILL && nrot % FILL != 0 && nrot % FILL <= 256 && wide_supported(logM, a.l, a.blk_len)) {
+        const size_t rem = nrot % FILL, head = nrot - rem;
+        hipError_t e = W == 64 ? launch_rot_plain_u64(logM, a, head, s) : launch_rot_plain_u32(logM, a, head, s);
+        if (e != hipSuccess) return e;
+        RotArgs b = a;
+        b.block0 = (unsigned)head;
+        return launch_blindrotate_wide(logM, W, b, rem, s);
+    }
     if (a.blk_len > 1) {
         // block schemes: G rotations of one slot per workgroup (rot_block.hip) once the batch fills the chip that way
         // automatic: four rotations per workgroup where that workgroup exists (M <= 512) and the batch still fills the
@@ -1652,7 +1383,7 @@ hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hip
 
 template <int LM, typename WORD, int LT, int BT>
 static hipError_t launch_ccs_one(const CcsArgs &a, size_t B, hipStream_t s) {
-    using P = Plan<LM, LOGR, MKT_CCS_PAIR ? 2 : 1>;
+    using P = Plan<LM, LOGR, 1>;
     constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
     hipError_t e = set_lds(ccs_blindrotate_kernel<LM, WORD, LT, BT>, LB); if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ccs_blindrotate_kernel<LM, WORD, LT, BT>), dim3((unsigned)B), dim3(P::NT), LB, s, a);
@@ -1662,14 +1393,12 @@ hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, h
     if (!B) return hipSuccess;
     MKT_DISPATCH_LOGM(logM, {
         if (W == 64) return launch_ccs_one<LM, uint64_t, 0, 0>(a, B, s);
-#if MKT_CCS_LT
         // the shipped gadgets of the 32-bit CCS sets (params.jl:15-45): CCS2party (3, 8), CCS4party (4, 8), CCS8party (5, 6)
         if constexpr (LM == 9 || LM == 10) {
             if (a.l == 3 && a.logB == 8) return launch_ccs_one<LM, uint32_t, 3, 8>(a, B, s);
             if (a.l == 4 && a.logB == 8) return launch_ccs_one<LM, uint32_t, 4, 8>(a, B, s);
             if (a.l == 5 && a.logB == 6) return launch_ccs_one<LM, uint32_t, 5, 6>(a, B, s);
         }
-#endif
         return launch_ccs_one<LM, uint32_t, 0, 0>(a, B, s);
     });
     return hipGetLastError();
@@ -1691,7 +1420,7 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     if (slabs > a.N / 8) slabs = a.N / 8;
     const int jslab = (a.N + slabs - 1) / slabs;
     slabs = (a.N + jslab - 1) / jslab;
-    int waves = MKT_KS_WAVES;
+    int waves = 4;
     if (const char *e = getenv("MKT_KS_WAVES")) waves = atoi(e);
     if (waves != 2 && waves != 4) waves = 1;
     if (G != 32) waves = 1;

@@ -137,10 +137,11 @@ def kms(p, trials=24, seed=1, block=False):
     sr2 = (p.beta / 2.0**W) ** 2
     rng = np.random.default_rng(seed)
     u = lambda bits, size=N: (rng.random(size) - 0.5) * 2.0 ** (-bits)             # rounding error of a decomposition to `bits` bits
-    s_fft1 = float64_product_error(N, bg, W, 2 * lg)                                # one CMux: 2 l products summed, one inverse
+    LB = p.blk_len if block else 1
+    # one CMux / block: 2 l LB products summed in the transform domain, times the monomial (|X^a - 1|, rms sqrt 2), ONE inverse
+    s_fft1 = float64_product_error(N, bg, W, 2 * lg * LB) * math.sqrt(2.0)
     s_fft2 = float64_product_error(N, bl, W, ll)
     s_fft3 = float64_product_error(N, bu, W, lu)
-    LB = p.blk_len if block else 1
     samples = []
     for _ in range(trials):
         zg = [rng.integers(0, 2, N).astype(np.float64) for _ in range(k)]           # gsw keys z'
