@@ -1,0 +1,50 @@
+"""The parameter sets' output noise, predicted from the schemes' variance formulas (tools/noise_theory.py: nothing of the
+oracle, the engine or the transforms is called), against the noise measured on the engine (profiles/r03_noise_measured.jsonl,
+tools/noise_measure.py on an MI355X).  An implementation that decrypted correctly but computed something other than the
+papers' external / hybrid products -- a misread key row, digit order or relinearisation step -- would be noisier than
+predicted; agreement within a few per cent on CGGI / LMSS / CCS pins the semantics of those paths independently of any
+transcription of the Julia source.  It also settles which sets are unsound by construction: CCS4party and CCS16party
+(params.jl:23-29, :39-45) leave 1.9 and 1.6 sigma of margin and fail on every implementation."""
+import json
+import math
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import noise_theory as T   # noqa: E402
+import mktfhe_amd as mk    # noqa: E402
+
+
+def measured():
+    out = {}
+    for ln in open(os.path.join(ROOT, "profiles", "r03_noise_measured.jsonl")):
+        d = json.loads(ln)
+        if d["variant"] == "as shipped":
+            out[d["set"]] = d["sigma_after_parties"][-1] if (d["fails"] > 0 and d["sigma_after_parties"]) else d["sigma"]
+    return out
+
+
+@pytest.mark.parametrize("name", ["CGGIparam", "CGGI_N1024_l2", "Blockparam", "Blockparam_k2", "CCS2party", "CCS4party", "CCS8party",
+                                  "CCS16party", "CCS8party_N2048"])
+def test_closed_form_noise_matches_the_engine(name):
+    _, _, tot = T.predict(getattr(mk, name))
+    ratio = measured()[name] / tot
+    assert 0.85 < ratio < 1.30, (name, tot, ratio)
+
+
+def test_ccs_sets_without_margin_are_predicted_to_fail():
+    """margin / sigma of the blind rotation + key switch alone; a NAND sees sqrt(2) x that noise at its input"""
+    for name, lo, hi in (("CCS2party", 3.5, 4.5), ("CCS4party", 1.5, 2.2), ("CCS8party", 2.8, 3.5), ("CCS16party", 1.3, 1.8)):
+        _, _, tot = T.predict(getattr(mk, name))
+        assert lo < 0.125 / tot < hi, (name, 0.125 / tot)
+
+
+def test_kms_linear_noise_model_matches_the_engine():
+    """KMS: the phase-1 error recursion and the phase-2 error identity simulated on random digits, keys and rounding errors
+    (the Float64 product error measured against exact integer products) -- heavy-tailed per gate, so a loose band"""
+    br, ks = T.kms(mk.KMS2party_N1024_l2, trials=6, seed=3)
+    ratio = measured()["KMS2party_N1024_l2"] / math.sqrt(br + ks)
+    assert 0.6 < ratio < 2.2, ratio
