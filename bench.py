@@ -162,15 +162,15 @@ def blindrotate_flop(mk, p, B):
     return per_iter * (p.n // LB) * rows * B, rows
 
 
-def make_scheme(mk, p, local, need_host_keys):
+def make_scheme(mk, p, local, need_host_keys, arith=0):
     """synthetic keys: pinned seed 1 (benchmark only); the large keys are generated on the GPU (mkt_keygen_device: the
     host generator's words), the host copies exist only where the CPU baseline needs them"""
     if p.multikey:
         crs = mk.CRS(p, 1)
         keys = [mk.party_keygen(crs, p, party=i, secrets_only=not need_host_keys, deterministic_seed=1) for i in range(p.k)]
-        return crs, keys, mk.setup(p, keys=keys, a=crs, device=local)
+        return crs, keys, mk.setup(p, keys=keys, a=crs, device=local, arith=arith)
     keys = [mk.PartyKeys(p, secrets_only=not need_host_keys, deterministic_seed=1)]
-    return None, keys, mk.setup(p, keys=keys[0], device=local)[1]
+    return None, keys, mk.setup(p, keys=keys[0], device=local, arith=arith)[1]
 
 
 def make_inputs(mk, torch, p, keys, sch, B, rank, dev, kind):
@@ -342,6 +342,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--workload", default="kms2_n1024", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch gates per GPU; strong: --batch gates in total, sharded over the ranks")
+    ap.add_argument("--arith", default="f64ref", choices=["f64ref", "exact"], help="f64ref: the reference's Float64 transforms, bit-identical to it (default); exact: integer NTT over two 31-bit primes (MKT_ARITH_EXACT: CGGI, LMSS, KMS)")
     ap.add_argument("--inputs", default="mixed", choices=["mixed", "fresh"], help="mixed: every ciphertext involves all k parties (default); fresh: single-party first-level encryptions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the transform legs (roofline_transform)")
@@ -384,7 +385,8 @@ def main():
         if B == 0:
             raise SystemExit(f"rank {rank}: empty shard (batch {args.batch} over {world} ranks)")
     need_host_keys = rank == 0 and world == 1 and not args.no_cpu_baseline
-    crs, keys, sch = make_scheme(mk, p, local, need_host_keys)
+    arith = mk.ARITH_EXACT if args.arith == "exact" else mk.ARITH_F64REF
+    crs, keys, sch = make_scheme(mk, p, local, need_host_keys, arith)
     bits, x, y = make_inputs(mk, torch, p, keys, sch, B, rank, dev, args.inputs)
     torch.cuda.synchronize()
     allc = np.concatenate([x.cpu().numpy(), y.cpu().numpy()]).view(np.uint32)
@@ -400,7 +402,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t["elapsed"] / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "params": pname, "parties": p.k, "N": p.N, "n": p.n, "ring_bits": p.W,
-                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": "NAND", "inputs": args.inputs, "arith": "F64REF", "sharding": "gates across GPUs, keys replicated"},
+                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": "NAND", "inputs": args.inputs, "arith": "F64REF" if args.arith == "f64ref" else "EXACT (integer NTT, residues mod 15*2^27+1 and 63*2^25+1)", "sharding": "gates across GPUs, keys replicated"},
             "ranks_seen": ranks_seen, "per_rank_ms_per_step": t["per_rank_ms"],
             # Wrong decryptions are the parameter set's own output noise (profiles/r03_noise_theory_vs_measured.md: predicted
             # from the schemes' variance formulas, measured on this engine; the oracle produces the identical words --
@@ -458,7 +460,7 @@ def main():
         line["cpu_baseline"] = {"value": sample / dt, "unit": "gates/s", "cores": cores, "kind": "port",
                                 "sample": f"{sample} NAND gates of the same workload, C oracle (F64REF restatement of the reference CPU path), {cores} threads (the host's CPU quota), one gate per thread",
                                 "seconds": dt}
-        line["oracle_bitexact"] = bool(np.array_equal(ref, res[:sample]))
+        line["oracle_bitexact"] = bool(np.array_equal(ref, res[:sample])) if args.arith == "f64ref" else None   # EXACT words differ from the Float64 reference by construction (checked against big-integer arithmetic in tests)
 
     if rank == 0:
         print(json.dumps(line), flush=True)

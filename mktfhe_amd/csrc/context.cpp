@@ -62,6 +62,7 @@ struct mkt_ctx {
     std::shared_ptr<KeySet> ks;  // shared with the contexts forked from this one
     bool exact = false;          // MKT_ARITH_EXACT (integer NTT, two 31-bit primes); d_ntt = psi_rev | psiinv_rev | N^-1 | N^-1 2^32, with Shoup companions
     uint64_t *d_ntt = nullptr;
+    int split = 1;               // EXACT on the 64-bit ring: every resident 64-bit table is kept as (low, high) residue polynomials -> 2 per logical polynomial
     // workspace
     size_t ws_gates = 0;
     uint32_t *ws_lin = nullptr;
@@ -106,7 +107,7 @@ void clear_spans(mkt_ctx *c) {
 size_t poly_bytes(const mkt_ctx *c) { return (size_t)c->p.N * c->sh.word; }
 
 // transform `npolys` coefficient-form polynomials (host) into TransPolys at `dst` (device)
-int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt) {
+int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt, bool small = false) {   // small: coefficients far below 2^32 in magnitude (monomials): never split
     if (c->exact && fmt != MKT_FMT_INT_COEFF) return fail(c, MKT_ERR_UNSUPPORTED, "an MKT_ARITH_EXACT context takes keys in integer form (MKT_FMT_INT_COEFF)");
     if (fmt == MKT_FMT_F64_FFT) {   // the reference's Trans* values: copy, then natural -> device point order
         cplx *tmpc = nullptr;
@@ -123,8 +124,9 @@ int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt
     void *tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, npolys * poly_bytes(c)));
     hipError_t e = hipMemcpyAsync(tmp, host, npolys * poly_bytes(c), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = c->exact ? mktd::launch_ntt_fwd(c->logN, c->p.W, c->d_ntt, tmp, reinterpret_cast<uint64_t *>(dst), npolys, 1, c->stream)   // N residues = the bytes of M complex
-                               : mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, c->dev_order, c->stream);
+    if (e == hipSuccess) e = !c->exact ? mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, c->dev_order, c->stream)
+                           : (c->split == 2 && !small) ? mktd::launch_ntt_fwd_split(c->logN, c->d_ntt, tmp, reinterpret_cast<uint64_t *>(dst), npolys, c->stream)   // 2 residue polynomials per input
+                           : mktd::launch_ntt_fwd(c->logN, c->p.W, c->d_ntt, tmp, reinterpret_cast<uint64_t *>(dst), npolys, 1, c->stream);   // N residues = the bytes of M complex
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) return hipfail(c, e, "key pre-transform");
@@ -143,7 +145,7 @@ int build_monomial(mkt_ctx *c) {   // scheme.jl:121-146
     for (int e = 1; e < N; e++) { set(e, 0, m1); set(e, e, 1); }            // -1 + X^e
     set(N, 0, m1 - 1);                                                       // -2
     for (int e = N + 1; e < 2 * N; e++) { set(e, 0, m1); set(e, e - N, m1); } // -1 - X^(e-N)
-    int r = upload_polys(c, host.data(), (size_t)2 * N, c->ks->d_monomial, MKT_FMT_INT_COEFF);
+    int r = upload_polys(c, host.data(), (size_t)2 * N, c->ks->d_monomial, MKT_FMT_INT_COEFF, true);
     if (r) return r;
     HIPCHK(c, hipMemsetAsync(c->ks->d_monomial + (size_t)(2 * N - 1) * c->M, 0, (size_t)c->M * sizeof(cplx), c->stream));  // entry 2N = 0
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -177,8 +179,8 @@ int ensure_workspace(mkt_ctx *c, size_t gates) {
     HIPCHK(c, hipMalloc((void **)&c->ws_lin, gates * (size_t)c->sh.lwe_len * 4));
     HIPCHK(c, hipMalloc(&c->ws_acc, gates * (size_t)(1 + c->sh.kacc) * poly_bytes(c)));
     if (mkt::is_kms(p.scheme)) {
-        HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * (size_t)c->ks->rtot * 2 * c->M * sizeof(cplx)));
-        HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)2 * (p.k + 1) * c->M * sizeof(cplx)));
+        HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * (size_t)c->ks->rtot * 2 * c->M * sizeof(cplx) * c->split));
+        HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)2 * (p.k + 1) * c->M * sizeof(cplx) * c->split));
     } else if (p.scheme == MKT_CCS) {
         HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * poly_bytes(c)));    // v scratch (ring words)
         HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)(p.k + 1) * c->M * sizeof(cplx)));
@@ -236,6 +238,19 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         if (const char *v = getenv("MKT_CCS_STAGGER")) q.stagger = atoi(v);
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_ccs_blindrotate(c->logM, p.W, q, B, c->stream));
+        return MKT_OK;
+    }
+    if (c->exact && p.scheme == MKT_KMS) {   // 64-bit ring, split tables: phase 1 and phase 2 with exact products (ntt_exact.hip)
+        mktd::ExactKmsArgs q{};
+        q.brk = reinterpret_cast<const uint64_t *>(c->ks->d_brk); q.brk_party_stride = c->ks->brk_party_cplx * 2 /* in 8-byte residue pairs */; q.mono = reinterpret_cast<const uint64_t *>(c->ks->d_monomial);
+        q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.k = p.k; q.l_gsw = p.l_gsw; q.logB_gsw = p.logB_gsw;
+        q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni; q.rtot = c->ks->rtot; q.lwe_len = c->sh.lwe_len;
+        q.slot_party = c->ks->d_slot_party; q.slot_row = c->ks->d_slot_row; q.levkey = reinterpret_cast<uint64_t *>(lev);
+        q.rlk_d = reinterpret_cast<const uint64_t *>(c->ks->d_rlk_d); q.rlk_f = reinterpret_cast<const uint64_t *>(c->ks->d_rlk_f);
+        q.pub_b = reinterpret_cast<const uint64_t *>(c->ks->d_pub); q.crs = reinterpret_cast<const uint64_t *>(c->ks->d_crs);
+        q.lin_for_tv = lin_for_tv; q.acc = reinterpret_cast<uint64_t *>(acc); q.scratch = reinterpret_cast<uint64_t *>(scratch); q.phase1_only = 0;
+        Timer tm(c, 1);
+        HIPCHK(c, mktd::launch_exact_kms(c->logN, c->d_ntt, q, B, c->stream));
         return MKT_OK;
     }
     if (c->exact) {          // CGGI / LMSS, RLWE length 1, 32-bit ring (exact_gate_ok): every product exact mod 2^32
@@ -355,13 +370,25 @@ int upload_ntt_tables(mkt_ctx *c) {
 // the gate path of an EXACT context: CGGI with RLWE length 1 on the 32-bit ring (every true product coefficient < p / 2)
 // (every true product coefficient below P / 2 = 2^60.88: 2l polynomials of N digits of magnitude <= 2^(logB-1) against 32-bit words)
 bool exact_gate_ok(const mkt_ctx *c) {
-    const bool lmss = c->p.scheme == MKT_LMSS;
-    if (!((c->p.scheme == MKT_CGGI || lmss) && c->p.k == 1 && c->p.W == 32)) return false;
-    if (lmss && c->p.blk_len != 3) return false;             // the block length the kernel is instantiated for (params.jl:8-13)
-    const double bound = (lmss ? 2.0 * c->p.blk_len : 1.0) * 2.0 * c->p.l_gsw * (double)c->p.N * std::ldexp(1.0, c->p.logB_gsw - 1) * 4294967296.0;
-    return bound < 0.5 * (double)NTT_P[0] * (double)NTT_P[1];
+    const double half_P = 0.5 * (double)NTT_P[0] * (double)NTT_P[1];
+    const mkt_params &p = c->p;
+    if (p.scheme == MKT_KMS && p.W == 64) {
+        // 64-bit ring: tables split into 32-bit halves, every accumulated product sum of one half must stay below P / 2:
+        // phase 1 (twice the sum after the monomial X^a - 1), the LEV multiplication + relinearisation sums, the v sum over the parties
+        const double n32 = (double)p.N * 4294967296.0;
+        const double ph1 = 2.0 * 2.0 * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n32;
+        const double acc = (p.l_lev * std::ldexp(1.0, p.logB_lev - 1) + 2.0 * p.l_uni * std::ldexp(1.0, p.logB_uni - 1)) * n32;
+        const double tv = (double)p.k * p.l_uni * std::ldexp(1.0, p.logB_uni - 1) * n32;
+        return ph1 < half_P && acc < half_P && tv < half_P;
+    }
+    const bool lmss = p.scheme == MKT_LMSS;
+    if (!((p.scheme == MKT_CGGI || lmss) && p.k == 1 && p.W == 32)) return false;
+    if (lmss && p.blk_len != 3) return false;             // the block length the kernel is instantiated for (params.jl:8-13)
+    const double bound = (lmss ? 2.0 * p.blk_len : 1.0) * 2.0 * p.l_gsw * (double)p.N * std::ldexp(1.0, p.logB_gsw - 1) * 4294967296.0;
+    return bound < half_P;
 }
-#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1, 32-bit ring, block length 3) only; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
+#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1, 32-bit ring, block length 3) and for KMS (64-bit ring, gadgets within the two-prime modulus); other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
+#define MKT_F64_OR_EXACT_KMS(c) do { if ((c) && (c)->exact && !((c)->p.scheme == MKT_KMS && exact_gate_ok(c))) return fail((c), MKT_ERR_UNSUPPORTED, "on an MKT_ARITH_EXACT context this entry point serves the KMS gate path only"); } while (0)
 #define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; not offered by an MKT_ARITH_EXACT context"); } while (0)
 
 }  // namespace
@@ -395,6 +422,7 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     c->p = *params; c->sh = mkt::shape_of(*params); c->device = device;
     c->logN = logN; c->logM = logN - 1; c->M = params->N / 2;
     c->exact = arith_mode == MKT_ARITH_EXACT;
+    c->split = (c->exact && params->W == 64) ? 2 : 1;
     // the RLWE-length-k kernels of the plain schemes want the slot-pair order, everything else the slot-major one (fft_device.h)
     c->dev_order = ((params->scheme == MKT_CGGI || params->scheme == MKT_LMSS) && params->k > 1) ? MKT_DEVORDER_KR : MKT_DEVORDER;
     DevGuard dg(device);
@@ -407,18 +435,18 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
 #define CK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(_e); return bail(_e == hipErrorOutOfMemory ? MKT_ERR_NOMEM : MKT_ERR_HIP); } } while (0)
     CK(hipMalloc((void **)&c->ks->d_tw, (size_t)4 * M * sizeof(cplx)));
     CK(hipMalloc((void **)&c->ks->d_monomial, (size_t)2 * N * M * sizeof(cplx)));
-    c->ks->brk_party_cplx = (size_t)p.n * c->sh.brk_polys * M;
+    c->ks->brk_party_cplx = (size_t)p.n * c->sh.brk_polys * M * c->split;
     CK(hipMalloc((void **)&c->ks->d_brk, (size_t)np * c->ks->brk_party_cplx * sizeof(cplx)));
     c->ks->n1p = (p.n + 1 + 3) / 4 * 4;   // device rows padded to 16 B
     c->ks->ksk_party_words = (size_t)c->sh.ksk_kr * N * c->sh.ksk_drows * p.f * c->ks->n1p;
     CK(hipMalloc((void **)&c->ks->d_ksk, (size_t)np * c->ks->ksk_party_words * sizeof(uint32_t)));
     if (mkt::is_mk(p.scheme)) {
-        CK(hipMalloc((void **)&c->ks->d_pub, (size_t)np * p.l_uni * M * sizeof(cplx)));
-        CK(hipMalloc((void **)&c->ks->d_crs, (size_t)p.l_uni * M * sizeof(cplx)));
+        CK(hipMalloc((void **)&c->ks->d_pub, (size_t)np * p.l_uni * M * sizeof(cplx) * c->split));
+        CK(hipMalloc((void **)&c->ks->d_crs, (size_t)p.l_uni * M * sizeof(cplx) * c->split));
     }
     if (mkt::is_kms(p.scheme)) {
-        CK(hipMalloc((void **)&c->ks->d_rlk_d, (size_t)np * p.l_uni * M * sizeof(cplx)));
-        CK(hipMalloc((void **)&c->ks->d_rlk_f, (size_t)np * p.l_uni * 2 * M * sizeof(cplx)));
+        CK(hipMalloc((void **)&c->ks->d_rlk_d, (size_t)np * p.l_uni * M * sizeof(cplx) * c->split));
+        CK(hipMalloc((void **)&c->ks->d_rlk_f, (size_t)np * p.l_uni * 2 * M * sizeof(cplx) * c->split));
     }
     // rotation slots: KMS phase 1 runs 1 row for party 0 and l_lev rows for the others (bootstrapping.jl:400)
     std::vector<int> sp, sr;
@@ -549,29 +577,29 @@ int mkt_load_ksk(mkt_ctx *c, int party, const uint32_t *data) {
 
 int mkt_load_rlk(mkt_ctx *c, int party, const void *d, const void *f, int fmt) {
     if (!c || !d || !f || party < 0 || party >= c->sh.nparty || !mkt::is_kms(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_F64_OR_EXACT_KMS(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     const size_t l = (size_t)c->p.l_uni;
-    int r = upload_polys(c, d, l, c->ks->d_rlk_d + (size_t)party * l * c->M, fmt);
-    if (!r) r = upload_polys(c, f, 2 * l, c->ks->d_rlk_f + (size_t)party * 2 * l * c->M, fmt);
+    int r = upload_polys(c, d, l, c->ks->d_rlk_d + (size_t)party * l * c->M * c->split, fmt);
+    if (!r) r = upload_polys(c, f, 2 * l, c->ks->d_rlk_f + (size_t)party * 2 * l * c->M * c->split, fmt);
     if (!r) c->ks->rlk_loaded[party] = 1;
     return r;
 }
 
 int mkt_load_pubkey(mkt_ctx *c, int party, const void *b, int fmt) {
     if (!c || !b || party < 0 || party >= c->sh.nparty || !mkt::is_mk(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_F64_OR_EXACT_KMS(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
-    int r = upload_polys(c, b, (size_t)c->p.l_uni, c->ks->d_pub + (size_t)party * c->p.l_uni * c->M, fmt);
+    int r = upload_polys(c, b, (size_t)c->p.l_uni, c->ks->d_pub + (size_t)party * c->p.l_uni * c->M * c->split, fmt);
     if (!r) c->ks->pub_loaded[party] = 1;
     return r;
 }
 
 int mkt_load_crs(mkt_ctx *c, const void *a, int fmt) {
     if (!c || !a || !mkt::is_mk(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_F64_OR_EXACT_KMS(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
     int r = upload_polys(c, a, (size_t)c->p.l_uni, c->ks->d_crs, fmt);
@@ -616,7 +644,8 @@ static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, 
     else { a.kr = c->sh.kr; a.l = p.l_gsw; a.logB = p.logB_gsw; a.zoff = 0; }
     e = mktd::launch_keygen_brk(a, unienc ? 1 : 0, c->stream);
     if (e == hipSuccess && brk_out) e = hipMemcpyAsync(brk_out, d_out, brk_polys_total * poly_bytes(c), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = c->exact ? mktd::launch_ntt_fwd(c->logN, p.W, c->d_ntt, d_out, reinterpret_cast<uint64_t *>(c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx), brk_polys_total, 1, c->stream)
+    if (e == hipSuccess) e = (c->exact && c->split == 2) ? mktd::launch_ntt_fwd_split(c->logN, c->d_ntt, d_out, reinterpret_cast<uint64_t *>(c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx), brk_polys_total, c->stream)
+                           : c->exact ? mktd::launch_ntt_fwd(c->logN, p.W, c->d_ntt, d_out, reinterpret_cast<uint64_t *>(c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx), brk_polys_total, 1, c->stream)
                                : mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, brk_polys_total, c->dev_order, c->stream);
     uint32_t *ksk = c->ks->d_ksk + (size_t)party * c->ks->ksk_party_words;
     if (e == hipSuccess) e = hipMemsetAsync(ksk, 0, c->ks->ksk_party_words * sizeof(uint32_t), c->stream);
@@ -738,13 +767,23 @@ int mkt_blindrotate_batch(mkt_ctx *c, const uint32_t *atilde, void *acc, size_t 
 
 int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, size_t B, int mem) {
     if (!c || !atilde || !levkey || !mem_ok(mem) || !mkt::is_kms(c->p.scheme)) return fail(c, MKT_ERR_ARG, "bad argument");
-    MKT_F64_ONLY(c);
+    MKT_F64_OR_EXACT_KMS(c);
     int r;
     if ((r = check_ready(c, true, false))) return r;
     DevGuard dg(c->device);
-    const size_t alen = (size_t)c->sh.lwe_len - 1, lb = (size_t)c->ks->rtot * 2 * c->M * sizeof(cplx);
+    const size_t alen = (size_t)c->sh.lwe_len - 1, lb = (size_t)c->ks->rtot * 2 * c->M * sizeof(cplx) * c->split;
     Staged sa{c}, sl{c};
     if ((r = sa.in(atilde, B * alen * 4, mem, true)) || (r = sl.in(levkey, B * lb, mem, false))) return r;
+    if (c->exact) {   // the rows as split residue tables [B][rows][2 polys][2 halves][N] (uint64 residue pairs, Montgomery form)
+        const mkt_params &p = c->p;
+        mktd::ExactKmsArgs q{};
+        q.brk = reinterpret_cast<const uint64_t *>(c->ks->d_brk); q.brk_party_stride = c->ks->brk_party_cplx * 2 /* in 8-byte residue pairs */; q.mono = reinterpret_cast<const uint64_t *>(c->ks->d_monomial);
+        q.lwe = (const uint32_t *)sa.dev; q.lwe_stride = (int)alen; q.pre_switched = 1; q.n = p.n; q.k = p.k; q.l_gsw = p.l_gsw; q.logB_gsw = p.logB_gsw;
+        q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni; q.rtot = c->ks->rtot; q.lwe_len = c->sh.lwe_len;
+        q.slot_party = c->ks->d_slot_party; q.slot_row = c->ks->d_slot_row; q.levkey = (uint64_t *)sl.dev; q.phase1_only = 1;
+        { Timer tm(c, 1); HIPCHK(c, mktd::launch_exact_kms(c->logN, c->d_ntt, q, B, c->stream)); }
+        return sl.out(levkey);
+    }
     mktd::RotArgs a = rot_args(c, (const uint32_t *)sa.dev, (int)alen, 1);
     a.init_mode = 1; a.out_mode = 1; a.tout = (cplx *)sl.dev; a.tout_natural = 1; a.ngates = B;
     { Timer tm(c, 1); HIPCHK(c, mktd::launch_blindrotate_k1(c->logM, c->p.W, a, B * (size_t)c->ks->rtot, c->stream)); }

@@ -133,6 +133,21 @@ hipError_t launch_ntt_inv(int logN, int W, const uint64_t *tab, const uint64_t *
 // CGGI blind rotation (RLWE length 1, 32-bit ring) with exact products; brk [n][2l][2][N], mono [2N][N] residues, natural order
 hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
                                     int pre_switched, int n, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s);
+// the 64-bit ring with exact products (KMS): resident 64-bit tables as (low, high) residue polynomials per logical polynomial
+hipError_t launch_ntt_fwd_split(int logN, const uint64_t *tab, const void *p, uint64_t *out, size_t B, hipStream_t s);
+struct ExactKmsArgs {
+    const uint64_t *brk; size_t brk_party_stride;   // split tables, u64 units; [n][2l][2 polys][2 halves][N] per party
+    const uint64_t *mono;                           // [2N][N] (not split)
+    const uint32_t *lwe; int lwe_stride, pre_switched;
+    int n, k, l_gsw, logB_gsw, l_lev, logB_lev, l_uni, logB_uni, rtot, lwe_len;
+    const int *slot_party, *slot_row;
+    uint64_t *levkey;                               // [B][rtot][2][2][N]
+    const uint64_t *rlk_d, *rlk_f, *pub_b, *crs;    // split tables
+    const uint32_t *lin_for_tv;                     // bootstrapping.jl:11-23 from the linear combination, or NULL (acc holds the test vector)
+    uint64_t *acc, *scratch;                        // [B][1+k][N] ; [B][4(k+1)][N]
+    int phase1_only;
+};
+hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a, size_t B, hipStream_t s);
 hipError_t launch_exact_polymul(int logN, int W, const uint64_t *tab, const void *a, const void *b, void *out, size_t B, hipStream_t s);
 
 }  // namespace mktd

@@ -358,6 +358,272 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
         for (int e = 0; e < 8; e++) accg[c * N + e * NT + t] = acc[c][e];
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 64-bit ring (KMS) with exact products.  A product  digit polynomial x 64-bit polynomial  exceeds P, so every resident
+// 64-bit table is kept as TWO residue polynomials -- the transforms of its low and of its high 32-bit halves (unsigned
+// pieces) -- every sum of such products as a (low, high) pair of transform-domain accumulators, and every inverse runs
+// twice:  sum_j d_j T_j = [sum_j d_j lo(T_j)] + 2^32 [sum_j d_j hi(T_j)]  mod 2^64,  each bracket an exact integer below
+// P / 2 (count * N * 2^(logB-1) * 2^32, twice that after the monomial; checked on the host for the context's gadgets).
+// Layout of a split table: logical polynomial i -> residue polynomials 2i (low half) and 2i + 1 (high half), natural
+// transform order, Montgomery form.  The monomial table (coefficients -2 .. 1) is not split.
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) void ntt_fwd_split_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ p,
+                                                                           uint64_t *__restrict__ out, size_t B) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
+    const int t = threadIdx.x;
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + N), t, NT, tw, which);
+    for (size_t b = blockIdx.x; b < B; b += gridDim.x) {
+        uint64_t w[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) w[e] = p[b * N + e * NT + t];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            Pt z[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const uint32_t piece = (uint32_t)(w[e] >> (32 * h)); z[e].a = red_u32<P1>(piece); z[e].b = red_u32<P2>(piece); }
+            ntt_forward<LOGN>(z, tw[0], lds, t);
+#pragma unroll
+            for (int e = 0; e < 8; e++) out[(2 * b + h) * N + 8 * t + e] = pack(Pt{montmul<P1, PI1>(z[e].a, RR1), montmul<P2, PI2>(z[e].b, RR2)});
+            __syncthreads();
+        }
+    }
+}
+
+// the exact integers behind a (low, high) accumulator pair, combined mod 2^64: inverse transforms, N^-1, Garner lift
+template <int LOGN>
+__device__ __forceinline__ void lift_pair(Pt (&lo)[8], Pt (&hi)[8], uint64_t (&w)[8], const uint4 *psiinv, const NttConsts &k, uint64_t *lds, int t) {
+    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(lo, psiinv, lds, t);
+    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(hi, psiinv, lds, t);
+#pragma unroll
+    for (int e = 0; e < 8; e++) w[e] = crt_signed(pt_shoup(lo[e], k.ninv)) + (crt_signed(pt_shoup(hi[e], k.ninv)) << 32);
+}
+
+// KMS phase 1 (bootstrapping.jl:389-443) with exact products: one workgroup per RLEV row rotation, accumulator (b, a) in
+// registers (slot e = coefficient e*NT + t); output: the row's two polynomials as split residue tables for phase 2
+template <int LOGN>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase1_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
+                                                                              const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe, int lwe_stride,
+                                                                              int pre_switched, int n, int l, int logB, size_t ngates, int rows_per_gate,
+                                                                              const int *__restrict__ slot_party, const int *__restrict__ slot_row, int logB_lev,
+                                                                              uint64_t *__restrict__ lev_out) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
+    const int t = threadIdx.x;
+    const uint4 *tw[2]; const int which[2] = {0, 1};
+    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + N), t, NT, tw, which);
+    const NttConsts k = tab_consts<LOGN>(tab);
+    const size_t gate = blockIdx.x % ngates;
+    const int slot = (int)(blockIdx.x / ngates);
+    const size_t rot = gate * (size_t)rows_per_gate + slot;
+    const int party = slot_party[slot], row = slot_row[slot];
+    const uint32_t *at_src = lwe + gate * (size_t)lwe_stride + (size_t)party * n;
+    const uint64_t *brk = brk0 + (size_t)party * brk_party_stride;
+    const Gadget<uint64_t> gd(l, logB);
+    uint64_t acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[c][e] = 0;
+    if (t == 0) acc[0][0] = (uint64_t)1 << (64 - (row + 1) * logB_lev);           // :403-406 trivial RLEV row
+    const int msbit = 32 - LOGN - 1;
+    for (int i = 0; i < n; i++) {
+        const uint32_t v0 = at_src[i];
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+        if (at == 0) continue;                                                     // :413
+        Pt tacc[2][2][8];                                                          // [output polynomial][half]
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) { tacc[pp][h][e].a = 0; tacc[pp][h][e].b = 0; }
+        for (int c = 0; c < 2; c++) {
+            uint64_t tp[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) tp[e] = gd.prep(c ? acc[1][e] : acc[0][e]);   // :415-425 decompto!
+            for (int j = 0; j < l; j++) {
+                Pt z[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(tp[e], j));
+                ntt_forward<LOGN>(z, tw[0], lds, t);
+                const uint64_t *rowp = brk + (((size_t)i * 2 * l + (size_t)(c * l + j)) * 4) * N + 8 * t;   // [poly][half][N]
+#pragma unroll
+                for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int e = 0; e < 8; e++) tacc[pp][h][e] = pt_add(tacc[pp][h][e], pt_mont(z[e], unpack(rowp[(size_t)(pp * 2 + h) * N + e])));   // :427-432, exactly
+            }
+        }
+        const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) tacc[pp][h][e] = pt_mont(tacc[pp][h][e], unpack(mrow[e]));   // :435
+            uint64_t w[8];
+            lift_pair<LOGN>(tacc[pp][0], tacc[pp][1], w, tw[1], k, lds, t);        // :436
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[pp][e] += w[e];                        // :437
+        }
+    }
+    // :441 fftto!(tacc, acc): the row as split residue tables, Montgomery form
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            Pt z[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const uint32_t piece = (uint32_t)(acc[c][e] >> (32 * h)); z[e].a = red_u32<P1>(piece); z[e].b = red_u32<P2>(piece); }
+            ntt_forward<LOGN>(z, tw[0], lds, t);
+            uint64_t *o = lev_out + ((rot * 2 + c) * 2 + h) * (size_t)N + 8 * t;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = pack(Pt{montmul<P1, PI1>(z[e].a, RR1), montmul<P2, PI2>(z[e].b, RR2)});
+            __syncthreads();
+        }
+}
+
+// KMS phase 2 (bootstrapping.jl:448-558) with exact products; one workgroup per ciphertext, every thread only touches its
+// own coefficients (e*NT + t) and transform points (8t + e)
+struct ExactPhase2Args {
+    const uint32_t *lin; int lwe_stride;
+    int k, l_lev, logB_lev, l_uni, logB_uni, rtot;
+    const uint64_t *levkey;    // [B][rtot][2 polys][2 halves][N]
+    const uint64_t *rlk_d;     // [k][l_uni][2 halves][N]
+    const uint64_t *rlk_f;     // [k][l_uni][2 polys][2 halves][N]
+    const uint64_t *pub_b;     // [k][l_uni][2 halves][N]
+    const uint64_t *crs;       // [l_uni][2 halves][N]
+    uint64_t *acc;             // [B][1+k][N]
+    uint64_t *scratch;         // [B][2][k+1][2 halves][N]
+};
+template <int LOGN>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(const uint4 *__restrict__ tab, const ExactPhase2Args a) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
+    const int t = threadIdx.x;
+    const uint4 *tw[2]; const int which[2] = {0, 1};
+    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + N), t, NT, tw, which);
+    const NttConsts kc = tab_consts<LOGN>(tab);
+    const size_t g = blockIdx.x;
+    const int k = a.k;
+    uint64_t *acc = a.acc + g * (size_t)(k + 1) * N;
+    uint64_t *tx = a.scratch + g * (size_t)4 * (k + 1) * N;
+    uint64_t *ty2 = tx + (size_t)2 * (k + 1) * N;
+    const Gadget<uint64_t> glev(a.l_lev, a.logB_lev), guni(a.l_uni, a.logB_uni);
+    if (a.lin) {                                                                   // bootstrapping.jl:11-23
+        uint32_t tb = divbits<uint32_t>(a.lin[g * a.lwe_stride + a.lwe_stride - 1], 32 - LOGN - 1);
+        const uint64_t ev = (uint64_t)1 << 61, me = (uint64_t)0 - ev;
+        uint64_t lo_v = ev, hi_v = me;
+        if (tb > (uint32_t)N) { tb -= (uint32_t)N; lo_v = me; hi_v = ev; }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int i = e * NT + t;
+            acc[i] = ((uint32_t)i < tb) ? lo_v : hi_v;
+            for (int q = 1; q <= k; q++) acc[(size_t)q * N + i] = 0;
+        }
+    }
+    auto zero2 = [](Pt (&x)[2][8]) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) { x[h][e].a = 0; x[h][e].b = 0; }
+    };
+    auto digit_ntt = [&](Pt (&z)[8], const uint64_t (&tp)[8], const Gadget<uint64_t> &gd, int j) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(tp[e], j));
+        ntt_forward<LOGN>(z, tw[0], lds, t);
+    };
+    auto mac2 = [&](Pt (&dst)[2][8], const Pt (&z)[8], const uint64_t *tbl, bool subtract) {   // dst += / -= z * (low, high) of one split polynomial
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const Pt pr = pt_mont(z[e], unpack(tbl[(size_t)h * N + 8 * t + e]));
+                dst[h][e] = subtract ? pt_sub(dst[h][e], pr) : pt_add(dst[h][e], pr);
+            }
+    };
+    for (int idx = 0; idx < k; idx++) {
+        const int iter = idx == 0 ? 1 : a.l_lev;                                   // :481
+        const int rowbase = idx == 0 ? 0 : 1 + (idx - 1) * a.l_lev;
+        const uint64_t *lev = a.levkey + (g * (size_t)a.rtot + rowbase) * 4 * N;   // [row][poly][half][N]
+        const uint64_t *rd = a.rlk_d + (size_t)idx * a.l_uni * 2 * N;
+        const uint64_t *rf = a.rlk_f + (size_t)idx * a.l_uni * 4 * N;
+        Pt tv[2][8];
+        zero2(tv);
+        for (int q = 0; q <= idx; q++) {
+            uint64_t tp[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) tp[e] = glev.prep(acc[(size_t)q * N + e * NT + t]);   // :470-471
+            Pt txq[2][8], tyq[2][8];
+            zero2(txq); zero2(tyq);
+            for (int j = 0; j < iter; j++) {                                       // :485-499 LEV multiplication
+                Pt z[8];
+                digit_ntt(z, tp, glev, j);
+                mac2(txq, z, lev + (size_t)(2 * j) * 2 * N, false);
+                mac2(tyq, z, lev + (size_t)(2 * j + 1) * 2 * N, false);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) tx[((size_t)q * 2 + h) * N + 8 * t + e] = pack(txq[h][e]);
+            uint64_t yw[8];
+            lift_pair<LOGN>(tyq[0], tyq[1], yw, tw[1], kc, lds, t);                // :501-504
+#pragma unroll
+            for (int e = 0; e < 8; e++) tp[e] = guni.prep(yw[e]);                  // :508-509
+            Pt tyu[2][8];
+            zero2(tyu);
+            const uint64_t *vk = q == 0 ? a.crs : a.pub_b + (size_t)(q - 1) * a.l_uni * 2 * N;
+            for (int j = 0; j < a.l_uni; j++) {                                    // :521-535 u and v
+                Pt z[8];
+                digit_ntt(z, tp, guni, j);
+                mac2(tyu, z, rd + (size_t)j * 2 * N, false);
+                mac2(tv, z, vk + (size_t)j * 2 * N, q == 0);                       // mulsubto! with crs, muladdto! with b_i
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) ty2[((size_t)q * 2 + h) * N + 8 * t + e] = pack(tyu[h][e]);
+        }
+        uint64_t vw[8];
+        lift_pair<LOGN>(tv[0], tv[1], vw, tw[1], kc, lds, t);                      // :538
+        uint64_t tp[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) tp[e] = guni.prep(vw[e]);                      // :541
+        Pt tyb[2][8], tya[2][8];
+        zero2(tya);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) tyb[h][e] = unpack(ty2[(size_t)h * N + 8 * t + e]);
+        for (int i = 0; i < a.l_uni; i++) {                                        // :547-550 w
+            Pt z[8];
+            digit_ntt(z, tp, guni, i);
+            mac2(tyb, z, rf + (size_t)(2 * i) * 2 * N, false);
+            mac2(tya, z, rf + (size_t)(2 * i + 1) * 2 * N, false);
+        }
+        for (int q = 0; q <= idx + 1; q++) {                                       // :553 add!(tx, ty); :556 ifftto!(acc, tx)
+            Pt s[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    Pt xv; xv.a = 0; xv.b = 0;
+                    if (q <= idx) xv = unpack(tx[((size_t)q * 2 + h) * N + 8 * t + e]);
+                    const Pt yv = q == 0 ? tyb[h][e] : (q == idx + 1 ? tya[h][e] : unpack(ty2[((size_t)q * 2 + h) * N + 8 * t + e]));
+                    s[h][e] = pt_add(xv, yv);
+                }
+            uint64_t w[8];
+            lift_pair<LOGN>(s[0], s[1], w, tw[1], kc, lds, t);
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[(size_t)q * N + e * NT + t] = w[e];
+        }
+    }
+}
+
 template <typename K>
 static hipError_t ntt_set_lds(K kern, size_t bytes) {
     if (bytes > 48 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -431,6 +697,36 @@ hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_
             hipError_t e = ntt_set_lds(exact_blindrotate_kernel<LN, 3>, lds); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((exact_blindrotate_kernel<LN, 3>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, acc);
         }
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt_fwd_split(int logN, const uint64_t *tab, const void *p, uint64_t *out, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    const int grid = (int)(B < 32768 ? B : 32768);
+    const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
+    MKT_NTT_DISPATCH(logN, {
+        const size_t lds = lds_bytes<LN>(1);
+        hipError_t e = ntt_set_lds(ntt_fwd_split_kernel<LN>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((ntt_fwd_split_kernel<LN>), dim3(grid), dim3(1 << (LN - NLR)), lds, s, tb, (const uint64_t *)p, out, B);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
+    MKT_NTT_DISPATCH(logN, {
+        const size_t lds = lds_bytes<LN>(2);
+        hipError_t e = ntt_set_lds(exact_kms_phase1_kernel<LN>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((exact_kms_phase1_kernel<LN>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
+                           a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+        if (a.phase1_only) return hipGetLastError();
+        ExactPhase2Args q;
+        q.lin = a.lin_for_tv; q.lwe_stride = a.lwe_len; q.k = a.k; q.l_lev = a.l_lev; q.logB_lev = a.logB_lev; q.l_uni = a.l_uni; q.logB_uni = a.logB_uni; q.rtot = a.rtot;
+        q.levkey = a.levkey; q.rlk_d = a.rlk_d; q.rlk_f = a.rlk_f; q.pub_b = a.pub_b; q.crs = a.crs; q.acc = a.acc; q.scratch = a.scratch;
+        e = ntt_set_lds(exact_kms_phase2_kernel<LN>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((exact_kms_phase2_kernel<LN>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, q);
     });
     return hipGetLastError();
 }

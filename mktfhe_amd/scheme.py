@@ -376,7 +376,10 @@ class Scheme:
         B = self._batch(a)
         p = self.params
         rtot = 1 + (p.k - 1) * p.l_lev
-        out = np.empty(a.shape[:-1] + (rtot, 2, p.N // 2), dtype=np.complex128)
+        if self.arith == ARITH_EXACT:    # split residue tables: [rows][polynomial b / a][low / high 32-bit half][N] residue pairs, Montgomery form
+            out = np.empty(a.shape[:-1] + (rtot, 2, 2, p.N), dtype=np.uint64)
+        else:
+            out = np.empty(a.shape[:-1] + (rtot, 2, p.N // 2), dtype=np.complex128)
         self._ck(_lib.lib().mkt_kms_phase1_batch(self.h, _np_ptr(a), _np_ptr(out), B, MEM_HOST))
         return out
 
@@ -422,7 +425,7 @@ class Scheme:
         return out
 
 
-def setup(params: Params, keys=None, a=None, device=0, deterministic_seed=None):
+def setup(params: Params, keys=None, a=None, device=0, deterministic_seed=None, arith=ARITH_F64REF):
     """scheme.jl:151 / :190 setup(params) -> (keys, scheme) for the single-key schemes, and
     scheme.jl:244 / :292 / :343 setup(a, btk, params) -> scheme for the multi-key ones
     (keys = list of PartyKeys, a = CRS).  The evaluation keys are uploaded and pre-transformed
@@ -431,10 +434,10 @@ def setup(params: Params, keys=None, a=None, device=0, deterministic_seed=None):
         (sch.keygen_device if kk.secrets_only else sch.load_party)(i, kk)
     if not params.multikey:
         ks = keys if keys is not None else PartyKeys(params, party=0, deterministic_seed=deterministic_seed)
-        sch = Scheme(params, device=device)
+        sch = Scheme(params, device=device, arith=arith)
         install(sch, 0, ks)
         return ks, sch
-    sch = Scheme(params, device=device)
+    sch = Scheme(params, device=device, arith=arith)
     sch.load_crs(a)
     for i, kk in enumerate(keys):
         install(sch, i, kk)

@@ -1,4 +1,4 @@
-"""Exact-arithmetic restatement of the CGGI and LMSS gate bootstraps (test infrastructure; checker of the MKT_ARITH_EXACT
+"""Exact-arithmetic restatement of the CGGI, LMSS and KMS gate bootstraps (test infrastructure; checker of the MKT_ARITH_EXACT
 gate path): bootstrapping.jl:4-76 / :114-165 with every transform-domain product replaced by the exact negacyclic product
 mod 2^W (the oracle's schoolbook), i.e. what the reference's Float64 pipeline approximates.  Mod-switch, test vector, gadget
 decomposition and key switch are the integer steps of the oracle itself."""
@@ -64,6 +64,81 @@ def blindrotate_lmss(p, brk, atilde, acc):
                 add[pp] = (add[pp] + monomial_minus_one(t, a, N, W)) & mask       # :157
         acc = (acc + add) & mask                                           # :162-163
     return acc.reshape(-1)
+
+
+def kms_phase1(p, brk, at_party, party):
+    """bootstrapping.jl:389-443 with exact products: the RLEV rows [(b, a)] of one party (1 row for party 0, l_lev otherwise)"""
+    N, W, l = p.N, p.W, p.l_gsw
+    mask = np.uint64((1 << W) - 1)
+    brk = brk.reshape(p.n, 2 * l, 2, N).astype(np.uint64)
+    rows = []
+    for r in range(1 if party == 0 else p.l_lev):
+        acc = np.zeros((2, N), dtype=np.uint64)
+        acc[0, 0] = np.uint64(1) << np.uint64(W - (r + 1) * p.logB_lev)             # :403-406
+        for i in range(p.n):
+            a = int(at_party[i])
+            if a == 0:
+                continue                                                       # :413
+            dig = [O.decomp_poly(acc[c], l, p.logB_gsw, W) for c in range(2)]
+            new = acc.copy()
+            for pp in range(2):
+                t = np.zeros(N, dtype=np.uint64)
+                for c in range(2):
+                    for j in range(l):
+                        t = (t + O.negacyclic(dig[c][j], brk[i, c * l + j, pp], W)) & mask
+                new[pp] = (acc[pp] + monomial_minus_one(t, a, N, W)) & mask      # :435-437
+            acc = new
+        rows.append(acc)
+    return rows
+
+
+def kms_phase2(p, lev, keys, crs, acc):
+    """bootstrapping.jl:448-558 with exact products.  lev[party] = rows of kms_phase1; keys: PartyKeys (integer rlk_d, rlk_f,
+    pubkey); crs: [l_uni][N]; acc: [k+1][N] (test vector in polynomial 0)"""
+    N, W, k = p.N, p.W, p.k
+    ll, lu = p.l_lev, p.l_uni
+    mask = np.uint64((1 << W) - 1)
+    mul = lambda d, t: O.negacyclic(d, t, W)
+    acc = [np.asarray(a, dtype=np.uint64).copy() for a in np.asarray(acc).reshape(k + 1, N)]
+    crs = np.asarray(crs).reshape(lu, N).astype(np.uint64)
+    for idx in range(k):
+        rows = lev[idx]
+        it = 1 if idx == 0 else ll                                             # :481
+        rd = keys[idx].rlk_d.reshape(lu, N).astype(np.uint64)
+        rf = keys[idx].rlk_f.reshape(lu, 2, N).astype(np.uint64)
+        dig = [O.decomp_poly(acc[q], ll, p.logB_lev, W) for q in range(idx + 1)]    # :470-479
+        tx = [np.zeros(N, dtype=np.uint64) for _ in range(k + 1)]
+        ty = [np.zeros(N, dtype=np.uint64) for _ in range(k + 1)]
+        for q in range(idx + 1):
+            for j in range(it):                                                # :485-499
+                tx[q] = (tx[q] + mul(dig[q][j], rows[j][0])) & mask
+                ty[q] = (ty[q] + mul(dig[q][j], rows[j][1])) & mask
+        ydig = [O.decomp_poly(ty[q], lu, p.logB_uni, W) for q in range(idx + 1)]    # :501-517
+        ty = [np.zeros(N, dtype=np.uint64) for _ in range(k + 1)]
+        tv = np.zeros(N, dtype=np.uint64)
+        for q in range(idx + 1):
+            vk = crs if q == 0 else keys[q - 1].pubkey.reshape(lu, N).astype(np.uint64)
+            for j in range(lu):                                                # :521-535
+                ty[q] = (ty[q] + mul(ydig[q][j], rd[j])) & mask
+                pr = mul(ydig[q][j], vk[j])
+                tv = (tv - pr) & mask if q == 0 else (tv + pr) & mask
+        vdig = O.decomp_poly(tv, lu, p.logB_uni, W)                              # :538-544
+        for i in range(lu):                                                    # :547-550
+            ty[0] = (ty[0] + mul(vdig[i], rf[i, 0])) & mask
+            ty[1 + idx] = (ty[1 + idx] + mul(vdig[i], rf[i, 1])) & mask
+        acc = [(tx[q] + ty[q]) & mask for q in range(k + 1)]                   # :553-556
+    return np.stack(acc)
+
+
+def kms_blindrotate(p, keys, crs, atilde, acc):
+    lev = [kms_phase1(p, keys[i].brk, atilde[i * p.n:(i + 1) * p.n], i) for i in range(p.k)]
+    return kms_phase2(p, lev, keys, crs, acc)
+
+
+def kms_gate(p, so, keys, crs, op, x, y):
+    lin = O.gate_linear(op, x, y)
+    at, bt = so.modswitch(lin)
+    return so.keyswitch(kms_blindrotate(p, keys, crs, at, so.testvector(bt)))
 
 
 def gate(p, so, brk, op, x, y):

@@ -949,6 +949,51 @@ def test_exact_mode_integer_ntt(require_gpu, N, W):
     ex.close()
 
 
+@pytest.mark.parametrize("p", [mk.KMS2party.scaled(n=8, N=256), mk.KMS2party_N1024_l2.scaled(n=8), mk.KMS2party.scaled(n=6), mk.KMS4party.scaled(n=4, N=512),
+                               mk.KMS8party.scaled(n=3, N=256, k=3)], ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
+def test_exact_mode_kms_gates(require_gpu, p):
+    """MKT_ARITH_EXACT on the 64-bit ring (KMS, bootstrapping.jl:369-594): every resident 64-bit table kept as the transforms
+    of its low and high 32-bit halves, every product sum as a (low, high) accumulator pair with two inverse transforms.
+    Accumulators after the whole blind rotation (phase 1 + phase 2) and gate outputs equal the exact-arithmetic restatement
+    (tests/ref_exact.py: the oracle's integer steps + exact schoolbook products mod 2^64) word for word, on inputs that
+    involve every party; they decrypt; and their noise is BELOW the Float64 path's (whose transform error dominates the KMS
+    output noise: profiles/r03_kms_stage_noise.txt)."""
+    import ref_exact as RX
+    crs, keys = keygen(p, 73)
+    so = oracle_scheme(p, crs, keys)
+    sx = mk.Scheme(p, arith=mk.ARITH_EXACT)
+    sx.load_crs(crs)
+    for i, kk in enumerate(keys):
+        sx.load_party(i, kk)
+    k, B = p.k, 3
+    rng = np.random.default_rng(74)
+    bits = rng.integers(0, 2, 2 * B * k).astype(bool)
+    c = encrypt_bits(p, keys, bits, seed=7400)                       # ciphertext j under party j mod k
+    # all-party inputs by ciphertext addition: party 0's bit + (enc 1 + enc 0) of every other party
+    def allp(j):
+        ct = mk.lwe_ith_encrypt(int(bits[j]), 0, keys[0], p, deterministic_seed=8000 + 100 * j).astype(np.uint32)
+        for i in range(1, k):
+            for m in (0, 1):
+                ct = ct + mk.lwe_ith_encrypt(m, i, keys[i], p, deterministic_seed=8000 + 100 * j + 2 * i + m).astype(np.uint32)
+        return ct
+    x = np.stack([allp(j) for j in range(B)]); y = np.stack([allp(B + j) for j in range(B)])
+    lin = np.stack([O.gate_linear(0, x[j], y[j]) for j in range(B)])
+    at, bt = sx.modswitch(lin)
+    at[0, :2] = [0, 2 * p.N]
+    acc0 = np.stack([so.testvector(bt[j]) for j in range(B)])
+    acc_x = sx.blindrotate_(at, acc0.astype(np.uint64).copy())
+    for j in range(B):
+        assert np.array_equal(acc_x[j], RX.kms_blindrotate(p, keys, crs, at[j], acc0[j])), f"exact KMS blind rotation {j}"
+    for op in (0, 3):
+        out = sx.gate(op, x, y)
+        assert np.array_equal(out, np.stack([RX.kms_gate(p, so, keys, crs, op, x[j], y[j]) for j in range(B)])), f"exact KMS gate {op}"
+        assert np.array_equal(mk.lwe_decrypt(out, keys, p), GATE_FUNCS[op](bits[:B], bits[B:2 * B]))
+    z = x.copy()
+    sx.bootstrapping_(z)
+    assert np.array_equal(mk.lwe_decrypt(z, keys, p), bits[:B])
+    sx.close()
+
+
 @pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=12, N=256), mk.CGGIparam.scaled(n=10, N=1024), mk.CGGI_N1024_l2.scaled(n=10),
                                mk.CGGIparam.scaled(n=6, N=2048, l_gsw=4, logB_gsw=7),
                                mk.Blockparam.scaled(n=12, N=256, blk_d=4), mk.Blockparam.scaled(n=9, N=1024, blk_d=3)],

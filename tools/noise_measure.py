@@ -23,9 +23,9 @@ def phase_err(p, keys, ct, bits):
     return ph - np.where(bits, 0.125, -0.125)
 
 
-def measure(p, B):
+def measure(p, B, arith=0):
     crs, keys = keygen(p, 12)
-    sg = gpu_scheme(p, crs, keys)
+    sg = mk.setup(p, keys=keys, a=crs, arith=arith) if p.multikey else mk.setup(p, keys=keys[0], arith=arith)[1]
     k = p.nparty
     rng = np.random.default_rng(13)
     bits = rng.integers(0, 2, 2 * B * k).astype(bool)
@@ -50,6 +50,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("names", nargs="+")
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--variants", action="store_true")
+ap.add_argument("--arith", default="f64ref", choices=["f64ref", "exact"])
 args = ap.parse_args()
 for name in args.names:
     p0 = eval(name, {"mk": mk}) if "." in name or "(" in name else getattr(mk, name)
@@ -59,6 +60,6 @@ for name in args.names:
     for vn, kw in variants:
         p = p0.scaled(**kw) if kw else p0
         B = args.batch if p.nparty * p.N <= 8192 else max(64, args.batch // 4)
-        r = measure(p, B)
-        r.update(set=name, variant=vn)
+        r = measure(p, B, mk.ARITH_EXACT if args.arith == "exact" else mk.ARITH_F64REF)
+        r.update(set=name, variant=vn, arith=args.arith)
         print(json.dumps(r), flush=True)
