@@ -240,11 +240,11 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         HIPCHK(c, mktd::launch_ccs_blindrotate(c->logM, p.W, q, B, c->stream));
         return MKT_OK;
     }
-    if (c->exact && p.scheme == MKT_KMS) {   // 64-bit ring, split tables: phase 1 and phase 2 with exact products (ntt_exact.hip)
+    if (c->exact && mkt::is_kms(p.scheme)) {   // 64-bit ring, split tables: phase 1 and phase 2 with exact products (ntt_exact.hip)
         mktd::ExactKmsArgs q{};
         q.brk = reinterpret_cast<const uint64_t *>(c->ks->d_brk); q.brk_party_stride = c->ks->brk_party_cplx * 2 /* in 8-byte residue pairs */; q.mono = reinterpret_cast<const uint64_t *>(c->ks->d_monomial);
         q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.k = p.k; q.l_gsw = p.l_gsw; q.logB_gsw = p.logB_gsw;
-        q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni; q.rtot = c->ks->rtot; q.lwe_len = c->sh.lwe_len;
+        q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni; q.rtot = c->ks->rtot; q.lwe_len = c->sh.lwe_len; q.blk_len = p.scheme == MKT_KMS_BLOCK ? p.blk_len : 1;
         q.slot_party = c->ks->d_slot_party; q.slot_row = c->ks->d_slot_row; q.levkey = reinterpret_cast<uint64_t *>(lev);
         q.rlk_d = reinterpret_cast<const uint64_t *>(c->ks->d_rlk_d); q.rlk_f = reinterpret_cast<const uint64_t *>(c->ks->d_rlk_f);
         q.pub_b = reinterpret_cast<const uint64_t *>(c->ks->d_pub); q.crs = reinterpret_cast<const uint64_t *>(c->ks->d_crs);
@@ -372,11 +372,12 @@ int upload_ntt_tables(mkt_ctx *c) {
 bool exact_gate_ok(const mkt_ctx *c) {
     const double half_P = 0.5 * (double)NTT_P[0] * (double)NTT_P[1];
     const mkt_params &p = c->p;
-    if (p.scheme == MKT_KMS && p.W == 64) {
+    if (mkt::is_kms(p.scheme) && p.W == 64) {
+        const double LBf = p.scheme == MKT_KMS_BLOCK ? (double)p.blk_len : 1.0;   // a block sums its key bits' products before the inverse
         // 64-bit ring: tables split into 32-bit halves, every accumulated product sum of one half must stay below P / 2:
         // phase 1 (twice the sum after the monomial X^a - 1), the LEV multiplication + relinearisation sums, the v sum over the parties
         const double n32 = (double)p.N * 4294967296.0;
-        const double ph1 = 2.0 * 2.0 * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n32;
+        const double ph1 = LBf * 2.0 * 2.0 * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n32;
         const double acc = (p.l_lev * std::ldexp(1.0, p.logB_lev - 1) + 2.0 * p.l_uni * std::ldexp(1.0, p.logB_uni - 1)) * n32;
         const double tv = (double)p.k * p.l_uni * std::ldexp(1.0, p.logB_uni - 1) * n32;
         return ph1 < half_P && acc < half_P && tv < half_P;
@@ -387,8 +388,8 @@ bool exact_gate_ok(const mkt_ctx *c) {
     const double bound = (lmss ? 2.0 * p.blk_len : 1.0) * 2.0 * p.l_gsw * (double)p.N * std::ldexp(1.0, p.logB_gsw - 1) * 4294967296.0;
     return bound < half_P;
 }
-#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1, 32-bit ring, block length 3) and for KMS (64-bit ring, gadgets within the two-prime modulus); other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
-#define MKT_F64_OR_EXACT_KMS(c) do { if ((c) && (c)->exact && !((c)->p.scheme == MKT_KMS && exact_gate_ok(c))) return fail((c), MKT_ERR_UNSUPPORTED, "on an MKT_ARITH_EXACT context this entry point serves the KMS gate path only"); } while (0)
+#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1, 32-bit ring, block length 3) and for KMS / KMS_block (64-bit ring, gadgets within the two-prime modulus); other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
+#define MKT_F64_OR_EXACT_KMS(c) do { if ((c) && (c)->exact && !(mkt::is_kms((c)->p.scheme) && exact_gate_ok(c))) return fail((c), MKT_ERR_UNSUPPORTED, "on an MKT_ARITH_EXACT context this entry point serves the KMS gate path only"); } while (0)
 #define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; not offered by an MKT_ARITH_EXACT context"); } while (0)
 
 }  // namespace
@@ -779,7 +780,7 @@ int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, siz
         mktd::ExactKmsArgs q{};
         q.brk = reinterpret_cast<const uint64_t *>(c->ks->d_brk); q.brk_party_stride = c->ks->brk_party_cplx * 2 /* in 8-byte residue pairs */; q.mono = reinterpret_cast<const uint64_t *>(c->ks->d_monomial);
         q.lwe = (const uint32_t *)sa.dev; q.lwe_stride = (int)alen; q.pre_switched = 1; q.n = p.n; q.k = p.k; q.l_gsw = p.l_gsw; q.logB_gsw = p.logB_gsw;
-        q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni; q.rtot = c->ks->rtot; q.lwe_len = c->sh.lwe_len;
+        q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni; q.rtot = c->ks->rtot; q.lwe_len = c->sh.lwe_len; q.blk_len = p.scheme == MKT_KMS_BLOCK ? p.blk_len : 1;
         q.slot_party = c->ks->d_slot_party; q.slot_row = c->ks->d_slot_row; q.levkey = (uint64_t *)sl.dev; q.phase1_only = 1;
         { Timer tm(c, 1); HIPCHK(c, mktd::launch_exact_kms(c->logN, c->d_ntt, q, B, c->stream)); }
         return sl.out(levkey);

@@ -140,6 +140,7 @@ struct ExactKmsArgs {
     const uint64_t *mono;                           // [2N][N] (not split)
     const uint32_t *lwe; int lwe_stride, pre_switched;
     int n, k, l_gsw, logB_gsw, l_lev, logB_lev, l_uni, logB_uni, rtot, lwe_len;
+    int blk_len;                                    // KMS_block: key bits per block (1 for KMS)
     const int *slot_party, *slot_row;
     uint64_t *levkey;                               // [B][rtot][2][2][N]
     const uint64_t *rlk_d, *rlk_f, *pub_b, *crs;    // split tables

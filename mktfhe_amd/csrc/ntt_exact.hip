@@ -403,10 +403,10 @@ __device__ __forceinline__ void lift_pair(Pt (&lo)[8], Pt (&hi)[8], uint64_t (&w
 
 // KMS phase 1 (bootstrapping.jl:389-443) with exact products: one workgroup per RLEV row rotation, accumulator (b, a) in
 // registers (slot e = coefficient e*NT + t); output: the row's two polynomials as split residue tables for phase 2
-template <int LOGN>
-__global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase1_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
+template <int LOGN, bool BLK>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(2, 2))) void exact_kms_phase1_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
                                                                               const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe, int lwe_stride,
-                                                                              int pre_switched, int n, int l, int logB, size_t ngates, int rows_per_gate,
+                                                                              int pre_switched, int n, int l, int logB, int blk_len, size_t ngates, int rows_per_gate,
                                                                               const int *__restrict__ slot_party, const int *__restrict__ slot_row, int logB_lev,
                                                                               uint64_t *__restrict__ lev_out) {
     constexpr int N = 1 << LOGN, NT = N >> NLR;
@@ -429,46 +429,73 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase1_kernel(c
         for (int e = 0; e < 8; e++) acc[c][e] = 0;
     if (t == 0) acc[0][0] = (uint64_t)1 << (64 - (row + 1) * logB_lev);           // :403-406 trivial RLEV row
     const int msbit = 32 - LOGN - 1;
-    for (int i = 0; i < n; i++) {
-        const uint32_t v0 = at_src[i];
-        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
-        if (at == 0) continue;                                                     // :413
-        Pt tacc[2][2][8];                                                          // [output polynomial][half]
-#pragma unroll
-        for (int pp = 0; pp < 2; pp++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int e = 0; e < 8; e++) { tacc[pp][h][e].a = 0; tacc[pp][h][e].b = 0; }
-        for (int c = 0; c < 2; c++) {
-            uint64_t tp[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) tp[e] = gd.prep(c ? acc[1][e] : acc[0][e]);   // :415-425 decompto!
-            for (int j = 0; j < l; j++) {
-                Pt z[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(tp[e], j));
-                ntt_forward<LOGN>(z, tw[0], lds, t);
-                const uint64_t *rowp = brk + (((size_t)i * 2 * l + (size_t)(c * l + j)) * 4) * N + 8 * t;   // [poly][half][N]
-#pragma unroll
-                for (int pp = 0; pp < 2; pp++)
-#pragma unroll
-                    for (int h = 0; h < 2; h++)
-#pragma unroll
-                        for (int e = 0; e < 8; e++) tacc[pp][h][e] = pt_add(tacc[pp][h][e], pt_mont(z[e], unpack(rowp[(size_t)(pp * 2 + h) * N + e])));   // :427-432, exactly
-            }
+    // blk_len = 1: bootstrapping.jl:411-438; > 1 (KMS_block, :623-655): one decomposition per block of key bits, every key bit's
+    // product times its monomial summed in the transform domain (:648), one inverse per block.  The digit transforms are
+    // recomputed per key bit (same values) instead of being held for the block: registers, not arithmetic, are short here.
+    for (int blk = 0; blk < n / blk_len; blk++) {
+        bool any = false;
+        for (int q = 0; q < blk_len; q++) {
+            const uint32_t v0 = at_src[blk * blk_len + q];
+            any |= (pre_switched ? v0 : divbits<uint32_t>(v0, msbit)) != 0;
         }
-        const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
+        if (!__builtin_amdgcn_readfirstlane((int)any)) continue;                   // :413 / :638
+        uint64_t tp[2][8];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) tp[c][e] = gd.prep(acc[c][e]);              // :415-425 / :625-633 decompto!
+        Pt sum[2][2][8];                                                           // [output polynomial][half]; BLK only (one key bit: the product itself)
+        if (BLK) {
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { sum[pp][h][e].a = 0; sum[pp][h][e].b = 0; }
+        }
+        for (int q = 0; q < (BLK ? blk_len : 1); q++) {
+            const int i = blk * blk_len + q;
+            const uint32_t v0 = at_src[i];
+            const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+            if (at == 0) continue;
+            Pt tacc[2][2][8];
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { tacc[pp][h][e].a = 0; tacc[pp][h][e].b = 0; }
+            for (int c = 0; c < 2; c++)
+                for (int j = 0; j < l; j++) {
+                    Pt z[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(c ? tp[1][e] : tp[0][e], j));
+                    ntt_forward<LOGN>(z, tw[0], lds, t);
+                    const uint64_t *rowp = brk + (((size_t)i * 2 * l + (size_t)(c * l + j)) * 4) * N + 8 * t;   // [poly][half][N]
+#pragma unroll
+                    for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+#pragma unroll
+                            for (int e = 0; e < 8; e++) tacc[pp][h][e] = pt_add(tacc[pp][h][e], pt_mont(z[e], unpack(rowp[(size_t)(pp * 2 + h) * N + e])));   // :427-432 / :639-646, exactly
+                }
+            const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {                                  // :435 / :648
+                        const Pt pr = pt_mont(tacc[pp][h][e], unpack(mrow[e]));
+                        sum[pp][h][e] = BLK ? pt_add(sum[pp][h][e], pr) : pr;
+                    }
+        }
 #pragma unroll
         for (int pp = 0; pp < 2; pp++) {
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int e = 0; e < 8; e++) tacc[pp][h][e] = pt_mont(tacc[pp][h][e], unpack(mrow[e]));   // :435
             uint64_t w[8];
-            lift_pair<LOGN>(tacc[pp][0], tacc[pp][1], w, tw[1], k, lds, t);        // :436
+            lift_pair<LOGN>(sum[pp][0], sum[pp][1], w, tw[1], k, lds, t);          // :436 / :653
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[pp][e] += w[e];                        // :437
+            for (int e = 0; e < 8; e++) acc[pp][e] += w[e];                        // :437 / :654
         }
     }
     // :441 fftto!(tacc, acc): the row as split residue tables, Montgomery form
@@ -718,9 +745,16 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
     MKT_NTT_DISPATCH(logN, {
         const size_t lds = lds_bytes<LN>(2);
-        hipError_t e = ntt_set_lds(exact_kms_phase1_kernel<LN>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((exact_kms_phase1_kernel<LN>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
-                           a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+        hipError_t e = hipSuccess;
+        if (a.blk_len > 1) {
+            e = ntt_set_lds(exact_kms_phase1_kernel<LN, true>, lds); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, true>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
+                               a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, a.blk_len, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+        } else {
+            e = ntt_set_lds(exact_kms_phase1_kernel<LN, false>, lds); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, false>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
+                               a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, 1, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+        }
         if (a.phase1_only) return hipGetLastError();
         ExactPhase2Args q;
         q.lin = a.lin_for_tv; q.lwe_stride = a.lwe_len; q.k = a.k; q.l_lev = a.l_lev; q.logB_lev = a.logB_lev; q.l_uni = a.l_uni; q.logB_uni = a.logB_uni; q.rtot = a.rtot;

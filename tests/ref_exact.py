@@ -75,19 +75,24 @@ def kms_phase1(p, brk, at_party, party):
     for r in range(1 if party == 0 else p.l_lev):
         acc = np.zeros((2, N), dtype=np.uint64)
         acc[0, 0] = np.uint64(1) << np.uint64(W - (r + 1) * p.logB_lev)             # :403-406
-        for i in range(p.n):
-            a = int(at_party[i])
-            if a == 0:
-                continue                                                       # :413
+        L = p.blk_len if p.blk_len > 1 else 1                                  # KMS_block (:599-659): one decomposition per block
+        for blk in range(p.n // L):
+            ats = [int(at_party[blk * L + q]) for q in range(L)]
+            if not any(ats):
+                continue                                                       # :413 / :638
             dig = [O.decomp_poly(acc[c], l, p.logB_gsw, W) for c in range(2)]
-            new = acc.copy()
-            for pp in range(2):
-                t = np.zeros(N, dtype=np.uint64)
-                for c in range(2):
-                    for j in range(l):
-                        t = (t + O.negacyclic(dig[c][j], brk[i, c * l + j, pp], W)) & mask
-                new[pp] = (acc[pp] + monomial_minus_one(t, a, N, W)) & mask      # :435-437
-            acc = new
+            add = np.zeros((2, N), dtype=np.uint64)
+            for q, a in enumerate(ats):
+                if a == 0:
+                    continue
+                i = blk * L + q
+                for pp in range(2):
+                    t = np.zeros(N, dtype=np.uint64)
+                    for c in range(2):
+                        for j in range(l):
+                            t = (t + O.negacyclic(dig[c][j], brk[i, c * l + j, pp], W)) & mask
+                    add[pp] = (add[pp] + monomial_minus_one(t, a, N, W)) & mask      # :435 / :648
+            acc = (acc + add) & mask                                           # :437 / :654
         rows.append(acc)
     return rows
 

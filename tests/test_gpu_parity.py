@@ -950,7 +950,8 @@ def test_exact_mode_integer_ntt(require_gpu, N, W):
 
 
 @pytest.mark.parametrize("p", [mk.KMS2party.scaled(n=8, N=256), mk.KMS2party_N1024_l2.scaled(n=8), mk.KMS2party.scaled(n=6), mk.KMS4party.scaled(n=4, N=512),
-                               mk.KMS8party.scaled(n=3, N=256, k=3)], ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
+                               mk.KMS8party.scaled(n=3, N=256, k=3), mk.KMS2partyblock.scaled(n=12, N=256, blk_d=4), mk.KMS2partyblock.scaled(n=6, blk_d=2)],
+                         ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
 def test_exact_mode_kms_gates(require_gpu, p):
     """MKT_ARITH_EXACT on the 64-bit ring (KMS, bootstrapping.jl:369-594): every resident 64-bit table kept as the transforms
     of its low and high 32-bit halves, every product sum as a (low, high) accumulator pair with two inverse transforms.
