@@ -6,6 +6,9 @@ done
 python3 bench.py --steps 10 --warmup 2 --workload cggi_l2 --batch 1 --no-roofline --no-cpu-baseline > $O/bench_cggi_l2_b1.json 2>/dev/null
 python3 bench.py --steps 10 --warmup 2 --workload cggi --batch 1 --no-roofline --no-cpu-baseline > $O/bench_cggi_b1.json 2>/dev/null
 python3 bench.py --steps 10 --warmup 2 --workload kms2party --batch 1 --no-roofline --no-cpu-baseline > $O/bench_kms2party_b1.json 2>/dev/null
+python3 bench.py --steps 2 --warmup 1 --workload lmss --batch 16384 --no-roofline --no-cpu-baseline > $O/bench_lmss_16384.json 2>/dev/null
+python3 bench.py --steps 2 --warmup 1 --workload lmss_k2 --batch 16384 --no-roofline --no-cpu-baseline > $O/bench_lmss_k2_16384.json 2>/dev/null
+for w in kms2_n1024 kms2party kms2partyblock cggi; do python3 bench.py --steps 3 --warmup 1 --workload $w --arith exact --no-roofline --no-cpu-baseline --no-secondary > $O/bench_${w}_exact.json 2>/dev/null; done
 : > $O/batch_curve.txt
 for w in kms2_n1024 cggi; do for b in 1 16 64 256 512 1024 2048 4096 16384; do
   python3 bench.py --steps 3 --warmup 1 --workload $w --batch $b --no-roofline --no-cpu-baseline --no-secondary 2>/dev/null | python3 -c "
