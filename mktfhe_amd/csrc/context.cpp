@@ -229,6 +229,16 @@ mktd::RotArgs rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
 // blind rotation of `B` accumulators resident at `acc` ([B][1+k][N]); atilde source described by (lwe, stride, pre)
 int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const uint32_t *lin_for_tv, void *acc, cplx *lev, cplx *scratch, size_t B) {
     const mkt_params &p = c->p;
+    if (p.scheme == MKT_CCS && c->exact) {   // hybrid products over Z_P (ntt_exact.hip)
+        mktd::ExactCcsHostArgs q{};
+        q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.k = p.k; q.l = p.l_uni; q.logB = p.logB_uni;
+        q.brk = reinterpret_cast<const uint64_t *>(c->ks->d_brk); q.brk_party_stride = c->ks->brk_party_cplx * 2;
+        q.pub_b = reinterpret_cast<const uint64_t *>(c->ks->d_pub); q.crs = reinterpret_cast<const uint64_t *>(c->ks->d_crs);
+        q.mono = reinterpret_cast<const uint64_t *>(c->ks->d_monomial); q.acc = (uint32_t *)acc; q.scratch = reinterpret_cast<uint64_t *>(scratch);
+        Timer tm(c, 1);
+        HIPCHK(c, mktd::launch_exact_ccs(c->logN, c->d_ntt, q, B, c->stream));
+        return MKT_OK;
+    }
     if (p.scheme == MKT_CCS) {
         mktd::CcsArgs q{};
         q.tw = c->twp(); q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.logN = c->logN; q.k = p.k;
@@ -382,14 +392,16 @@ bool exact_gate_ok(const mkt_ctx *c) {
         const double tv = (double)p.k * p.l_uni * std::ldexp(1.0, p.logB_uni - 1) * n32;
         return ph1 < half_P && acc < half_P && tv < half_P;
     }
+    if (p.scheme == MKT_CCS && p.W == 32)    // tacc.b gathers u_0 and the w of all np + 1 polynomials, then the monomial doubles it
+        return 2.0 * (p.k + 2.0) * p.l_uni * (double)p.N * std::ldexp(1.0, p.logB_uni - 1) * 4294967296.0 < half_P;
     const bool lmss = p.scheme == MKT_LMSS;
     if (!((p.scheme == MKT_CGGI || lmss) && p.k == 1 && p.W == 32)) return false;
     if (lmss && p.blk_len != 3) return false;             // the block length the kernel is instantiated for (params.jl:8-13)
     const double bound = (lmss ? 2.0 * p.blk_len : 1.0) * 2.0 * p.l_gsw * (double)p.N * std::ldexp(1.0, p.logB_gsw - 1) * 4294967296.0;
     return bound < half_P;
 }
-#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1, 32-bit ring, block length 3) and for KMS / KMS_block (64-bit ring, gadgets within the two-prime modulus); other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
-#define MKT_F64_OR_EXACT_KMS(c) do { if ((c) && (c)->exact && !(mkt::is_kms((c)->p.scheme) && exact_gate_ok(c))) return fail((c), MKT_ERR_UNSUPPORTED, "on an MKT_ARITH_EXACT context this entry point serves the KMS gate path only"); } while (0)
+#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1, 32-bit ring, block length 3) for CCS (32-bit ring) and for KMS / KMS_block (64-bit ring, tables split in 32-bit halves), gadgets within the two-prime modulus; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
+#define MKT_F64_OR_EXACT_KMS(c) do { if ((c) && (c)->exact && !(mkt::is_mk((c)->p.scheme) && exact_gate_ok(c))) return fail((c), MKT_ERR_UNSUPPORTED, "on an MKT_ARITH_EXACT context this entry point serves the multi-key gate paths only"); } while (0)
 #define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; not offered by an MKT_ARITH_EXACT context"); } while (0)
 
 }  // namespace

@@ -149,6 +149,15 @@ struct ExactKmsArgs {
     int phase1_only;
 };
 hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a, size_t B, hipStream_t s);
+// CCS blind rotation with exact products (32-bit ring); tables as residue pairs, natural order, Montgomery form
+struct ExactCcsHostArgs {
+    const uint32_t *lwe; int lwe_stride, pre_switched;
+    int n, k, l, logB;
+    const uint64_t *brk; size_t brk_party_stride;   // 8-byte residue pairs
+    const uint64_t *pub_b, *crs, *mono;
+    uint32_t *acc; uint64_t *scratch;
+};
+hipError_t launch_exact_ccs(int logN, const uint64_t *tab, const ExactCcsHostArgs &a, size_t B, hipStream_t s);
 hipError_t launch_exact_polymul(int logN, int W, const uint64_t *tab, const void *a, const void *b, void *out, size_t B, hipStream_t s);
 
 }  // namespace mktd

@@ -651,6 +651,111 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// CCS blind rotation with exact products (bootstrapping.jl:234-328), 32-bit ring: one workgroup per ciphertext, the same step
+// sequence as ccs_blindrotate_kernel -- per input polynomial q: decompose, l forward transforms, u = sum dig_j d[j],
+// v = -/+ sum dig_j (crs | b_{q-1})[j], inverse of v, decompose v, l forward transforms, w into tacc.b and tacc.a[idx]; then
+// every polynomial times the monomial, inverse, add.  All sums are integers mod P, so the order in which the reference's
+// Float64 sums must be formed plays no role here.  True coefficients stay below 2 (np + 2) l N 2^(logB-1) 2^32 < P / 2
+// (host check).  The accumulator lives in the caller's buffer, the u of the earlier parties' polynomials in a scratch area.
+// ------------------------------------------------------------------------------------------------
+struct ExactCcsArgs {
+    const uint32_t *lwe; int lwe_stride, pre_switched;
+    int n, k, l, logB;
+    const uint64_t *brk; size_t brk_party_stride;    // [party][n][3l][N]: d[l], then (f[j].b, f[j].a)
+    const uint64_t *pub_b, *crs, *mono;               // [party][l][N], [l][N], [2N][N]
+    uint32_t *acc;                                    // [B][1+k][N]
+    uint64_t *scratch;                                // [B][k+1][N] residue pairs
+};
+template <int LOGN>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(2, 2))) void exact_ccs_kernel(const uint4 *__restrict__ tab, const ExactCcsArgs a) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
+    const int t = threadIdx.x;
+    const uint4 *tw[2]; const int which[2] = {0, 1};
+    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + N), t, NT, tw, which);
+    const NttConsts kc = tab_consts<LOGN>(tab);
+    const size_t g = blockIdx.x;
+    const int k = a.k, l = a.l, n = a.n;
+    uint32_t *acc = a.acc + g * (size_t)(k + 1) * N;
+    uint64_t *sc = a.scratch + g * (size_t)(k + 1) * N;
+    const Gadget<uint32_t> gd(l, a.logB);
+    const int msbit = 32 - LOGN - 1;
+    auto zero = [](Pt (&x)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { x[e].a = 0; x[e].b = 0; }
+    };
+    for (int idx = 0; idx < k; idx++) {
+        const int np = idx + 1;
+        const uint32_t *at_src = a.lwe + g * (size_t)a.lwe_stride + (size_t)idx * n;
+        for (int i = 0; i < n; i++) {
+            const uint32_t v0 = at_src[i];
+            const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+            if (at == 0) continue;                                                 // :261
+            const uint64_t *uni = a.brk + (size_t)idx * a.brk_party_stride + (size_t)i * 3 * l * N;
+            const uint64_t *ud = uni, *uf = uni + (size_t)l * N;
+            Pt tb[8], ta[8];
+            zero(tb); zero(ta);
+            for (int q = 0; q <= np; q++) {
+                uint32_t tp[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) tp[e] = gd.prep(acc[(size_t)q * N + e * NT + t]);   // :264-275
+                Pt tu[8], tv[8];
+                zero(tu); zero(tv);
+                const uint64_t *vk = q == 0 ? a.crs : a.pub_b + (size_t)(q - 1) * l * N;
+                for (int j = 0; j < l; j++) {                                      // :279-294 u and v
+                    Pt z[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(tp[e], j));
+                    ntt_forward<LOGN>(z, tw[0], lds, t);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        tu[e] = pt_add(tu[e], pt_mont(z[e], unpack(ud[(size_t)j * N + 8 * t + e])));
+                        const Pt pr = pt_mont(z[e], unpack(vk[(size_t)j * N + 8 * t + e]));
+                        tv[e] = q == 0 ? pt_sub(tv[e], pr) : pt_add(tv[e], pr);     // mulsubto! with crs, muladdto! with b_i
+                    }
+                }
+                if (q == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) tb[e] = pt_add(tb[e], tu[e]);
+                } else if (q == np) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) ta[e] = pt_add(ta[e], tu[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) sc[(size_t)q * N + 8 * t + e] = pack(tu[e]);
+                }
+                ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(tv, tw[1], lds, t);   // :297-300
+#pragma unroll
+                for (int e = 0; e < 8; e++) tp[e] = gd.prep((uint32_t)crt_signed(pt_shoup(tv[e], kc.ninv)));   // :303-310
+                for (int j = 0; j < l; j++) {                                      // :313-320 w
+                    Pt z[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(tp[e], j));
+                    ntt_forward<LOGN>(z, tw[0], lds, t);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        tb[e] = pt_add(tb[e], pt_mont(z[e], unpack(uf[(size_t)(2 * j) * N + 8 * t + e])));
+                        ta[e] = pt_add(ta[e], pt_mont(z[e], unpack(uf[(size_t)(2 * j + 1) * N + 8 * t + e])));
+                    }
+                }
+            }
+            const uint64_t *mrow = a.mono + (size_t)(at - 1) * N + 8 * t;
+            for (int q = 0; q <= np; q++) {                                        // :322-324 mul!(monomial, tacc); ifftto!; add!
+                Pt s[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const Pt x = q == 0 ? tb[e] : (q == np ? ta[e] : unpack(sc[(size_t)q * N + 8 * t + e]));
+                    s[e] = pt_mont(x, unpack(mrow[e]));
+                }
+                ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s, tw[1], lds, t);
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[(size_t)q * N + e * NT + t] += (uint32_t)crt_signed(pt_shoup(s[e], kc.ninv));
+            }
+        }
+    }
+}
+
 template <typename K>
 static hipError_t ntt_set_lds(K kern, size_t bytes) {
     if (bytes > 48 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -761,6 +866,20 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
         q.levkey = a.levkey; q.rlk_d = a.rlk_d; q.rlk_f = a.rlk_f; q.pub_b = a.pub_b; q.crs = a.crs; q.acc = a.acc; q.scratch = a.scratch;
         e = ntt_set_lds(exact_kms_phase2_kernel<LN>, lds); if (e != hipSuccess) return e;
         hipLaunchKernelGGL((exact_kms_phase2_kernel<LN>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, q);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_exact_ccs(int logN, const uint64_t *tab, const ExactCcsHostArgs &h, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
+    ExactCcsArgs a;
+    a.lwe = h.lwe; a.lwe_stride = h.lwe_stride; a.pre_switched = h.pre_switched; a.n = h.n; a.k = h.k; a.l = h.l; a.logB = h.logB;
+    a.brk = h.brk; a.brk_party_stride = h.brk_party_stride; a.pub_b = h.pub_b; a.crs = h.crs; a.mono = h.mono; a.acc = h.acc; a.scratch = h.scratch;
+    MKT_NTT_DISPATCH(logN, {
+        const size_t lds = lds_bytes<LN>(2);
+        hipError_t e = ntt_set_lds(exact_ccs_kernel<LN>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((exact_ccs_kernel<LN>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, a);
     });
     return hipGetLastError();
 }

@@ -146,6 +146,47 @@ def kms_gate(p, so, keys, crs, op, x, y):
     return so.keyswitch(kms_blindrotate(p, keys, crs, at, so.testvector(bt)))
 
 
+def ccs_blindrotate(p, keys, crs, atilde, acc):
+    """bootstrapping.jl:234-328 with exact products (32-bit ring): UniEnc brk [n][3l][N] = d[l], then (f[j].b, f[j].a)"""
+    N, W, k, l, n = p.N, p.W, p.k, p.l_uni, p.n
+    mask = np.uint64((1 << W) - 1)
+    mul = lambda d, t: O.negacyclic(d, t, W)
+    acc = [np.asarray(a, dtype=np.uint64).copy() for a in np.asarray(acc).reshape(k + 1, N)]
+    crs = np.asarray(crs).reshape(l, N).astype(np.uint64)
+    for idx in range(k):
+        npm = idx + 1
+        uni_all = keys[idx].brk.reshape(n, 3 * l, N).astype(np.uint64)
+        for i in range(n):
+            a = int(atilde[idx * n + i])
+            if a == 0:
+                continue                                                       # :261
+            ud, uf = uni_all[i, :l], uni_all[i, l:].reshape(l, 2, N)
+            dig = [O.decomp_poly(acc[q], l, p.logB_uni, W) for q in range(npm + 1)]     # :264-275
+            tacc = [np.zeros(N, dtype=np.uint64) for _ in range(k + 1)]
+            for q in range(npm + 1):                                           # :279-284 u
+                for j in range(l):
+                    tacc[q] = (tacc[q] + mul(dig[q][j], ud[j])) & mask
+            for q in range(npm + 1):                                           # :287-300 v, :303-320 w
+                vk = crs if q == 0 else keys[q - 1].pubkey.reshape(l, N).astype(np.uint64)
+                v = np.zeros(N, dtype=np.uint64)
+                for j in range(l):
+                    pr = mul(dig[q][j], vk[j])
+                    v = (v - pr) & mask if q == 0 else (v + pr) & mask
+                vd = O.decomp_poly(v, l, p.logB_uni, W)
+                for j in range(l):
+                    tacc[0] = (tacc[0] + mul(vd[j], uf[j, 0])) & mask
+                    tacc[1 + idx] = (tacc[1 + idx] + mul(vd[j], uf[j, 1])) & mask
+            for q in range(npm + 1):                                           # :322-324
+                acc[q] = (acc[q] + monomial_minus_one(tacc[q], a, N, W)) & mask
+    return np.stack(acc)
+
+
+def ccs_gate(p, so, keys, crs, op, x, y):
+    lin = O.gate_linear(op, x, y)
+    at, bt = so.modswitch(lin)
+    return so.keyswitch(ccs_blindrotate(p, keys, crs, at, so.testvector(bt)))
+
+
 def gate(p, so, brk, op, x, y):
     lin = O.gate_linear(op, x, y)
     at, bt = so.modswitch(lin)

@@ -995,6 +995,43 @@ def test_exact_mode_kms_gates(require_gpu, p):
     sx.close()
 
 
+@pytest.mark.parametrize("p", [mk.CCS2party.scaled(n=8, N=256), mk.CCS2party.scaled(n=6), mk.CCS4party.scaled(n=4, N=512), mk.CCS8party.scaled(n=3, N=256, k=3),
+                               mk.CCS16party.scaled(n=2, N=256, k=4)], ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
+def test_exact_mode_ccs_gates(require_gpu, p):
+    """MKT_ARITH_EXACT for CCS (bootstrapping.jl:234-364, 32-bit ring): the hybrid products over Z_P.  Accumulators after the
+    blind rotation and gate outputs equal the exact-arithmetic restatement (tests/ref_exact.py ccs_*) word for word on inputs
+    that involve every party, and decrypt."""
+    import ref_exact as RX
+    crs, keys = keygen(p, 75)
+    so = oracle_scheme(p, crs, keys)
+    sx = mk.Scheme(p, arith=mk.ARITH_EXACT)
+    sx.load_crs(crs)
+    for i, kk in enumerate(keys):
+        sx.load_party(i, kk)
+    k, B = p.k, 3
+    bits = np.random.default_rng(76).integers(0, 2, 2 * B).astype(bool)
+
+    def allp(j):
+        ct = mk.lwe_ith_encrypt(int(bits[j]), 0, keys[0], p, deterministic_seed=9000 + 100 * j).astype(np.uint32)
+        for i in range(1, k):
+            for m in (0, 1):
+                ct = ct + mk.lwe_ith_encrypt(m, i, keys[i], p, deterministic_seed=9000 + 100 * j + 2 * i + m).astype(np.uint32)
+        return ct
+    x = np.stack([allp(j) for j in range(B)]); y = np.stack([allp(B + j) for j in range(B)])
+    lin = np.stack([O.gate_linear(0, x[j], y[j]) for j in range(B)])
+    at, bt = sx.modswitch(lin)
+    at[0, :2] = [0, 2 * p.N]
+    acc0 = np.stack([so.testvector(bt[j]) for j in range(B)])
+    acc_x = sx.blindrotate_(at, acc0.astype(np.uint32).copy())
+    for j in range(B):
+        assert np.array_equal(acc_x[j].astype(np.uint64), RX.ccs_blindrotate(p, keys, crs, at[j], acc0[j])), f"exact CCS blind rotation {j}"
+    for op in (0, 3):
+        out = sx.gate(op, x, y)
+        assert np.array_equal(out, np.stack([RX.ccs_gate(p, so, keys, crs, op, x[j], y[j]) for j in range(B)])), f"exact CCS gate {op}"
+        assert np.array_equal(mk.lwe_decrypt(out, keys, p), GATE_FUNCS[op](bits[:B], bits[B:]))
+    sx.close()
+
+
 @pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=12, N=256), mk.CGGIparam.scaled(n=10, N=1024), mk.CGGI_N1024_l2.scaled(n=10),
                                mk.CGGIparam.scaled(n=6, N=2048, l_gsw=4, logB_gsw=7),
                                mk.Blockparam.scaled(n=12, N=256, blk_d=4), mk.Blockparam.scaled(n=9, N=1024, blk_d=3)],
