@@ -62,10 +62,15 @@ enum {
                              (15 * 2^27 + 1)(63 * 2^25 + 1) = 2^61.88.
                              Transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch,
                              mkt_decompose_batch, mkt_modswitch_batch, mkt_not_batch) for every scheme; the gate path
-                             (mkt_load_brk/ksk, mkt_keygen_device, mkt_gate, mkt_bootstrap, mkt_blindrotate,
-                             mkt_keyswitch) for MKT_CGGI and MKT_LMSS (RLWE length 1, 32-bit ring), whose ciphertexts are valid but NOT the
-                             reference's words (no Float64 truncation); other schemes return MKT_ERR_UNSUPPORTED
-                             there */
+                             (mkt_load_*, mkt_keygen_device, mkt_gate, mkt_bootstrap, mkt_blindrotate, mkt_keyswitch) for
+                             MKT_CGGI / MKT_LMSS (RLWE length 1, 32-bit ring), MKT_CCS (32-bit ring) and MKT_KMS /
+                             MKT_KMS_BLOCK (64-bit ring: every 64-bit table kept as the transforms of its two 32-bit
+                             halves), provided the context's gadgets keep every product sum below P / 2 (checked at the
+                             first key upload: MKT_ERR_UNSUPPORTED otherwise).  The ciphertexts are valid -- on the
+                             64-bit ring 3-4x LESS noisy than the Float64 path, whose transform error dominates there --
+                             but NOT the reference's words (no Float64 rounding); keys in MKT_FMT_INT_COEFF only.
+                             On such a KMS context mkt_kms_phase1_batch returns the rows as split residue tables
+                             [B][rows][2 polynomials][low, high half][N] uint64 (Montgomery form)   */
 };
 /* where batch pointers live */
 enum { MKT_MEM_DEVICE = 0, MKT_MEM_HOST = 1 };
