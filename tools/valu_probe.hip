@@ -50,6 +50,10 @@ __global__ __launch_bounds__(1024) void probe(uint64_t *out, int iters, double s
         if constexpr (OP == 17) { REP8(asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:4096\n ds_read_b128 %2, %4 offset:8192\n ds_read_b128 %3, %4 offset:12288\n s_waitcnt lgkmcnt(0)" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3) : "v"(laddr) : "memory");) }
         if constexpr (OP == 18) { REP8(asm volatile("ds_write_b128 %4, %0\n ds_write_b128 %4, %1 offset:4096\n ds_write_b128 %4, %2 offset:8192\n ds_write_b128 %4, %3 offset:12288\n s_waitcnt lgkmcnt(0)" :: "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(laddr) : "memory");) }
         if constexpr (OP == 19) { REP8(asm volatile("v_cvt_f64_u32 %0, %8\n v_cvt_f64_u32 %1, %9\n v_cvt_f64_u32 %2, %10\n v_cvt_f64_u32 %3, %11\n v_cvt_f64_u32 %4, %8\n v_cvt_f64_u32 %5, %9\n v_cvt_f64_u32 %6, %10\n v_cvt_f64_u32 %7, %11" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
+        if constexpr (OP == 23) { REP8(asm volatile("ds_swizzle_b32 %0, %0 offset:0x101F\n ds_swizzle_b32 %1, %1 offset:0x101F\n ds_swizzle_b32 %2, %2 offset:0x201F\n ds_swizzle_b32 %3, %3 offset:0x201F\n ds_swizzle_b32 %4, %4 offset:0x101F\n ds_swizzle_b32 %5, %5 offset:0x201F\n ds_swizzle_b32 %6, %6 offset:0x101F\n ds_swizzle_b32 %7, %7 offset:0x201F\n s_waitcnt lgkmcnt(0)" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) :: "memory");) }
+        if constexpr (OP == 24) { REP8(asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(laddr) : "memory");) }
+        // 8 exchanges issued to the LDS crossbar, 8 independent f64 adds behind them, then the wait: do the two overlap?
+        if constexpr (OP == 25) { REP8(asm volatile("ds_swizzle_b32 %4, %4 offset:0x101F\n ds_swizzle_b32 %5, %5 offset:0x201F\n ds_swizzle_b32 %6, %6 offset:0x101F\n ds_swizzle_b32 %7, %7 offset:0x201F\n v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(c) : "memory");) }
         if constexpr (OP == 20) { REP8(asm volatile("v_add_f64 %0, %0, %8\n v_mov_b32_dpp %4, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f64 %1, %1, %8\n v_mov_b32_dpp %5, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f64 %2, %2, %8\n v_mov_b32_dpp %6, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f64 %3, %3, %8\n v_mov_b32_dpp %7, %10 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(c), "v"(d), "v"(m));) }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
@@ -61,8 +65,9 @@ __global__ __launch_bounds__(1024) void probe(uint64_t *out, int iters, double s
 
 static const char *NAMES[] = {"v_add_f64", "v_mul_f64", "v_fma_f64", "v_cvt_f64_i32", "v_cvt_u32_f64", "v_floor_f64", "v_trunc_f64", "v_ldexp_f64",
                               "v_mov_b32_dpp", "v_permlane16/32_swap_b32", "v_cndmask_b32", "v_mov_b32", "v_mad_u64_u32", "v_mul_hi_u32", "v_mul_lo_u32",
-                              "v_lshl_add_u64", "v_add_u32", "ds_read_b128 (x4 then wait)", "ds_write_b128 (x4 then wait)", "v_cvt_f64_u32", "v_add_f64 + v_mov_dpp pairs (per pair)", "v_cndmask_b32_e64 sgpr mask", "v_cndmask_b32 vcc, fresh dst"};
-static const int PER_ITER[] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64, 32, 64, 64};
+                              "v_lshl_add_u64", "v_add_u32", "ds_read_b128 (x4 then wait)", "ds_write_b128 (x4 then wait)", "v_cvt_f64_u32", "v_add_f64 + v_mov_dpp pairs (per pair)", "v_cndmask_b32_e64 sgpr mask", "v_cndmask_b32 vcc, fresh dst",
+                              "ds_swizzle_b32 (x8 then wait)", "ds_bpermute_b32 (x8 then wait)", "4 ds_swizzle + 4 v_add_f64 then wait (per 8)"};
+static const int PER_ITER[] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64, 32, 64, 64, 64, 64, 64};
 
 template <int OP>
 void run(uint64_t *d_out, int waves) {
@@ -92,7 +97,7 @@ int main() {
     uint64_t *d;
     hipMalloc(&d, ((1 << 20) + 8) * 8);
     four<0>(d); both<1>(d); both<2>(d); both<3>(d); both<19>(d); both<4>(d); both<5>(d); both<6>(d); both<7>(d); four<8>(d); both<9>(d); four<10>(d); both<21>(d); both<22>(d); both<11>(d);
-    both<20>(d); both<12>(d); both<13>(d); both<14>(d); both<15>(d); both<16>(d); both<17>(d); both<18>(d);
+    both<20>(d); both<12>(d); both<13>(d); both<14>(d); both<15>(d); both<16>(d); both<17>(d); both<18>(d); both<23>(d); both<24>(d); both<25>(d);
     hipFree(d);
     return 0;
 }
