@@ -182,7 +182,7 @@ int ensure_workspace(mkt_ctx *c, size_t gates) {
         HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * (size_t)c->ks->rtot * 2 * c->M * sizeof(cplx) * c->split));
         HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)2 * (p.k + 1) * c->M * sizeof(cplx) * c->split));
     } else if (p.scheme == MKT_CCS) {
-        HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * poly_bytes(c)));    // v scratch (ring words)
+        HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * 3 * poly_bytes(c)));    // v scratch (ring words): parked v + two hand-off slots
         HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)(p.k + 1) * c->M * sizeof(cplx)));
     }
     c->ws_gates = gates;
@@ -246,7 +246,18 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         q.monomial = c->ks->d_monomial; q.acc = acc; q.scratch = scratch; q.vscratch = lev;
         q.stagger = 0; q.dev_order = c->dev_order;
         if (const char *v = getenv("MKT_CCS_STAGGER")) q.stagger = atoi(v);
+        // batches that leave compute units idle run each ciphertext on two thread groups (ccs_pipe.hip); MKT_CCS_PIPE: 0 never,
+        // 1 always, unset: below one chip-fill of one-group workgroups (4 per CU at M = 512, 2 at M = 1024)
+        int pipe = -1;
+        if (const char *v = getenv("MKT_CCS_PIPE")) pipe = atoi(v);
+        const size_t fill = (size_t)256 * (c->logM <= 9 ? 4 : 2);
+        const bool use_pipe = pipe == 1 || (pipe < 0 && B * 2 <= fill);
         Timer tm(c, 1);
+        if (use_pipe) {
+            const hipError_t e = mktd::launch_ccs_pipe(c->logM, p.W, q, B, c->stream);
+            if (e == hipSuccess) return MKT_OK;
+            if (e != hipErrorInvalidValue) return hipfail(c, e, "launch_ccs_pipe");
+        }
         HIPCHK(c, mktd::launch_ccs_blindrotate(c->logM, p.W, q, B, c->stream));
         return MKT_OK;
     }

@@ -74,7 +74,7 @@ struct CcsArgs {
     const cplx *monomial;
     void *acc;                // [B][1+k][N] ring words, in place
     cplx *scratch;            // [B][k+1][M]
-    void *vscratch;           // [B][N] ring words
+    void *vscratch;           // [B][3][N] ring words (the two-group kernel uses all three, the one-group kernel the first)
     int stagger;              // start-up delay between the workgroups that share a compute unit, in units of 64 cycles (0 = off)
     int dev_order;            // device point order of the resident tables
 };
@@ -124,6 +124,7 @@ hipError_t launch_rot_blockg_u64(int logM, int G, const RotArgs &a, size_t nslot
 hipError_t launch_blindrotate_kr(int logM, int W, int kr, const RotArgs &a, size_t nrot, hipStream_t s);
 hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hipStream_t s);
 hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, hipStream_t s);
+hipError_t launch_ccs_pipe(int logM, int W, const CcsArgs &a, size_t B, hipStream_t s);   // one ciphertext on two thread groups (ccs_pipe.hip); vscratch [B][3][N]
 hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s);
 bool transform_supported(int logM);
 

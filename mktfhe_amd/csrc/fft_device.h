@@ -400,6 +400,19 @@ __device__ __forceinline__ void fft_inverse_barriers_pass() {
         fft_inverse_barriers_pass<LOGM, LOGR, NB, PASS - 1, MO>();
     }
 }
+template <int LOGM, int LOGR, int NB, int PASS, int MO>
+__device__ __forceinline__ void fft_forward_barriers_pass() {
+    using P = Plan<LOGM, LOGR, NB>;
+    if constexpr (PASS < P::NPASS - 1) {
+        exchange_barriers_only<LOGM, LOGR, NB, P::lo(PASS), P::lo(PASS + 1), MO>();
+        fft_forward_barriers_pass<LOGM, LOGR, NB, PASS + 1, MO>();
+    }
+}
+template <int LOGM, int LOGR, int NB, int MO = -1>
+__device__ __forceinline__ void fft_forward_barriers_only() {
+    if (Route<LOGM, LOGR, MO>::guard_fwd) __syncthreads();
+    fft_forward_barriers_pass<LOGM, LOGR, NB, 0, MO>();
+}
 template <int LOGM, int LOGR, int NB, int MO = -1>
 __device__ __forceinline__ void fft_inverse_barriers_only() {
     if (Route<LOGM, LOGR, MO>::guard_inv) __syncthreads();

@@ -224,6 +224,20 @@ def test_block_rotation_groupings_are_bit_identical(require_gpu, p, G, monkeypat
     _stage_check(p, B=5, seed=3)
 
 
+# CCS has two blind-rotation kernels: one thread group per ciphertext, and -- for batches that leave compute units idle -- two
+# thread groups per ciphertext as a two-stage pipeline over a step's input polynomials (ccs_pipe.hip: the ordered Float64 sums
+# into tacc.b / tacc.a[idx] stay one chain in one group).  MKT_CCS_PIPE forces either; every stage and gate must give the oracle's words.
+CCS_SETS = [mk.CCS2party.scaled(n=12, N=256), mk.CCS2party.scaled(n=8, N=1024), mk.CCS4party.scaled(n=6, N=512), mk.CCS8party.scaled(n=4, N=512),
+            mk.CCS8party.scaled(n=3, N=2048, k=3), mk.CCS16party.scaled(n=2, N=128, k=5)]
+
+
+@pytest.mark.parametrize("pipe", ["0", "1"])
+@pytest.mark.parametrize("p", CCS_SETS, ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
+def test_ccs_rotation_kernels_are_bit_identical(require_gpu, p, pipe, monkeypatch):
+    monkeypatch.setenv("MKT_CCS_PIPE", pipe)
+    _stage_check(p, B=5, seed=4)
+
+
 FULL = [mk.CGGIparam, mk.CGGI_N1024_l2, mk.Blockparam, mk.Blockparam_k2, mk.KMS2party, mk.KMS2partyblock, mk.KMS2party_N1024_l2, mk.CCS2party]
 
 
@@ -311,12 +325,14 @@ def test_errors(require_gpu):
         s.gate(0, x, x)
     with pytest.raises(ValueError):       # wrong length (reference: @assert)
         s.gate(0, x[:, :-1], x[:, :-1])
-    pk = mk.KMS2party.scaled(n=8, N=256)          # EXACT evaluates CGGI gates only: other schemes say so instead of computing something else
-    ex = mk.Scheme(pk, arith=mk.ARITH_EXACT)
-    xk = np.zeros((2, pk.lwe_len), dtype=np.uint32)
-    with pytest.raises(mk.MktError, match="MKT_ARITH_EXACT evaluates gates for CGGI"):
-        ex.gate(0, xk, xk)
-    ex.close()
+    # EXACT: a gadget whose product sums would not fit the two-prime modulus (P / 2 = 2^60.9), or an RLWE length it has no kernel
+    # for, is refused instead of computing something else
+    for pk in (mk.KMS2party.scaled(n=8, N=2048, l_gsw=2, logB_gsw=20), mk.CGGIparam.scaled(n=8, N=256, k=2)):
+        ex = mk.Scheme(pk, arith=mk.ARITH_EXACT)
+        xk = np.zeros((2, pk.lwe_len), dtype=np.uint32)
+        with pytest.raises(mk.MktError, match="MKT_ARITH_EXACT evaluates gates for CGGI"):
+            ex.gate(0, xk, xk)
+        ex.close()
     s.close()
 
 
