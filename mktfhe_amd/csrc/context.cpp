@@ -357,7 +357,7 @@ struct Staged {
 bool mem_ok(int mem) { return mem == MKT_MEM_DEVICE || mem == MKT_MEM_HOST; }
 
 // ---- MKT_ARITH_EXACT: tables of the two-prime negacyclic NTT (ntt_exact.hip), computed on the host, uploaded once ----
-constexpr uint32_t NTT_P[2] = {2013265921u, 2113929217u};        // 15 * 2^27 + 1, 63 * 2^25 + 1
+constexpr uint32_t NTT_P[2] = {1073668097u, 1073692673u};        // 131063 * 2^13 + 1, 131066 * 2^13 + 1: the two largest NTT primes below 2^30 (ntt_exact.hip)
 uint32_t ntt_mulmod(uint32_t a, uint32_t b, uint32_t p) { return (uint32_t)((uint64_t)a * b % p); }
 uint32_t ntt_powmod(uint32_t a, uint64_t e, uint32_t p) { uint32_t r = 1; while (e) { if (e & 1) r = ntt_mulmod(r, a, p); a = ntt_mulmod(a, a, p); e >>= 1; } return r; }
 uint32_t ntt_shoup(uint32_t w, uint32_t p) { return (uint32_t)(((uint64_t)w << 32) / p); }
@@ -389,26 +389,28 @@ int upload_ntt_tables(mkt_ctx *c) {
     return MKT_OK;
 }
 // the gate path of an EXACT context: CGGI with RLWE length 1 on the 32-bit ring (every true product coefficient < p / 2)
-// (every true product coefficient below P / 2 = 2^60.88: 2l polynomials of N digits of magnitude <= 2^(logB-1) against 32-bit words)
+// (every true product coefficient below P / 2 = 2^58.9998: 2l polynomials of N digits of magnitude <= 2^(logB-1) against 32-bit words)
 bool exact_gate_ok(const mkt_ctx *c) {
     const double half_P = 0.5 * (double)NTT_P[0] * (double)NTT_P[1];
     const mkt_params &p = c->p;
+    // ring words and their 32-bit pieces enter as centered integers (magnitude <= 2^31: ntt_exact.hip res_word / piece_of)
+    const double n31 = (double)p.N * 2147483648.0;
     if (mkt::is_kms(p.scheme) && p.W == 64) {
-        const double LBf = p.scheme == MKT_KMS_BLOCK ? (double)p.blk_len : 1.0;   // a block sums its key bits' products before the inverse
         // 64-bit ring: tables split into 32-bit halves, every accumulated product sum of one half must stay below P / 2:
-        // phase 1 (twice the sum after the monomial X^a - 1), the LEV multiplication + relinearisation sums, the v sum over the parties
-        const double n32 = (double)p.N * 4294967296.0;
-        const double ph1 = LBf * 2.0 * 2.0 * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n32;
-        const double acc = (p.l_lev * std::ldexp(1.0, p.logB_lev - 1) + 2.0 * p.l_uni * std::ldexp(1.0, p.logB_uni - 1)) * n32;
-        const double tv = (double)p.k * p.l_uni * std::ldexp(1.0, p.logB_uni - 1) * n32;
+        // phase 1 (KMS: the sum of the 2l products, the monomial X^a - 1 is applied after the lift; KMS_block: a block sums
+        // its key bits' products times their monomials before the inverse), the LEV multiplication + relinearisation sums,
+        // the v sum over the parties
+        const double ph1 = (p.scheme == MKT_KMS_BLOCK ? 2.0 * p.blk_len : 1.0) * 2.0 * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n31;
+        const double acc = (p.l_lev * std::ldexp(1.0, p.logB_lev - 1) + 2.0 * p.l_uni * std::ldexp(1.0, p.logB_uni - 1)) * n31;
+        const double tv = (double)p.k * p.l_uni * std::ldexp(1.0, p.logB_uni - 1) * n31;
         return ph1 < half_P && acc < half_P && tv < half_P;
     }
     if (p.scheme == MKT_CCS && p.W == 32)    // tacc.b gathers u_0 and the w of all np + 1 polynomials, then the monomial doubles it
-        return 2.0 * (p.k + 2.0) * p.l_uni * (double)p.N * std::ldexp(1.0, p.logB_uni - 1) * 4294967296.0 < half_P;
+        return 2.0 * (p.k + 2.0) * p.l_uni * std::ldexp(1.0, p.logB_uni - 1) * n31 < half_P;
     const bool lmss = p.scheme == MKT_LMSS;
     if (!((p.scheme == MKT_CGGI || lmss) && p.k == 1 && p.W == 32)) return false;
     if (lmss && p.blk_len != 3) return false;             // the block length the kernel is instantiated for (params.jl:8-13)
-    const double bound = (lmss ? 2.0 * p.blk_len : 1.0) * 2.0 * p.l_gsw * (double)p.N * std::ldexp(1.0, p.logB_gsw - 1) * 4294967296.0;
+    const double bound = (lmss ? 2.0 * p.blk_len : 1.0) * 2.0 * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n31;
     return bound < half_P;
 }
 #define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1, 32-bit ring, block length 3) for CCS (32-bit ring) and for KMS / KMS_block (64-bit ring, tables split in 32-bit halves), gadgets within the two-prime modulus; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)

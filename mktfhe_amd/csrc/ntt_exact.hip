@@ -1,14 +1,20 @@
 // MKT_ARITH_EXACT: the negacyclic number-theoretic transform over Z_P[X]/(X^N + 1) in residue form, P = p1 * p2 with the
-// two 31-bit NTT primes p1 = 15 * 2^27 + 1 and p2 = 63 * 2^25 + 1 (P = 2^61.88), batched HBM -> HBM; the exact negacyclic
+// two largest NTT primes below 2^30, p1 = 131063 * 2^13 + 1 and p2 = 131066 * 2^13 + 1 (P = 2^59.9998), batched HBM -> HBM; the exact negacyclic
 // product of a gadget-digit polynomial with a ring polynomial mod 2^W built on it (the operation the reference's Float64
 // transform approximates: src/ring/fft.jl:57-81 + polynomial.jl:99-113; the MultiFloat option of README.md:9 aims at the
 // same exact value); and the CGGI blind rotation with exact products.
 //
-// Why two 31-bit primes and not one 64-bit prime: gfx950 multiplies 32 x 32 bits per lane and instruction
+// Why two 30-bit primes and not one 64-bit prime: gfx950 multiplies 32 x 32 bits per lane and instruction
 // (v_mul_lo_u32 / v_mul_hi_u32, 4.4 cycles per wave each); a product mod p = 2^64 - 2^32 + 1 costs ~33 instructions, a
-// Shoup product mod a 31-bit prime 6, so a butterfly over both residues is ~2.1x cheaper than the Goldilocks one
-// (tools/ntt_probe.hip) and the batched transform is bound by HBM, not by integer issue.  A point is the pair
-// (x mod p1, x mod p2) packed into 64 bits -- the same 8 N bytes per polynomial as M complex doubles.
+// Shoup product mod a 32-bit-word prime 4-6, so a butterfly over both residues is >2x cheaper than the Goldilocks one
+// (tools/ntt_probe.hip).  A point is the pair (x mod p1, x mod p2) packed into 64 bits -- the same 8 N bytes per
+// polynomial as M complex doubles.
+//
+// Why BELOW 2^30 (round 3; rounds 1-2 used 31-bit primes): the batched transforms are bound by integer issue, not by HBM
+// (software-prefetching the next polynomial moved nothing), and 4p < 2^32 admits Harvey's lazy butterflies -- values stay
+// in [0, 4p) through the forward stages and [0, 2p) through the inverse ones, corrections are single v_min_u32 -- 8 and 9
+// instructions per residue butterfly instead of 12.  The 1.9 bits of modulus this gives up are not needed by any
+// parameter set of the reference (exact_gate_ok, context.cpp: the largest bound is 2^52).
 //
 // Same butterfly network as the Float64 transform (fft_device.h), so the same pass / window / staging machinery: stage
 // with stride 2^b multiplies by psi_rev[m + i] (Cooley-Tukey, bit-reversed output), the inverse runs Gentleman-Sande
@@ -25,7 +31,8 @@ namespace mktd {
 
 namespace {
 
-constexpr uint32_t P1 = 2013265921u, P2 = 2113929217u;      // 15 * 2^27 + 1, 63 * 2^25 + 1: both = 1 mod 2^13
+constexpr uint32_t P1 = 1073668097u, P2 = 1073692673u;      // 131063 * 2^13 + 1 < 131066 * 2^13 + 1 < 2^30: both = 1 mod 2^13
+static_assert(P1 < P2 && P2 < (1u << 30), "lazy butterflies need 4 p < 2^32; crt_signed takes r.a < p2 as given");
 constexpr uint64_t PP = (uint64_t)P1 * P2;
 constexpr int NLR = 3;   // points per thread = 8
 
@@ -43,6 +50,7 @@ __device__ __forceinline__ uint64_t pack(Pt x) { return (uint64_t)x.a | ((uint64
 __device__ __forceinline__ Pt unpack(uint64_t v) { Pt x; x.a = (uint32_t)v; x.b = (uint32_t)(v >> 32); return x; }
 
 template <uint32_t P> __device__ __forceinline__ uint32_t red1(uint32_t v) { const uint32_t w = v - P; return w < v ? w : v; }   // v < 2P -> [0, P)
+template <uint32_t P> __device__ __forceinline__ uint32_t canon4(uint32_t v) { const uint32_t w = v - 2u * P; return red1<P>(w < v ? w : v); }   // v < 4P -> [0, P)
 template <uint32_t P> __device__ __forceinline__ uint32_t addm(uint32_t x, uint32_t y) { return red1<P>(x + y); }               // 2P < 2^32
 template <uint32_t P> __device__ __forceinline__ uint32_t subm(uint32_t x, uint32_t y) { const uint32_t d = x - y, e = d + P; return e < d ? e : d; }
 // x * w mod P for a constant w with companion ws = floor(w * 2^32 / P); any 32-bit x
@@ -50,7 +58,7 @@ template <uint32_t P> __device__ __forceinline__ uint32_t shoup(uint32_t x, uint
     const uint32_t q = __umulhi(x, ws);
     return red1<P>(x * w - q * P);
 }
-// Montgomery product x * y * 2^-32 mod P (x, y < P)
+// Montgomery product x * y * 2^-32 mod P (x < 4P: a lazy forward-transform value is fine; y < P), result in [0, P)
 template <uint32_t P, uint32_t PINV> __device__ __forceinline__ uint32_t montmul(uint32_t x, uint32_t y) {
     const uint32_t lo = x * y, hi = __umulhi(x, y);
     const uint32_t m = lo * PINV, u = __umulhi(m, P);
@@ -61,6 +69,21 @@ __device__ __forceinline__ Pt pt_add(Pt x, Pt y) { Pt r; r.a = addm<P1>(x.a, y.a
 __device__ __forceinline__ Pt pt_sub(Pt x, Pt y) { Pt r; r.a = subm<P1>(x.a, y.a); r.b = subm<P2>(x.b, y.b); return r; }
 __device__ __forceinline__ Pt pt_shoup(Pt x, uint4 w) { Pt r; r.a = shoup<P1>(x.a, w.x, w.y); r.b = shoup<P2>(x.b, w.z, w.w); return r; }
 __device__ __forceinline__ Pt pt_mont(Pt x, Pt y) { Pt r; r.a = montmul<P1, PI1>(x.a, y.a); r.b = montmul<P2, PI2>(x.b, y.b); return r; }
+__device__ __forceinline__ Pt pt_canon4(Pt x) { Pt r; r.a = canon4<P1>(x.a); r.b = canon4<P2>(x.b); return r; }
+// Lazy butterflies (D. Harvey, "Faster arithmetic for number-theoretic transforms", 2014), 4P < 2^32.
+// forward (Cooley-Tukey): x, y in [0, 4P) -> x + w y, x - w y in [0, 4P); FIRST: x < 2P already (a transform's first stage)
+template <uint32_t P> __device__ __forceinline__ void bfly_fwd(uint32_t &x, uint32_t &y, uint32_t w, uint32_t ws, bool FIRST) {   // FIRST folds after unrolling
+    uint32_t x1 = x;
+    if (!FIRST) { const uint32_t v = x - 2u * P; x1 = v < x ? v : x; }
+    const uint32_t tn = __umulhi(y, ws) * P - y * w;             // -(w y mod P) - {0, P}  (mod 2^32)
+    x = x1 - tn; y = x1 + 2u * P + tn;
+}
+// inverse (Gentleman-Sande): x, y in [0, 2P) -> x + y, w (x - y) in [0, 2P)
+template <uint32_t P> __device__ __forceinline__ void bfly_inv(uint32_t &x, uint32_t &y, uint32_t w, uint32_t ws) {
+    const uint32_t s = x + y, d = x - y + 2u * P, v = s - 2u * P;
+    x = v < s ? v : s;
+    y = d * w - __umulhi(d, ws) * P;
+}
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 
@@ -74,7 +97,9 @@ __device__ __forceinline__ void ntt_exchange(Pt (&z)[8], uint64_t *lds, int t, i
     for (int e = 0; e < 8; e++) z[e] = unpack(lds[lds_pos<NLR>(pt_index<NLR>(t, e, lo_to))]);
 }
 
-// In: slot e = point e*NT + t.  Out: slot e = point 8t + e (bit-reversed order of the transform, as the reference's).
+// In: slot e = point e*NT + t; slots 0..3 in [0, 2P), slots 4..7 any 32-bit value (fwd_in, res_small).  Out: slot e = point 8t + e (bit-reversed
+// order of the transform, as the reference's), values LAZY in [0, 4P): fine as the x of montmul and of shoup; pt_canon4
+// where the canonical residue is needed.
 // psi[k] = (w mod p1, its companion, w mod p2, its companion), w = psi^bitrev(k)
 template <int LOGN, int PASS = 0>
 __device__ __forceinline__ void ntt_forward(Pt (&z)[8], const uint4 *__restrict__ psi, uint64_t *lds, int t) {
@@ -90,8 +115,8 @@ __device__ __forceinline__ void ntt_forward(Pt (&z)[8], const uint4 *__restrict_
 #pragma unroll
             for (int q = 0; q < (1 << sb); q++) {
                 const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
-                const Pt u = pt_shoup(z[e2], w), a = z[e];
-                z[e] = pt_add(a, u); z[e2] = pt_sub(a, u);
+                bfly_fwd<P1>(z[e].a, z[e2].a, w.x, w.y, p == 0 && s == 0);
+                bfly_fwd<P2>(z[e].b, z[e2].b, w.z, w.w, p == 0 && s == 0);
             }
         }
     }
@@ -100,7 +125,8 @@ __device__ __forceinline__ void ntt_forward(Pt (&z)[8], const uint4 *__restrict_
         ntt_forward<LOGN, PASS + 1>(z, psi, lds, t);
     }
 }
-// In: slot e = point 8t + e.  Out: slot e = point e*NT + t, NOT yet scaled by N^-1
+// In: slot e = point 8t + e, values in [0, 2P).  Out: slot e = point e*NT + t, values in [0, 2P), NOT yet scaled by N^-1
+// (every caller follows with pt_shoup(., N^-1), which takes any 32-bit value to [0, P))
 template <int LOGN, int PASS>
 __device__ __forceinline__ void ntt_inverse(Pt (&z)[8], const uint4 *__restrict__ psiinv, uint64_t *lds, int t) {
     using P = Plan<LOGN, NLR>;
@@ -115,8 +141,8 @@ __device__ __forceinline__ void ntt_inverse(Pt (&z)[8], const uint4 *__restrict_
 #pragma unroll
             for (int q = 0; q < (1 << sb); q++) {
                 const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
-                const Pt a = z[e], u = z[e2];
-                z[e] = pt_add(a, u); z[e2] = pt_shoup(pt_sub(a, u), w);
+                bfly_inv<P1>(z[e].a, z[e2].a, w.x, w.y);
+                bfly_inv<P2>(z[e].b, z[e2].b, w.z, w.w);
             }
         }
     }
@@ -126,25 +152,42 @@ __device__ __forceinline__ void ntt_inverse(Pt (&z)[8], const uint4 *__restrict_
     }
 }
 
-// any 32-bit value -> [0, P)
-template <uint32_t P> __device__ __forceinline__ uint32_t red_u32(uint32_t v) { return red1<P>(red1<P>(v)); }   // v < 2^32 < 3P
-// signed 32-bit integer -> residue
-template <uint32_t P> __device__ __forceinline__ uint32_t res_s32(int32_t s) { return red1<P>(s < 0 ? (uint32_t)s + 2u * P : (uint32_t)s); }   // s + 2P in (0, 2P)
-__device__ __forceinline__ Pt res_small(int d) { Pt r; r.a = res_s32<P1>(d); r.b = res_s32<P2>(d); return r; }
-// signed W-bit ring word -> residues (64-bit words: hi * 2^32 + lo with hi signed)
-template <typename WORD> __device__ __forceinline__ Pt to_residue(WORD x);
-template <> __device__ __forceinline__ Pt to_residue<uint32_t>(uint32_t x) { return res_small((int32_t)x); }
-template <> __device__ __forceinline__ Pt to_residue<uint64_t>(uint64_t x) {
-    const int32_t hi = (int32_t)(x >> 32); const uint32_t lo = (uint32_t)x;
-    Pt r;
-    r.a = addm<P1>(shoup<P1>(res_s32<P1>(hi), R1, shoup_c(R1, P1)), red_u32<P1>(lo));
-    r.b = addm<P2>(shoup<P2>(res_s32<P2>(hi), R2, shoup_c(R2, P2)), red_u32<P2>(lo));
-    return r;
+// Inputs of ntt_forward.  Slot e < 4 is the x of a first-stage butterfly and must be below 2P; slot e >= 4 is its y, which the
+// Shoup product takes as ANY 32-bit value congruent to the point: conversions stop as early as the slot allows.
+// signed 32-bit integer (a ring word of the 32-bit ring, a centered piece of the 64-bit ring)
+template <uint32_t P> __device__ __forceinline__ uint32_t res_in(int32_t s, bool x_slot) {
+    uint32_t v = (uint32_t)s + ((uint32_t)(s >> 31) & (3u * P));               // [0, 3P): 2^31 < 3P < 2^32
+    if (x_slot) { const uint32_t w = v - 2u * P; v = w < v ? w : v; }
+    return v;
+}
+// signed 64-bit ring word hi * 2^32 + lo - [hi < 0] 2^64 (hi, lo unsigned)
+template <uint32_t P> __device__ __forceinline__ uint32_t res_in64(uint64_t x, bool x_slot) {
+    constexpr uint32_t R = (uint32_t)(((uint64_t)1 << 32) % P), RS = shoup_c(R, P), R64 = (uint32_t)((uint64_t)R * R % P);
+    static_assert(3u * ((1u << 30) - P) < P, "lo - (lo >> 30) P must land below 2P");
+    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+    const uint32_t a = hi * R - __umulhi(hi, RS) * P;                          // hi 2^32 mod P, lazy: [0, 2P)
+    const uint32_t b = lo - (lo >> 30) * P;                                    // [0, 2P)
+    uint32_t v = a + b, w = v - 2u * P;
+    v = w < v ? w : v;                                                         // [0, 2P)
+    v += (uint32_t)((int32_t)hi >> 31) & (P - R64);                            // [0, 3P)
+    if (x_slot) { w = v - 2u * P; v = w < v ? w : v; }
+    return v;
+}
+__device__ __forceinline__ Pt fwd_in(int32_t s, int e) { Pt r; r.a = res_in<P1>(s, e < 4); r.b = res_in<P2>(s, e < 4); return r; }
+__device__ __forceinline__ Pt fwd_in(uint32_t x, int e) { return fwd_in((int32_t)x, e); }
+__device__ __forceinline__ Pt fwd_in(uint64_t x, int e) { Pt r; r.a = res_in64<P1>(x, e < 4); r.b = res_in64<P2>(x, e < 4); return r; }
+// a gadget digit (|d| < P): d + P wraps past 2^32 exactly when d < 0
+template <uint32_t P> __device__ __forceinline__ uint32_t res_digit(int32_t d) { const uint32_t v = (uint32_t)d, w = v + P; return w < v ? w : v; }
+__device__ __forceinline__ Pt res_small(int d) { Pt r; r.a = res_digit<P1>(d); r.b = res_digit<P2>(d); return r; }
+// the 32-bit pieces of a 64-bit ring word, CENTERED: w = lo + 2^32 hi mod 2^64 with lo, hi in [-2^31, 2^31) -- half the
+// magnitude of unsigned pieces, i.e. one more bit of room under P / 2 for every product sum
+__device__ __forceinline__ int32_t piece_of(uint64_t w, int h) {
+    const int32_t lo = (int32_t)(uint32_t)w;
+    return h == 0 ? lo : (int32_t)(uint32_t)((w - (uint64_t)(int64_t)lo) >> 32);
 }
 // residues -> the integer of least magnitude they stand for (Garner), two's complement in 64 bits
 __device__ __forceinline__ uint64_t crt_signed(Pt r) {
-    const uint32_t a2 = red1<P2>(r.a);                           // r.a < p1 < 2 p2
-    const uint32_t tq = shoup<P2>(subm<P2>(r.b, a2), CRT_C, CRT_CS);
+    const uint32_t tq = shoup<P2>(subm<P2>(r.b, r.a), CRT_C, CRT_CS);   // r.a < p1 < p2
     const uint64_t x = (uint64_t)r.a + (uint64_t)P1 * tq;        // in [0, P)
     return x > (PP >> 1) ? x - PP : x;
 }
@@ -187,15 +230,32 @@ __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_fwd_kernel
     const uint4 *tw[1]; const int which[1] = {0};
     stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)PPW * N), threadIdx.x, PPW * NT, tw, which);
     const size_t groups = (B + PPW - 1) / PPW;
+    // software pipeline: the words of this workgroup's NEXT polynomial are in flight while one is transformed (the loads
+    // are HBM latency, ~2 us: resident waves alone do not cover it)
+    auto poly_of = [&](size_t g) { const size_t b0 = g * PPW + sub; return b0 < B ? b0 : B - 1; };   // a ragged last group repeats the last polynomial (same values, same address)
+    WORD nxt[8];
+    if (blockIdx.x < groups) {
+        const size_t b = poly_of(blockIdx.x);
+#pragma unroll
+        for (int e = 0; e < 8; e++) nxt[e] = __builtin_nontemporal_load(&p[b * N + e * NT + t]);
+    }
     for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
-        const size_t b0 = g * PPW + sub, b = b0 < B ? b0 : B - 1;       // a ragged last group repeats the last polynomial (same values, same address)
+        const size_t b = poly_of(g);
         Pt z[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) z[e] = to_residue<WORD>(__builtin_nontemporal_load(&p[b * N + e * NT + t]));
+        for (int e = 0; e < 8; e++) z[e] = fwd_in(nxt[e], e);
+        if (g + gridDim.x < groups) {
+            const size_t bn = poly_of(g + gridDim.x);
+#pragma unroll
+            for (int e = 0; e < 8; e++) nxt[e] = __builtin_nontemporal_load(&p[bn * N + e * NT + t]);
+        }
         ntt_forward<LOGN>(z, tw[0], lds, t);
         if (mont) {
 #pragma unroll
             for (int e = 0; e < 8; e++) { z[e].a = montmul<P1, PI1>(z[e].a, RR1); z[e].b = montmul<P2, PI2>(z[e].b, RR2); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) z[e] = pt_canon4(z[e]);
         }
         ntt_exchange<LOGN>(z, lds, t, 0, Plan<LOGN, NLR>::lo(0));        // thread-contiguous stores: point e*NT + t of the output order
 #pragma unroll
@@ -212,11 +272,23 @@ __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_inv_kernel
     stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)PPW * N), threadIdx.x, PPW * NT, tw, which);
     const NttConsts k = tab_consts<LOGN>(tab);
     const size_t groups = (B + PPW - 1) / PPW;
+    auto poly_of = [&](size_t g) { const size_t b0 = g * PPW + sub; return b0 < B ? b0 : B - 1; };
+    uint64_t nxt[8];                               // the next polynomial's points in flight (see ntt_fwd_kernel)
+    if (blockIdx.x < groups) {
+        const size_t b = poly_of(blockIdx.x);
+#pragma unroll
+        for (int e = 0; e < 8; e++) nxt[e] = __builtin_nontemporal_load(&in[b * N + e * NT + t]);
+    }
     for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
-        const size_t b0 = g * PPW + sub, b = b0 < B ? b0 : B - 1;
+        const size_t b = poly_of(g);
         Pt z[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) z[e] = unpack(__builtin_nontemporal_load(&in[b * N + e * NT + t]));
+        for (int e = 0; e < 8; e++) z[e] = unpack(nxt[e]);
+        if (g + gridDim.x < groups) {
+            const size_t bn = poly_of(g + gridDim.x);
+#pragma unroll
+            for (int e = 0; e < 8; e++) nxt[e] = __builtin_nontemporal_load(&in[bn * N + e * NT + t]);
+        }
         ntt_exchange<LOGN>(z, lds, t, Plan<LOGN, NLR>::lo(0), 0);
         ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(z, tw[0], lds, t);
 #pragma unroll
@@ -238,8 +310,10 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_polymul_kernel(cons
     for (size_t b = blockIdx.x; b < B; b += gridDim.x) {
         Pt za[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) za[e] = to_residue<WORD>(a[b * N + e * NT + t]);
+        for (int e = 0; e < 8; e++) za[e] = fwd_in(a[b * N + e * NT + t], e);
         ntt_forward<LOGN>(za, tw[0], lds, t);
+#pragma unroll
+        for (int e = 0; e < 8; e++) za[e] = pt_canon4(za[e]);                          // the y of montmul
         WORD acc[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[e] = 0;
@@ -249,8 +323,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_polymul_kernel(cons
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const uint64_t w = (uint64_t)bp[b * N + e * NT + t];
-                const uint32_t piece = (uint32_t)(W == 64 ? (w >> (32 * h)) : w);      // unsigned 32-bit pieces
-                zb[e].a = red_u32<P1>(piece); zb[e].b = red_u32<P2>(piece);
+                zb[e] = fwd_in(W == 64 ? piece_of(w, h) : (int32_t)(uint32_t)w, e);      // centered 32-bit pieces
             }
             ntt_forward<LOGN>(zb, tw[0], lds, t);
 #pragma unroll
@@ -360,10 +433,11 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // The 64-bit ring (KMS) with exact products.  A product  digit polynomial x 64-bit polynomial  exceeds P, so every resident
-// 64-bit table is kept as TWO residue polynomials -- the transforms of its low and of its high 32-bit halves (unsigned
-// pieces) -- every sum of such products as a (low, high) pair of transform-domain accumulators, and every inverse runs
-// twice:  sum_j d_j T_j = [sum_j d_j lo(T_j)] + 2^32 [sum_j d_j hi(T_j)]  mod 2^64,  each bracket an exact integer below
-// P / 2 (count * N * 2^(logB-1) * 2^32, twice that after the monomial; checked on the host for the context's gadgets).
+// 64-bit table is kept as TWO residue polynomials -- the transforms of its low and of its high 32-bit halves (centered
+// pieces in [-2^31, 2^31), piece_of) -- every sum of such products as a (low, high) pair of transform-domain accumulators,
+// and every inverse runs twice:  sum_j d_j T_j = [sum_j d_j lo(T_j)] + 2^32 [sum_j d_j hi(T_j)]  mod 2^64,  each bracket an
+// exact integer below P / 2 (count * N * 2^(logB-1) * 2^31, twice that where a monomial X^a - 1 multiplies in the transform
+// domain; checked on the host for the context's gadgets, exact_gate_ok).
 // Layout of a split table: logical polynomial i -> residue polynomials 2i (low half) and 2i + 1 (high half), natural
 // transform order, Montgomery form.  The monomial table (coefficients -2 .. 1) is not split.
 // ------------------------------------------------------------------------------------------------
@@ -383,7 +457,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void ntt_fwd_split_kernel(cons
         for (int h = 0; h < 2; h++) {
             Pt z[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) { const uint32_t piece = (uint32_t)(w[e] >> (32 * h)); z[e].a = red_u32<P1>(piece); z[e].b = red_u32<P2>(piece); }
+            for (int e = 0; e < 8; e++) z[e] = fwd_in(piece_of(w[e], h), e);
             ntt_forward<LOGN>(z, tw[0], lds, t);
 #pragma unroll
             for (int e = 0; e < 8; e++) out[(2 * b + h) * N + 8 * t + e] = pack(Pt{montmul<P1, PI1>(z[e].a, RR1), montmul<P2, PI2>(z[e].b, RR2)});
@@ -479,17 +553,36 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                             for (int e = 0; e < 8; e++) tacc[pp][h][e] = pt_add(tacc[pp][h][e], pt_mont(z[e], unpack(rowp[(size_t)(pp * 2 + h) * N + e])));   // :427-432 / :639-646, exactly
                 }
-            const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
+            if (BLK) {
+                const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
 #pragma unroll
-            for (int pp = 0; pp < 2; pp++)
+                for (int pp = 0; pp < 2; pp++)
 #pragma unroll
-                for (int h = 0; h < 2; h++)
+                    for (int h = 0; h < 2; h++)
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {                                  // :435 / :648
-                        const Pt pr = pt_mont(tacc[pp][h][e], unpack(mrow[e]));
-                        sum[pp][h][e] = BLK ? pt_add(sum[pp][h][e], pr) : pr;
+                        for (int e = 0; e < 8; e++) sum[pp][h][e] = pt_add(sum[pp][h][e], pt_mont(tacc[pp][h][e], unpack(mrow[e])));   // :648
+            } else {
+                // one key bit: lift the product sum S itself and apply X^at - 1 on the integers (a rotation through LDS) -- the
+                // same words mod 2^64, and the lifted sum is bounded by 2 l N 2^(logB-1) 2^31 instead of twice that: what lets
+                // the gadget l = 2, base 2^16 at N = 1024 (BASELINE configs[1]) fit two 30-bit primes
+#pragma unroll
+                for (int pp = 0; pp < 2; pp++) {
+                    uint64_t w[8];
+                    lift_pair<LOGN>(tacc[pp][0], tacc[pp][1], w, tw[1], k, lds, t);
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {                                  // :435-437: (X^at S)[i] = +-S[i - at mod N]
+                        const uint32_t src = (uint32_t)(e * NT + t - (int)at) & (2u * N - 1u);
+                        const uint64_t v = lds[src & (N - 1)];
+                        acc[pp][e] += (src >= (uint32_t)N ? (uint64_t)0 - v : v) - w[e];
                     }
+                }
+            }
         }
+        if (BLK)
 #pragma unroll
         for (int pp = 0; pp < 2; pp++) {
             uint64_t w[8];
@@ -505,7 +598,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
         for (int h = 0; h < 2; h++) {
             Pt z[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) { const uint32_t piece = (uint32_t)(acc[c][e] >> (32 * h)); z[e].a = red_u32<P1>(piece); z[e].b = red_u32<P2>(piece); }
+            for (int e = 0; e < 8; e++) z[e] = fwd_in(piece_of(acc[c][e], h), e);
             ntt_forward<LOGN>(z, tw[0], lds, t);
             uint64_t *o = lev_out + ((rot * 2 + c) * 2 + h) * (size_t)N + 8 * t;
 #pragma unroll

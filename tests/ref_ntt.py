@@ -1,9 +1,9 @@
 """Pure-Python restatement of the exact negacyclic transform of MKT_ARITH_EXACT (test infrastructure): the textbook
-Cooley-Tukey / Gentleman-Sande pair over Z_p[X]/(X^N + 1) for the two 31-bit primes p1 = 15 * 2^27 + 1 and
-p2 = 63 * 2^25 + 1 side by side, with the table psi_rev[k] = psi^bitrev(k) -- the integer twin of the reference's network
+Cooley-Tukey / Gentleman-Sande pair over Z_p[X]/(X^N + 1) for the two 30-bit primes p1 = 131063 * 2^13 + 1 and
+p2 = 131066 * 2^13 + 1 side by side, with the table psi_rev[k] = psi^bitrev(k) -- the integer twin of the reference's network
 (src/ring/fft.jl:105-209, Psi[m + i]).  A point is the pair (x mod p1, x mod p2) packed as x1 | x2 << 32; the integer a
 pair stands for is the one of least magnitude mod P = p1 p2 (Chinese remainder theorem)."""
-PRIMES = (15 * 2**27 + 1, 63 * 2**25 + 1)
+PRIMES = (131063 * 2**13 + 1, 131066 * 2**13 + 1)
 P = PRIMES[0] * PRIMES[1]
 
 

@@ -928,7 +928,7 @@ def test_largest_party_counts_at_full_size(require_gpu, name, decrypts):
 
 @pytest.mark.parametrize("N,W", [(32, 32), (64, 64), (256, 32), (1024, 32), (1024, 64), (2048, 64), (4096, 32)])
 def test_exact_mode_integer_ntt(require_gpu, N, W):
-    """MKT_ARITH_EXACT, transform level: the negacyclic NTT over Z_P[X]/(X^N+1), P = p1 p2 (two 31-bit primes, residue pairs).  Forward transforms
+    """MKT_ARITH_EXACT, transform level: the negacyclic NTT over Z_P[X]/(X^N+1), P = p1 p2 (two 30-bit primes, residue pairs).  Forward transforms
     equal a pure-Python restatement residue for residue (same network and table as the reference's FFT, fft.jl:105-155),
     forward -> inverse is the identity on edge words, and the product of a gadget-digit polynomial with a ring polynomial
     equals the exact schoolbook product mod 2^W (what polynomial.jl:99-113 approximates in Float64) -- bit-exact, also
@@ -947,8 +947,8 @@ def test_exact_mode_integer_ntt(require_gpu, N, W):
     back = ex.transform_inv(t.view(np.complex128))
     if N <= 1024:
         assert [int(v) for v in back[0]] == R.inv([int(v) for v in t[0]], W)
-    # the inverse returns the integer of least magnitude: the identity wherever |signed word| < P / 2 = 2^60.88
-    small = np.abs(polys.astype(np.int64 if W == 64 else np.int32).astype(np.float64)) < 2.0**60
+    # the inverse returns the integer of least magnitude: the identity wherever |signed word| < P / 2 = 2^58.9998
+    small = np.abs(polys.astype(np.int64 if W == 64 else np.int32).astype(np.float64)) < 2.0**58.99
     assert np.array_equal(back[small], polys[small]) and small.mean() > 0.05
     if W == 32:
         assert small.all()
