@@ -362,11 +362,11 @@ uint32_t ntt_mulmod(uint32_t a, uint32_t b, uint32_t p) { return (uint32_t)((uin
 uint32_t ntt_powmod(uint32_t a, uint64_t e, uint32_t p) { uint32_t r = 1; while (e) { if (e & 1) r = ntt_mulmod(r, a, p); a = ntt_mulmod(a, a, p); e >>= 1; } return r; }
 uint32_t ntt_shoup(uint32_t w, uint32_t p) { return (uint32_t)(((uint64_t)w << 32) / p); }
 
-// per point (w mod p1, companion, w mod p2, companion): psi_rev[N] | psiinv_rev[N] | N^-1 | N^-1 * 2^32, for the transform of
+// per point (w mod p1, companion, w mod p2, companion; the forward table holds 2^32 - w): psi_rev[N] | psiinv_rev[N] | N^-1, N^-1 w | N^-1 2^32, N^-1 2^32 w, for the transform of
 // size N; psi = g^((p - 1) / 2N) with g the smallest quadratic non-residue of p (so psi^N = -1: a primitive 2N-th root of unity)
 int upload_ntt_tables(mkt_ctx *c) {
     const int N = c->p.N, logN = c->logN;
-    std::vector<uint32_t> tab((size_t)(2 * N + 2) * 4);
+    std::vector<uint32_t> tab((size_t)(2 * N + 4) * 4);
     for (int k = 0; k < 2; k++) {
         const uint32_t p = NTT_P[k];
         uint32_t g = 2;
@@ -377,12 +377,14 @@ int upload_ntt_tables(mkt_ctx *c) {
             int r = 0;
             for (int b = 0; b < logN; b++) r |= ((i >> b) & 1) << (logN - 1 - b);
             const uint32_t w = ntt_powmod(psi, (uint64_t)r, p), wi = ntt_powmod(psiinv, (uint64_t)r, p);
-            tab[(size_t)i * 4 + 2 * k] = w; tab[(size_t)i * 4 + 2 * k + 1] = ntt_shoup(w, p);
+            tab[(size_t)i * 4 + 2 * k] = 0u - w; tab[(size_t)i * 4 + 2 * k + 1] = ntt_shoup(w, p);   // forward table: the NEGATED twiddle (ntt_exact.hip bfly_fwd)
             tab[((size_t)N + i) * 4 + 2 * k] = wi; tab[((size_t)N + i) * 4 + 2 * k + 1] = ntt_shoup(wi, p);
         }
+        // N^-1 and N^-1 2^32, each followed by its product with the one twiddle of the inverse's last stage (psiinv_rev[1])
         const uint32_t ninv = ntt_powmod((uint32_t)N, p - 2, p), ninv_r = (uint32_t)(((uint64_t)ninv << 32) % p);
-        tab[(size_t)(2 * N) * 4 + 2 * k] = ninv; tab[(size_t)(2 * N) * 4 + 2 * k + 1] = ntt_shoup(ninv, p);
-        tab[(size_t)(2 * N + 1) * 4 + 2 * k] = ninv_r; tab[(size_t)(2 * N + 1) * 4 + 2 * k + 1] = ntt_shoup(ninv_r, p);
+        const uint32_t wlast = ntt_powmod(psiinv, (uint64_t)N / 2, p);                    // bitrev(1) = N / 2
+        const uint32_t cs[4] = {ninv, ntt_mulmod(ninv, wlast, p), ninv_r, ntt_mulmod(ninv_r, wlast, p)};
+        for (int q = 0; q < 4; q++) { tab[(size_t)(2 * N + q) * 4 + 2 * k] = cs[q]; tab[(size_t)(2 * N + q) * 4 + 2 * k + 1] = ntt_shoup(cs[q], p); }
     }
     HIPCHK(c, hipMalloc((void **)&c->d_ntt, tab.size() * 4));
     HIPCHK(c, hipMemcpy(c->d_ntt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));

@@ -49,21 +49,24 @@ struct Pt { uint32_t a, b; };                                    // residues mod
 __device__ __forceinline__ uint64_t pack(Pt x) { return (uint64_t)x.a | ((uint64_t)x.b << 32); }
 __device__ __forceinline__ Pt unpack(uint64_t v) { Pt x; x.a = (uint32_t)v; x.b = (uint32_t)(v >> 32); return x; }
 
-template <uint32_t P> __device__ __forceinline__ uint32_t red1(uint32_t v) { const uint32_t w = v - P; return w < v ? w : v; }   // v < 2P -> [0, P)
-template <uint32_t P> __device__ __forceinline__ uint32_t canon4(uint32_t v) { const uint32_t w = v - 2u * P; return red1<P>(w < v ? w : v); }   // v < 4P -> [0, P)
+// the smaller of two words as unsigned integers: one v_min_u32.  (`w < v ? w : v` with w = v - c is recognised as a borrow test and
+// becomes v_sub_co + v_cndmask on vcc -- a 19-cycle instruction on gfx950, tools/valu_probe.hip -- in a third of the places.)
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return __builtin_elementwise_min(a, b); }
+template <uint32_t P> __device__ __forceinline__ uint32_t red1(uint32_t v) { return umin32(v, v - P); }   // v < 2P -> [0, P)
+template <uint32_t P> __device__ __forceinline__ uint32_t canon4(uint32_t v) { return red1<P>(umin32(v, v - 2u * P)); }   // v < 4P -> [0, P)
 template <uint32_t P> __device__ __forceinline__ uint32_t addm(uint32_t x, uint32_t y) { return red1<P>(x + y); }               // 2P < 2^32
-template <uint32_t P> __device__ __forceinline__ uint32_t subm(uint32_t x, uint32_t y) { const uint32_t d = x - y, e = d + P; return e < d ? e : d; }
+template <uint32_t P> __device__ __forceinline__ uint32_t subm(uint32_t x, uint32_t y) { const uint32_t d = x - y; return umin32(d, d + P); }
 // x * w mod P for a constant w with companion ws = floor(w * 2^32 / P); any 32-bit x
 template <uint32_t P> __device__ __forceinline__ uint32_t shoup(uint32_t x, uint32_t w, uint32_t ws) {
     const uint32_t q = __umulhi(x, ws);
     return red1<P>(x * w - q * P);
 }
 // Montgomery product x * y * 2^-32 mod P (x < 4P: a lazy forward-transform value is fine; y < P), result in [0, P)
+// (two v_mad_u64_u32 and one v_mul_lo_u32: the 64-bit multiply-add issues at the rate of a 32-bit multiply on gfx950)
 template <uint32_t P, uint32_t PINV> __device__ __forceinline__ uint32_t montmul(uint32_t x, uint32_t y) {
-    const uint32_t lo = x * y, hi = __umulhi(x, y);
-    const uint32_t m = lo * PINV, u = __umulhi(m, P);
-    const uint32_t d = hi - u, e = d + P;
-    return e < d ? e : d;                                        // hi - u in (-P, P)
+    const uint64_t z = (uint64_t)x * y;                          // < 4P * P < 2^62
+    const uint32_t m = (uint32_t)z * (0u - PINV);                // z + m P = 0 mod 2^32
+    return red1<P>((uint32_t)((z + (uint64_t)m * P) >> 32));     // (z + m P) / 2^32 < 4 P^2 / 2^32 + P < 2P
 }
 __device__ __forceinline__ Pt pt_add(Pt x, Pt y) { Pt r; r.a = addm<P1>(x.a, y.a); r.b = addm<P2>(x.b, y.b); return r; }
 __device__ __forceinline__ Pt pt_sub(Pt x, Pt y) { Pt r; r.a = subm<P1>(x.a, y.a); r.b = subm<P2>(x.b, y.b); return r; }
@@ -71,17 +74,23 @@ __device__ __forceinline__ Pt pt_shoup(Pt x, uint4 w) { Pt r; r.a = shoup<P1>(x.
 __device__ __forceinline__ Pt pt_mont(Pt x, Pt y) { Pt r; r.a = montmul<P1, PI1>(x.a, y.a); r.b = montmul<P2, PI2>(x.b, y.b); return r; }
 __device__ __forceinline__ Pt pt_canon4(Pt x) { Pt r; r.a = canon4<P1>(x.a); r.b = canon4<P2>(x.b); return r; }
 // Lazy butterflies (D. Harvey, "Faster arithmetic for number-theoretic transforms", 2014), 4P < 2^32.
-// forward (Cooley-Tukey): x, y in [0, 4P) -> x + w y, x - w y in [0, 4P); FIRST: x < 2P already (a transform's first stage)
+// forward (Cooley-Tukey): x, y in [0, 4P) -> x + w y, x - w y in [0, 4P); FIRST: x < 2P already (a transform's first stage).
+// The forward table holds the NEGATED twiddle (2^32 - w, with the companion of w): q P - y w is then one multiply-add
 template <uint32_t P> __device__ __forceinline__ void bfly_fwd(uint32_t &x, uint32_t &y, uint32_t w, uint32_t ws, bool FIRST) {   // FIRST folds after unrolling
     uint32_t x1 = x;
-    if (!FIRST) { const uint32_t v = x - 2u * P; x1 = v < x ? v : x; }
-    const uint32_t tn = __umulhi(y, ws) * P - y * w;             // -(w y mod P) - {0, P}  (mod 2^32)
+    if (!FIRST) x1 = umin32(x, x - 2u * P);
+    const uint32_t tn = __umulhi(y, ws) * P + y * w;             // w = -twiddle: -(twiddle y mod P) - {0, P}  (mod 2^32), a multiply-add
     x = x1 - tn; y = x1 + 2u * P + tn;
+}
+// the inverse's last stage with the scale c folded in: x, y in [0, 2P) -> c (x + y), c w (x - y) in [0, P)
+template <uint32_t P> __device__ __forceinline__ void bfly_inv_scaled(uint32_t &x, uint32_t &y, uint32_t c, uint32_t cs, uint32_t cw, uint32_t cws) {
+    const uint32_t s = x + y, d = x - y + 2u * P;
+    x = shoup<P>(s, c, cs); y = shoup<P>(d, cw, cws);
 }
 // inverse (Gentleman-Sande): x, y in [0, 2P) -> x + y, w (x - y) in [0, 2P)
 template <uint32_t P> __device__ __forceinline__ void bfly_inv(uint32_t &x, uint32_t &y, uint32_t w, uint32_t ws) {
     const uint32_t s = x + y, d = x - y + 2u * P, v = s - 2u * P;
-    x = v < s ? v : s;
+    x = umin32(s, v);
     y = d * w - __umulhi(d, ws) * P;
 }
 
@@ -100,7 +109,7 @@ __device__ __forceinline__ void ntt_exchange(Pt (&z)[8], uint64_t *lds, int t, i
 // In: slot e = point e*NT + t; slots 0..3 in [0, 2P), slots 4..7 any 32-bit value (fwd_in, res_small).  Out: slot e = point 8t + e (bit-reversed
 // order of the transform, as the reference's), values LAZY in [0, 4P): fine as the x of montmul and of shoup; pt_canon4
 // where the canonical residue is needed.
-// psi[k] = (w mod p1, its companion, w mod p2, its companion), w = psi^bitrev(k)
+// psi[k] = (-w mod p1 as 2^32 - w, the companion of w, the same mod p2), w = psi^bitrev(k)
 template <int LOGN, int PASS = 0>
 __device__ __forceinline__ void ntt_forward(Pt (&z)[8], const uint4 *__restrict__ psi, uint64_t *lds, int t) {
     using P = Plan<LOGN, NLR>;
@@ -125,10 +134,10 @@ __device__ __forceinline__ void ntt_forward(Pt (&z)[8], const uint4 *__restrict_
         ntt_forward<LOGN, PASS + 1>(z, psi, lds, t);
     }
 }
-// In: slot e = point 8t + e, values in [0, 2P).  Out: slot e = point e*NT + t, values in [0, 2P), NOT yet scaled by N^-1
-// (every caller follows with pt_shoup(., N^-1), which takes any 32-bit value to [0, P))
+// In: slot e = point 8t + e, values in [0, 2P).  Out: slot e = point e*NT + t, scaled by the constant sc[0] (N^-1 or N^-1 2^32;
+// sc[1] = sc[0] * psiinv[1]: the last stage has ONE twiddle, so the scale rides on its two products), values in [0, P)
 template <int LOGN, int PASS>
-__device__ __forceinline__ void ntt_inverse(Pt (&z)[8], const uint4 *__restrict__ psiinv, uint64_t *lds, int t) {
+__device__ __forceinline__ void ntt_inverse(Pt (&z)[8], const uint4 *__restrict__ psiinv, uint64_t *lds, int t, const uint4 (&sc)[2]) {
     using P = Plan<LOGN, NLR>;
     constexpr int p = PASS, lo = P::lo(p);
 #pragma unroll
@@ -141,14 +150,19 @@ __device__ __forceinline__ void ntt_inverse(Pt (&z)[8], const uint4 *__restrict_
 #pragma unroll
             for (int q = 0; q < (1 << sb); q++) {
                 const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
-                bfly_inv<P1>(z[e].a, z[e2].a, w.x, w.y);
-                bfly_inv<P2>(z[e].b, z[e2].b, w.z, w.w);
+                if (p == 0 && s == 0) {
+                    bfly_inv_scaled<P1>(z[e].a, z[e2].a, sc[0].x, sc[0].y, sc[1].x, sc[1].y);
+                    bfly_inv_scaled<P2>(z[e].b, z[e2].b, sc[0].z, sc[0].w, sc[1].z, sc[1].w);
+                } else {
+                    bfly_inv<P1>(z[e].a, z[e2].a, w.x, w.y);
+                    bfly_inv<P2>(z[e].b, z[e2].b, w.z, w.w);
+                }
             }
         }
     }
     if constexpr (p > 0) {
         ntt_exchange<LOGN>(z, lds, t, P::lo(p), P::lo(p - 1));
-        ntt_inverse<LOGN, PASS - 1>(z, psiinv, lds, t);
+        ntt_inverse<LOGN, PASS - 1>(z, psiinv, lds, t, sc);
     }
 }
 
@@ -157,7 +171,7 @@ __device__ __forceinline__ void ntt_inverse(Pt (&z)[8], const uint4 *__restrict_
 // signed 32-bit integer (a ring word of the 32-bit ring, a centered piece of the 64-bit ring)
 template <uint32_t P> __device__ __forceinline__ uint32_t res_in(int32_t s, bool x_slot) {
     uint32_t v = (uint32_t)s + ((uint32_t)(s >> 31) & (3u * P));               // [0, 3P): 2^31 < 3P < 2^32
-    if (x_slot) { const uint32_t w = v - 2u * P; v = w < v ? w : v; }
+    if (x_slot) v = umin32(v, v - 2u * P);
     return v;
 }
 // signed 64-bit ring word hi * 2^32 + lo - [hi < 0] 2^64 (hi, lo unsigned)
@@ -168,16 +182,16 @@ template <uint32_t P> __device__ __forceinline__ uint32_t res_in64(uint64_t x, b
     const uint32_t a = hi * R - __umulhi(hi, RS) * P;                          // hi 2^32 mod P, lazy: [0, 2P)
     const uint32_t b = lo - (lo >> 30) * P;                                    // [0, 2P)
     uint32_t v = a + b, w = v - 2u * P;
-    v = w < v ? w : v;                                                         // [0, 2P)
+    v = umin32(v, w);                                                          // [0, 2P)
     v += (uint32_t)((int32_t)hi >> 31) & (P - R64);                            // [0, 3P)
-    if (x_slot) { w = v - 2u * P; v = w < v ? w : v; }
+    if (x_slot) v = umin32(v, v - 2u * P);
     return v;
 }
 __device__ __forceinline__ Pt fwd_in(int32_t s, int e) { Pt r; r.a = res_in<P1>(s, e < 4); r.b = res_in<P2>(s, e < 4); return r; }
 __device__ __forceinline__ Pt fwd_in(uint32_t x, int e) { return fwd_in((int32_t)x, e); }
 __device__ __forceinline__ Pt fwd_in(uint64_t x, int e) { Pt r; r.a = res_in64<P1>(x, e < 4); r.b = res_in64<P2>(x, e < 4); return r; }
 // a gadget digit (|d| < P): d + P wraps past 2^32 exactly when d < 0
-template <uint32_t P> __device__ __forceinline__ uint32_t res_digit(int32_t d) { const uint32_t v = (uint32_t)d, w = v + P; return w < v ? w : v; }
+template <uint32_t P> __device__ __forceinline__ uint32_t res_digit(int32_t d) { const uint32_t v = (uint32_t)d; return umin32(v, v + P); }
 __device__ __forceinline__ Pt res_small(int d) { Pt r; r.a = res_digit<P1>(d); r.b = res_digit<P2>(d); return r; }
 // the 32-bit pieces of a 64-bit ring word, CENTERED: w = lo + 2^32 hi mod 2^64 with lo, hi in [-2^31, 2^31) -- half the
 // magnitude of unsigned pieces, i.e. one more bit of room under P / 2 for every product sum
@@ -189,15 +203,20 @@ __device__ __forceinline__ int32_t piece_of(uint64_t w, int h) {
 __device__ __forceinline__ uint64_t crt_signed(Pt r) {
     const uint32_t tq = shoup<P2>(subm<P2>(r.b, r.a), CRT_C, CRT_CS);   // r.a < p1 < p2
     const uint64_t x = (uint64_t)r.a + (uint64_t)P1 * tq;        // in [0, P)
-    return x > (PP >> 1) ? x - PP : x;
+    // x > P / 2  <=>  tq > (p2 - 1) / 2, or tq == (p2 - 1) / 2 and r.a > (p1 - 1) / 2  (P odd) -- as a mask by 32-bit arithmetic:
+    // the 64-bit compare + select it replaces is v_cmp_u64 + two v_cndmask on vcc (19 cycles each on gfx950)
+    const uint32_t u = 2u * tq + (((P1 - 1u) / 2u - r.a) >> 31);
+    const int32_t neg = (int32_t)(P2 - 1u - u) >> 31;
+    return x - (PP & (uint64_t)(int64_t)neg);
 }
 
-// constants at the tail of the table: N^-1 (+ companions) and N^-1 * 2^32 (for products of two plain operands taken with montmul)
-struct NttConsts { uint4 ninv, ninv_r; };
-// tables (32-bit words): psi_rev[N] x uint4 | psiinv_rev[N] x uint4 | NttConsts
+// constants at the tail of the table: N^-1 (+ companions) and N^-1 * 2^32 (for products of two plain operands taken with montmul),
+// each followed by its product with psiinv_rev[1]
+struct NttConsts { uint4 ninv[2], ninv_r[2]; };   // each: the constant c and c * w, w the twiddle of the inverse's last stage (ntt_inverse SCALED)
+// tables (32-bit words): psi_rev[N] x uint4 | psiinv_rev[N] x uint4 | NttConsts (4 x uint4)
 template <int LOGN> __device__ __forceinline__ const uint4 *tab_psi(const uint4 *tab) { return tab; }
 template <int LOGN> __device__ __forceinline__ const uint4 *tab_psiinv(const uint4 *tab) { return tab + (1 << LOGN); }
-template <int LOGN> __device__ __forceinline__ NttConsts tab_consts(const uint4 *tab) { NttConsts c; c.ninv = tab[2 << LOGN]; c.ninv_r = tab[(2 << LOGN) + 1]; return c; }
+template <int LOGN> __device__ __forceinline__ NttConsts tab_consts(const uint4 *tab) { NttConsts c; c.ninv[0] = tab[2 << LOGN]; c.ninv[1] = tab[(2 << LOGN) + 1]; c.ninv_r[0] = tab[(2 << LOGN) + 2]; c.ninv_r[1] = tab[(2 << LOGN) + 3]; return c; }
 
 // twiddles resident in LDS up to N = 2048 (one table: 16 N bytes); above, they are read through the caches
 template <int LOGN> struct TwLds { static constexpr bool on = LOGN <= 11; };
@@ -221,9 +240,9 @@ template <int LOGN> constexpr size_t lds_bytes(int ntab, int ppw = 1) { return (
 #define MKT_NTT_PPW 2
 #endif
 template <int LOGN> struct Ppw { static constexpr int v = (LOGN <= 10 && LOGN >= 6) ? MKT_NTT_PPW : 1; };
-template <int LOGN, typename WORD>
+template <int LOGN, typename WORD, bool MONT>
 __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_fwd_kernel(const uint4 *__restrict__ tab, const WORD *__restrict__ p,
-                                                                                 uint64_t *__restrict__ out, size_t B, int mont) {
+                                                                                 uint64_t *__restrict__ out, size_t B) {
     constexpr int N = 1 << LOGN, NT = N >> NLR, PPW = Ppw<LOGN>::v;
     const int sub = PPW > 1 ? threadIdx.x / NT : 0, t = PPW > 1 ? threadIdx.x % NT : threadIdx.x;
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)sub * N;
@@ -250,7 +269,7 @@ __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_fwd_kernel
             for (int e = 0; e < 8; e++) nxt[e] = __builtin_nontemporal_load(&p[bn * N + e * NT + t]);
         }
         ntt_forward<LOGN>(z, tw[0], lds, t);
-        if (mont) {
+        if (MONT) {
 #pragma unroll
             for (int e = 0; e < 8; e++) { z[e].a = montmul<P1, PI1>(z[e].a, RR1); z[e].b = montmul<P2, PI2>(z[e].b, RR2); }
         } else {
@@ -290,9 +309,9 @@ __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_inv_kernel
             for (int e = 0; e < 8; e++) nxt[e] = __builtin_nontemporal_load(&in[bn * N + e * NT + t]);
         }
         ntt_exchange<LOGN>(z, lds, t, Plan<LOGN, NLR>::lo(0), 0);
-        ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(z, tw[0], lds, t);
+        ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(z, tw[0], lds, t, k.ninv);
 #pragma unroll
-        for (int e = 0; e < 8; e++) __builtin_nontemporal_store((WORD)crt_signed(pt_shoup(z[e], k.ninv)), &p[b * N + e * NT + t]);
+        for (int e = 0; e < 8; e++) __builtin_nontemporal_store((WORD)crt_signed(z[e]), &p[b * N + e * NT + t]);
     }
 }
 
@@ -328,10 +347,10 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_polymul_kernel(cons
             ntt_forward<LOGN>(zb, tw[0], lds, t);
 #pragma unroll
             for (int e = 0; e < 8; e++) zb[e] = pt_mont(zb[e], za[e]);                 // x y 2^-32: undone by N^-1 2^32 below
-            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(zb, tw[1], lds, t);
+            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(zb, tw[1], lds, t, k.ninv_r);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const uint64_t v = crt_signed(pt_shoup(zb[e], k.ninv_r));              // the exact integer, two's complement mod 2^64
+                const uint64_t v = crt_signed(zb[e]);              // the exact integer, two's complement mod 2^64
                 acc[e] = (WORD)(acc[e] + (WORD)(W == 64 ? v << (32 * h) : v));
             }
         }
@@ -420,9 +439,9 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; e++) s2[e] = pt_add(s2[e], pt_mont(tacc[q][pp][e], unpack(mrow[e])));   // :71 / :157
             }
-            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s2, tw[1], lds, t);            // :72 / :162
+            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s2, tw[1], lds, t, k.ninv);            // :72 / :162
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[pp][e] += (uint32_t)crt_signed(pt_shoup(s2[e], k.ninv));   // :73 / :163
+            for (int e = 0; e < 8; e++) acc[pp][e] += (uint32_t)crt_signed(s2[e]);   // :73 / :163
         }
     }
 #pragma unroll
@@ -469,10 +488,10 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void ntt_fwd_split_kernel(cons
 // the exact integers behind a (low, high) accumulator pair, combined mod 2^64: inverse transforms, N^-1, Garner lift
 template <int LOGN>
 __device__ __forceinline__ void lift_pair(Pt (&lo)[8], Pt (&hi)[8], uint64_t (&w)[8], const uint4 *psiinv, const NttConsts &k, uint64_t *lds, int t) {
-    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(lo, psiinv, lds, t);
-    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(hi, psiinv, lds, t);
+    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(lo, psiinv, lds, t, k.ninv);
+    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(hi, psiinv, lds, t, k.ninv);
 #pragma unroll
-    for (int e = 0; e < 8; e++) w[e] = crt_signed(pt_shoup(lo[e], k.ninv)) + (crt_signed(pt_shoup(hi[e], k.ninv)) << 32);
+    for (int e = 0; e < 8; e++) w[e] = crt_signed(lo[e]) + (crt_signed(hi[e]) << 32);
 }
 
 // KMS phase 1 (bootstrapping.jl:389-443) with exact products: one workgroup per RLEV row rotation, accumulator (b, a) in
@@ -818,9 +837,9 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                     for (int e = 0; e < 8; e++) sc[(size_t)q * N + 8 * t + e] = pack(tu[e]);
                 }
-                ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(tv, tw[1], lds, t);   // :297-300
+                ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(tv, tw[1], lds, t, kc.ninv);   // :297-300
 #pragma unroll
-                for (int e = 0; e < 8; e++) tp[e] = gd.prep((uint32_t)crt_signed(pt_shoup(tv[e], kc.ninv)));   // :303-310
+                for (int e = 0; e < 8; e++) tp[e] = gd.prep((uint32_t)crt_signed(tv[e]));   // :303-310
                 for (int j = 0; j < l; j++) {                                      // :313-320 w
                     Pt z[8];
 #pragma unroll
@@ -841,9 +860,9 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
                     const Pt x = q == 0 ? tb[e] : (q == np ? ta[e] : unpack(sc[(size_t)q * N + 8 * t + e]));
                     s[e] = pt_mont(x, unpack(mrow[e]));
                 }
-                ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s, tw[1], lds, t);
+                ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s, tw[1], lds, t, kc.ninv);
 #pragma unroll
-                for (int e = 0; e < 8; e++) acc[(size_t)q * N + e * NT + t] += (uint32_t)crt_signed(pt_shoup(s[e], kc.ninv));
+                for (int e = 0; e < 8; e++) acc[(size_t)q * N + e * NT + t] += (uint32_t)crt_signed(s[e]);
             }
         }
     }
@@ -870,15 +889,22 @@ static hipError_t ntt_set_lds(K kern, size_t bytes) {
     default: return hipErrorInvalidValue;             \
     }
 
+template <int LN, typename WORD, bool MONT>
+static hipError_t ntt_fwd_launch(const uint4 *tb, const void *p, uint64_t *t, size_t B, int grid, size_t lds, hipStream_t s) {
+    hipError_t e = ntt_set_lds(ntt_fwd_kernel<LN, WORD, MONT>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ntt_fwd_kernel<LN, WORD, MONT>), dim3(grid), dim3(Ppw<LN>::v << (LN - NLR)), lds, s, tb, (const WORD *)p, t, B);
+    return hipSuccess;
+}
 hipError_t launch_ntt_fwd(int logN, int W, const uint64_t *tab, const void *p, uint64_t *t, size_t B, int montgomery, hipStream_t s) {
     if (!B) return hipSuccess;
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
+    hipError_t e_ = hipSuccess;
     MKT_NTT_DISPATCH(logN, {
         constexpr int PPW = Ppw<LN>::v; const size_t lds = lds_bytes<LN>(1, PPW); const size_t groups = (B + PPW - 1) / PPW; const int grid = (int)(groups < 32768 ? groups : 32768);
-        if (W == 64) { hipError_t e = ntt_set_lds(ntt_fwd_kernel<LN, uint64_t>, lds); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((ntt_fwd_kernel<LN, uint64_t>), dim3(grid), dim3(PPW << (LN - NLR)), lds, s, tb, (const uint64_t *)p, t, B, montgomery); }
-        else { hipError_t e = ntt_set_lds(ntt_fwd_kernel<LN, uint32_t>, lds); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((ntt_fwd_kernel<LN, uint32_t>), dim3(grid), dim3(PPW << (LN - NLR)), lds, s, tb, (const uint32_t *)p, t, B, montgomery); }
+if (W == 64) e_ = montgomery ? ntt_fwd_launch<LN, uint64_t, true>(tb, p, t, B, grid, lds, s) : ntt_fwd_launch<LN, uint64_t, false>(tb, p, t, B, grid, lds, s);
+        else e_ = montgomery ? ntt_fwd_launch<LN, uint32_t, true>(tb, p, t, B, grid, lds, s) : ntt_fwd_launch<LN, uint32_t, false>(tb, p, t, B, grid, lds, s);
+        if (e_ != hipSuccess) return e_;
     });
     return hipGetLastError();
 }
