@@ -96,14 +96,29 @@ template <uint32_t P> __device__ __forceinline__ void bfly_inv(uint32_t &x, uint
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 
+// Staging slot of point i: the XOR swizzle of the Float64 transform (fft_device.h lds_pos: conflict-free b64 writes, 1.15x the
+// conflict-free read cycles).  pt_index builds a point index from disjoint bit fields of t and e and the swizzle is linear over
+// GF(2), so slot(t, e) = slot(t, 0) ^ slot(e << lo): one base per exchange side and ONE v_xor per address, where the compiler
+// spent 2.3 instructions per address on the composed expression (19 of a point's ~150 in these integer-issue-bound kernels).
+// (MKT_NTT_LAYOUT=1: the padded layout i + 2 (i >> 4), whose slots are immediate offsets -- no address arithmetic at all, but
+// 1.35x the conflict-free LDS cycles and ds_read2/write2 pairs: +3 % on the batched transforms, -25 % on the gate kernels, which
+// run two waves per SIMD and wait on every exchange.  Measured, not shipped.)
+#ifndef MKT_NTT_LAYOUT
+#define MKT_NTT_LAYOUT 0
+#endif
+__host__ __device__ constexpr int ntt_pos(int i) { return MKT_NTT_LAYOUT ? i + 2 * (i >> 4) : (i ^ ((i >> 3) & 15)); }
+__host__ __device__ constexpr int ntt_join(int base, int off) { return MKT_NTT_LAYOUT ? base + off : (base ^ off); }
+template <int LOGN> struct NttLds { static constexpr int WORDS = MKT_NTT_LAYOUT ? ntt_pos(1 << LOGN) : (1 << LOGN); };   // 64-bit words of one polynomial's staging buffer
 template <int LOGN>
 __device__ __forceinline__ void ntt_exchange(Pt (&z)[8], uint64_t *lds, int t, int lo_from, int lo_to) {
     __syncthreads();
+    const int wr = ntt_pos(pt_index<NLR>(t, 0, lo_from));
 #pragma unroll
-    for (int e = 0; e < 8; e++) lds[lds_pos<NLR>(pt_index<NLR>(t, e, lo_from))] = pack(z[e]);
+    for (int e = 0; e < 8; e++) lds[ntt_join(wr, ntt_pos(e << lo_from))] = pack(z[e]);
     __syncthreads();
+    const int rd = ntt_pos(pt_index<NLR>(t, 0, lo_to));
 #pragma unroll
-    for (int e = 0; e < 8; e++) z[e] = unpack(lds[lds_pos<NLR>(pt_index<NLR>(t, e, lo_to))]);
+    for (int e = 0; e < 8; e++) z[e] = unpack(lds[ntt_join(rd, ntt_pos(e << lo_to))]);
 }
 
 // In: slot e = point e*NT + t; slots 0..3 in [0, 2P), slots 4..7 any 32-bit value (fwd_in, res_small).  Out: slot e = point 8t + e (bit-reversed
@@ -231,7 +246,7 @@ __device__ __forceinline__ void stage_tables(const uint4 *tab, uint4 *dst, int t
     }
     __syncthreads();
 }
-template <int LOGN> constexpr size_t lds_bytes(int ntab, int ppw = 1) { return (size_t)ppw * (1 << LOGN) * 8 + (TwLds<LOGN>::on ? (size_t)ntab * (1 << LOGN) * 16 : 0); }
+template <int LOGN> constexpr size_t lds_bytes(int ntab, int ppw = 1) { return (size_t)ppw * NttLds<LOGN>::WORDS * 8 + (TwLds<LOGN>::on ? (size_t)ntab * (1 << LOGN) * 16 : 0); }
 
 // Batched transforms: PPW polynomials per workgroup side by side (N / 8 threads each) share the staged twiddle table, which
 // lifts the number of resident waves per CU from 12 to 20 at N = 1024.
@@ -245,9 +260,9 @@ __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_fwd_kernel
                                                                                  uint64_t *__restrict__ out, size_t B) {
     constexpr int N = 1 << LOGN, NT = N >> NLR, PPW = Ppw<LOGN>::v;
     const int sub = PPW > 1 ? threadIdx.x / NT : 0, t = PPW > 1 ? threadIdx.x % NT : threadIdx.x;
-    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)sub * N;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)sub * NttLds<LOGN>::WORDS;
     const uint4 *tw[1]; const int which[1] = {0};
-    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)PPW * N), threadIdx.x, PPW * NT, tw, which);
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)PPW * NttLds<LOGN>::WORDS), threadIdx.x, PPW * NT, tw, which);
     const size_t groups = (B + PPW - 1) / PPW;
     // software pipeline: the words of this workgroup's NEXT polynomial are in flight while one is transformed (the loads
     // are HBM latency, ~2 us: resident waves alone do not cover it)
@@ -286,9 +301,9 @@ __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_inv_kernel
                                                                                  WORD *__restrict__ p, size_t B) {
     constexpr int N = 1 << LOGN, NT = N >> NLR, PPW = Ppw<LOGN>::v;
     const int sub = PPW > 1 ? threadIdx.x / NT : 0, t = PPW > 1 ? threadIdx.x % NT : threadIdx.x;
-    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)sub * N;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)sub * NttLds<LOGN>::WORDS;
     const uint4 *tw[1]; const int which[1] = {1};
-    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)PPW * N), threadIdx.x, PPW * NT, tw, which);
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)PPW * NttLds<LOGN>::WORDS), threadIdx.x, PPW * NT, tw, which);
     const NttConsts k = tab_consts<LOGN>(tab);
     const size_t groups = (B + PPW - 1) / PPW;
     auto poly_of = [&](size_t g) { const size_t b0 = g * PPW + sub; return b0 < B ? b0 : B - 1; };
@@ -324,7 +339,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_polymul_kernel(cons
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
     const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + N), t, NT, tw, which);
+    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts k = tab_consts<LOGN>(tab);
     for (size_t b = blockIdx.x; b < B; b += gridDim.x) {
         Pt za[8];
@@ -377,7 +392,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
     const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + N), t, NT, tw, which);
+    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts k = tab_consts<LOGN>(tab);
     const size_t rot = blockIdx.x;
     const uint32_t *at_src = lwe + rot * (size_t)lwe_stride;
@@ -467,7 +482,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void ntt_fwd_split_kernel(cons
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
     const uint4 *tw[1]; const int which[1] = {0};
-    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + N), t, NT, tw, which);
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     for (size_t b = blockIdx.x; b < B; b += gridDim.x) {
         uint64_t w[8];
 #pragma unroll
@@ -506,7 +521,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
     const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + N), t, NT, tw, which);
+    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts k = tab_consts<LOGN>(tab);
     const size_t gate = blockIdx.x % ngates;
     const int slot = (int)(blockIdx.x / ngates);
@@ -645,7 +660,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
     const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + N), t, NT, tw, which);
+    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts kc = tab_consts<LOGN>(tab);
     const size_t g = blockIdx.x;
     const int k = a.k;
@@ -785,7 +800,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
     const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + N), t, NT, tw, which);
+    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts kc = tab_consts<LOGN>(tab);
     const size_t g = blockIdx.x;
     const int k = a.k, l = a.l, n = a.n;
