@@ -324,7 +324,7 @@ def transform_roofline(mk, torch, local, dev):
             ms, cnt = sx.kernel_ms(3)
             sx.enable_timing(False)
             achieved = nb * 16 * N / (ms / cnt * 1e-3) / 1e9
-            out.append({"bound": "hbm", "kernel": "ntt_fwd_kernel" if direction == "forward" else "ntt_inv_kernel", "arith": "EXACT (integer NTT, residues mod 15*2^27+1 and 63*2^25+1)",
+            out.append({"bound": "hbm", "kernel": "ntt_fwd_kernel" if direction == "forward" else "ntt_inv_kernel", "arith": "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)",
                         "direction": direction, "N": N, "ring_bits": 64, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                         "traffic": None, "algorithmic_bytes_per_launch": nb * 16 * N, "bytes_per_transform": 16 * N, "transforms_per_launch": nb,
                         "avg_launch_ms": ms / cnt})
@@ -342,7 +342,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--workload", default="kms2_n1024", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch gates per GPU; strong: --batch gates in total, sharded over the ranks")
-    ap.add_argument("--arith", default="f64ref", choices=["f64ref", "exact"], help="f64ref: the reference's Float64 transforms, bit-identical to it (default); exact: integer NTT over two 31-bit primes (MKT_ARITH_EXACT: CGGI, LMSS, KMS)")
+    ap.add_argument("--arith", default="f64ref", choices=["f64ref", "exact"], help="f64ref: the reference's Float64 transforms, bit-identical to it (default); exact: integer NTT over two 30-bit primes (MKT_ARITH_EXACT: all five schemes)")
     ap.add_argument("--inputs", default="mixed", choices=["mixed", "fresh"], help="mixed: every ciphertext involves all k parties (default); fresh: single-party first-level encryptions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the transform legs (roofline_transform)")
@@ -402,7 +402,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t["elapsed"] / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "params": pname, "parties": p.k, "N": p.N, "n": p.n, "ring_bits": p.W,
-                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": "NAND", "inputs": args.inputs, "arith": "F64REF" if args.arith == "f64ref" else "EXACT (integer NTT, residues mod 15*2^27+1 and 63*2^25+1)", "sharding": "gates across GPUs, keys replicated"},
+                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": "NAND", "inputs": args.inputs, "arith": "F64REF" if args.arith == "f64ref" else "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)", "sharding": "gates across GPUs, keys replicated"},
             "ranks_seen": ranks_seen, "per_rank_ms_per_step": t["per_rank_ms"],
             # Wrong decryptions are the parameter set's own output noise (profiles/r03_noise_theory_vs_measured.md: predicted
             # from the schemes' variance formulas, measured on this engine; the oracle produces the identical words --

@@ -189,18 +189,18 @@ template <uint32_t P> __device__ __forceinline__ uint32_t res_in(int32_t s, bool
     if (x_slot) v = umin32(v, v - 2u * P);
     return v;
 }
-// signed 64-bit ring word hi * 2^32 + lo - [hi < 0] 2^64 (hi, lo unsigned)
+// signed 64-bit ring word x: with the sign bit flipped the word is x + 2^63 >= 0 = h 2^32 + l, and 2^32 = R mod P is an 18-bit
+// number -- two multiply-adds fold the word to 37 bits, a shift and a multiply-subtract to below 2P; the 2^63 leaves with a constant
 template <uint32_t P> __device__ __forceinline__ uint32_t res_in64(uint64_t x, bool x_slot) {
-    constexpr uint32_t R = (uint32_t)(((uint64_t)1 << 32) % P), RS = shoup_c(R, P), R64 = (uint32_t)((uint64_t)R * R % P);
-    static_assert(3u * ((1u << 30) - P) < P, "lo - (lo >> 30) P must land below 2P");
-    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
-    const uint32_t a = hi * R - __umulhi(hi, RS) * P;                          // hi 2^32 mod P, lazy: [0, 2P)
-    const uint32_t b = lo - (lo >> 30) * P;                                    // [0, 2P)
-    uint32_t v = a + b, w = v - 2u * P;
-    v = umin32(v, w);                                                          // [0, 2P)
-    v += (uint32_t)((int32_t)hi >> 31) & (P - R64);                            // [0, 3P)
-    if (x_slot) v = umin32(v, v - 2u * P);
-    return v;
+    constexpr uint64_t R = ((uint64_t)1 << 32) % P;
+    constexpr uint32_t K63 = (uint32_t)((P - (((uint64_t)1 << 63) % P)) % P);
+    constexpr uint64_t V2MAX = (R + 1) * R + ((uint64_t)1 << 32), QMAX = V2MAX >> 30;
+    static_assert(((uint64_t)1 << 30) + QMAX * (((uint64_t)1 << 30) - P) < 2ull * P, "the folded word must land below 2P");
+    const uint64_t v = (uint64_t)((uint32_t)(x >> 32) ^ 0x80000000u) * (uint32_t)R + (uint32_t)x;   // = x + 2^63 mod P, < 2^51
+    const uint64_t v2 = (uint64_t)(uint32_t)(v >> 32) * (uint32_t)R + (uint32_t)v;                  // < 2^37
+    uint32_t r = (uint32_t)v2 + K63 - (uint32_t)(v2 >> 30) * P;                                    // [0, 3P)
+    if (x_slot) r = umin32(r, r - 2u * P);
+    return r;
 }
 __device__ __forceinline__ Pt fwd_in(int32_t s, int e) { Pt r; r.a = res_in<P1>(s, e < 4); r.b = res_in<P2>(s, e < 4); return r; }
 __device__ __forceinline__ Pt fwd_in(uint32_t x, int e) { return fwd_in((int32_t)x, e); }
@@ -218,8 +218,8 @@ __device__ __forceinline__ int32_t piece_of(uint64_t w, int h) {
 __device__ __forceinline__ uint64_t crt_signed(Pt r) {
     const uint32_t tq = shoup<P2>(subm<P2>(r.b, r.a), CRT_C, CRT_CS);   // r.a < p1 < p2
     const uint64_t x = (uint64_t)r.a + (uint64_t)P1 * tq;        // in [0, P)
-    // x > P / 2  <=>  tq > (p2 - 1) / 2, or tq == (p2 - 1) / 2 and r.a > (p1 - 1) / 2  (P odd) -- as a mask by 32-bit arithmetic:
-    // the 64-bit compare + select it replaces is v_cmp_u64 + two v_cndmask on vcc (19 cycles each on gfx950)
+    // x > P / 2  <=>  tq > (p2 - 1) / 2, or tq == (p2 - 1) / 2 and r.a > (p1 - 1) / 2  (P odd): a 32-bit test instead of a 64-bit
+    // compare (the compiler turns the mask into v_cmp_i32 + v_cndmask; hiding it behind inline asm measured 2 % slower)
     const uint32_t u = 2u * tq + (((P1 - 1u) / 2u - r.a) >> 31);
     const int32_t neg = (int32_t)(P2 - 1u - u) >> 31;
     return x - (PP & (uint64_t)(int64_t)neg);
