@@ -72,6 +72,15 @@ __device__ __forceinline__ Pt pt_add(Pt x, Pt y) { Pt r; r.a = addm<P1>(x.a, y.a
 __device__ __forceinline__ Pt pt_sub(Pt x, Pt y) { Pt r; r.a = subm<P1>(x.a, y.a); r.b = subm<P2>(x.b, y.b); return r; }
 __device__ __forceinline__ Pt pt_shoup(Pt x, uint4 w) { Pt r; r.a = shoup<P1>(x.a, w.x, w.y); r.b = shoup<P2>(x.b, w.z, w.w); return r; }
 __device__ __forceinline__ Pt pt_mont(Pt x, Pt y) { Pt r; r.a = montmul<P1, PI1>(x.a, y.a); r.b = montmul<P2, PI2>(x.b, y.b); return r; }
+// acc + x * y * 2^-32 with a LAZY accumulator: acc in [0, 2P) -> [0, 2P) (x < 4P, y < P): 6 instructions per residue where the
+// canonical pt_add(acc, pt_mont(x, y)) takes 8.  Fine as the x of pt_mont and as the input of ntt_inverse.
+template <uint32_t P, uint32_t PINV> __device__ __forceinline__ uint32_t mac_lazy(uint32_t acc, uint32_t x, uint32_t y) {
+    const uint64_t z = (uint64_t)x * y;
+    const uint32_t m = (uint32_t)z * (0u - PINV);
+    const uint32_t s = acc + (uint32_t)((z + (uint64_t)m * P) >> 32);      // < 4P
+    return umin32(s, s - 2u * P);
+}
+__device__ __forceinline__ Pt pt_mac(Pt acc, Pt x, Pt y) { Pt r; r.a = mac_lazy<P1, PI1>(acc.a, x.a, y.a); r.b = mac_lazy<P2, PI2>(acc.b, x.b, y.b); return r; }
 __device__ __forceinline__ Pt pt_canon4(Pt x) { Pt r; r.a = canon4<P1>(x.a); r.b = canon4<P2>(x.b); return r; }
 // Lazy butterflies (D. Harvey, "Faster arithmetic for number-theoretic transforms", 2014), 4P < 2^32.
 // forward (Cooley-Tukey): x, y in [0, 4P) -> x + w y, x - w y in [0, 4P); FIRST: x < 2P already (a transform's first stage).
@@ -436,8 +445,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
                     const uint64_t *row = brk + (((size_t)(blk * LB + q) * 2 * l + (size_t)(c * l + j)) * 2) * N + 8 * t;
 #pragma unroll
                     for (int e = 0; e < 8; e++) {                        // :63-68 / :146-154, exactly
-                        tacc[q][0][e] = pt_add(tacc[q][0][e], pt_mont(z[e], unpack(row[e])));
-                        tacc[q][1][e] = pt_add(tacc[q][1][e], pt_mont(z[e], unpack(row[N + e])));
+                        tacc[q][0][e] = pt_mac(tacc[q][0][e], z[e], unpack(row[e]));
+                        tacc[q][1][e] = pt_mac(tacc[q][1][e], z[e], unpack(row[N + e]));
                     }
                 }
             }
@@ -452,7 +461,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
                 if (ats[q] == 0) continue;
                 const uint64_t *mrow = mono + (size_t)(ats[q] - 1) * N + 8 * t;
 #pragma unroll
-                for (int e = 0; e < 8; e++) s2[e] = pt_add(s2[e], pt_mont(tacc[q][pp][e], unpack(mrow[e])));   // :71 / :157
+                for (int e = 0; e < 8; e++) s2[e] = pt_mac(s2[e], tacc[q][pp][e], unpack(mrow[e]));   // :71 / :157
             }
             ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s2, tw[1], lds, t, k.ninv);            // :72 / :162
 #pragma unroll
@@ -585,7 +594,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                         for (int h = 0; h < 2; h++)
 #pragma unroll
-                            for (int e = 0; e < 8; e++) tacc[pp][h][e] = pt_add(tacc[pp][h][e], pt_mont(z[e], unpack(rowp[(size_t)(pp * 2 + h) * N + e])));   // :427-432 / :639-646, exactly
+                            for (int e = 0; e < 8; e++) tacc[pp][h][e] = pt_mac(tacc[pp][h][e], z[e], unpack(rowp[(size_t)(pp * 2 + h) * N + e]));   // :427-432 / :639-646, exactly
                 }
             if (BLK) {
                 const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
@@ -594,7 +603,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                     for (int h = 0; h < 2; h++)
 #pragma unroll
-                        for (int e = 0; e < 8; e++) sum[pp][h][e] = pt_add(sum[pp][h][e], pt_mont(tacc[pp][h][e], unpack(mrow[e])));   // :648
+                        for (int e = 0; e < 8; e++) sum[pp][h][e] = pt_mac(sum[pp][h][e], tacc[pp][h][e], unpack(mrow[e]));   // :648
             } else {
                 // one key bit: lift the product sum S itself and apply X^at - 1 on the integers (a rotation through LDS) -- the
                 // same words mod 2^64, and the lifted sum is bounded by 2 l N 2^(logB-1) 2^31 instead of twice that: what lets
