@@ -68,8 +68,6 @@ template <uint32_t P, uint32_t PINV> __device__ __forceinline__ uint32_t montmul
     const uint32_t m = (uint32_t)z * (0u - PINV);                // z + m P = 0 mod 2^32
     return red1<P>((uint32_t)((z + (uint64_t)m * P) >> 32));     // (z + m P) / 2^32 < 4 P^2 / 2^32 + P < 2P
 }
-__device__ __forceinline__ Pt pt_add(Pt x, Pt y) { Pt r; r.a = addm<P1>(x.a, y.a); r.b = addm<P2>(x.b, y.b); return r; }
-__device__ __forceinline__ Pt pt_sub(Pt x, Pt y) { Pt r; r.a = subm<P1>(x.a, y.a); r.b = subm<P2>(x.b, y.b); return r; }
 __device__ __forceinline__ Pt pt_shoup(Pt x, uint4 w) { Pt r; r.a = shoup<P1>(x.a, w.x, w.y); r.b = shoup<P2>(x.b, w.z, w.w); return r; }
 __device__ __forceinline__ Pt pt_mont(Pt x, Pt y) { Pt r; r.a = montmul<P1, PI1>(x.a, y.a); r.b = montmul<P2, PI2>(x.b, y.b); return r; }
 // acc + x * y * 2^-32 with a LAZY accumulator: acc in [0, 2P) -> [0, 2P) (x < 4P, y < P): 6 instructions per residue where the
@@ -80,6 +78,16 @@ template <uint32_t P, uint32_t PINV> __device__ __forceinline__ uint32_t mac_laz
     const uint32_t s = acc + (uint32_t)((z + (uint64_t)m * P) >> 32);      // < 4P
     return umin32(s, s - 2u * P);
 }
+// acc - x * y * 2^-32 and a + b on lazy values, [0, 2P) -> [0, 2P)
+template <uint32_t P, uint32_t PINV> __device__ __forceinline__ uint32_t msub_lazy(uint32_t acc, uint32_t x, uint32_t y) {
+    const uint64_t z = (uint64_t)x * y;
+    const uint32_t m = (uint32_t)z * (0u - PINV);
+    const uint32_t s = acc + 2u * P - (uint32_t)((z + (uint64_t)m * P) >> 32);      // (0, 4P)
+    return umin32(s, s - 2u * P);
+}
+template <uint32_t P> __device__ __forceinline__ uint32_t add_lazy(uint32_t a, uint32_t b) { const uint32_t s = a + b; return umin32(s, s - 2u * P); }
+__device__ __forceinline__ Pt pt_msub(Pt acc, Pt x, Pt y) { Pt r; r.a = msub_lazy<P1, PI1>(acc.a, x.a, y.a); r.b = msub_lazy<P2, PI2>(acc.b, x.b, y.b); return r; }
+__device__ __forceinline__ Pt pt_add_lazy(Pt x, Pt y) { Pt r; r.a = add_lazy<P1>(x.a, y.a); r.b = add_lazy<P2>(x.b, y.b); return r; }
 __device__ __forceinline__ Pt pt_mac(Pt acc, Pt x, Pt y) { Pt r; r.a = mac_lazy<P1, PI1>(acc.a, x.a, y.a); r.b = mac_lazy<P2, PI2>(acc.b, x.b, y.b); return r; }
 __device__ __forceinline__ Pt pt_canon4(Pt x) { Pt r; r.a = canon4<P1>(x.a); r.b = canon4<P2>(x.b); return r; }
 // Lazy butterflies (D. Harvey, "Faster arithmetic for number-theoretic transforms", 2014), 4P < 2^32.
@@ -705,8 +713,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
         for (int h = 0; h < 2; h++)
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const Pt pr = pt_mont(z[e], unpack(tbl[(size_t)h * N + 8 * t + e]));
-                dst[h][e] = subtract ? pt_sub(dst[h][e], pr) : pt_add(dst[h][e], pr);
+                const Pt y = unpack(tbl[(size_t)h * N + 8 * t + e]);               // accumulators are lazy, [0, 2P)
+                dst[h][e] = subtract ? pt_msub(dst[h][e], z[e], y) : pt_mac(dst[h][e], z[e], y);
             }
     };
     for (int idx = 0; idx < k; idx++) {
@@ -777,7 +785,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
                     Pt xv; xv.a = 0; xv.b = 0;
                     if (q <= idx) xv = unpack(tx[((size_t)q * 2 + h) * N + 8 * t + e]);
                     const Pt yv = q == 0 ? tyb[h][e] : (q == idx + 1 ? tya[h][e] : unpack(ty2[((size_t)q * 2 + h) * N + 8 * t + e]));
-                    s[h][e] = pt_add(xv, yv);
+                    s[h][e] = pt_add_lazy(xv, yv);
                 }
             uint64_t w[8];
             lift_pair<LOGN>(s[0], s[1], w, tw[1], kc, lds, t);
@@ -846,17 +854,17 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
                     ntt_forward<LOGN>(z, tw[0], lds, t);
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        tu[e] = pt_add(tu[e], pt_mont(z[e], unpack(ud[(size_t)j * N + 8 * t + e])));
-                        const Pt pr = pt_mont(z[e], unpack(vk[(size_t)j * N + 8 * t + e]));
-                        tv[e] = q == 0 ? pt_sub(tv[e], pr) : pt_add(tv[e], pr);     // mulsubto! with crs, muladdto! with b_i
+                        tu[e] = pt_mac(tu[e], z[e], unpack(ud[(size_t)j * N + 8 * t + e]));   // accumulators are lazy, [0, 2P)
+                        const Pt y = unpack(vk[(size_t)j * N + 8 * t + e]);
+                        tv[e] = q == 0 ? pt_msub(tv[e], z[e], y) : pt_mac(tv[e], z[e], y);     // mulsubto! with crs, muladdto! with b_i
                     }
                 }
                 if (q == 0) {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) tb[e] = pt_add(tb[e], tu[e]);
+                    for (int e = 0; e < 8; e++) tb[e] = pt_add_lazy(tb[e], tu[e]);
                 } else if (q == np) {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) ta[e] = pt_add(ta[e], tu[e]);
+                    for (int e = 0; e < 8; e++) ta[e] = pt_add_lazy(ta[e], tu[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; e++) sc[(size_t)q * N + 8 * t + e] = pack(tu[e]);
@@ -871,8 +879,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
                     ntt_forward<LOGN>(z, tw[0], lds, t);
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        tb[e] = pt_add(tb[e], pt_mont(z[e], unpack(uf[(size_t)(2 * j) * N + 8 * t + e])));
-                        ta[e] = pt_add(ta[e], pt_mont(z[e], unpack(uf[(size_t)(2 * j + 1) * N + 8 * t + e])));
+                        tb[e] = pt_mac(tb[e], z[e], unpack(uf[(size_t)(2 * j) * N + 8 * t + e]));
+                        ta[e] = pt_mac(ta[e], z[e], unpack(uf[(size_t)(2 * j + 1) * N + 8 * t + e]));
                     }
                 }
             }
