@@ -59,13 +59,14 @@ enum { MKT_NAND = 0, MKT_AND = 1, MKT_OR = 2, MKT_XOR = 3, MKT_XNOR = 4, MKT_NOR
 enum {
     MKT_ARITH_F64REF = 0, /* the reference's Float64 twisted FFT, operation for operation (fft.jl) */
     MKT_ARITH_EXACT = 1   /* exact integer arithmetic: the negacyclic NTT over Z_P[X]/(X^N+1) in residue form, P = p1 p2 =
-                             (15 * 2^27 + 1)(63 * 2^25 + 1) = 2^61.88.
+                             (131063 * 2^13 + 1)(131066 * 2^13 + 1) = 2^59.9998, the two largest NTT primes below 2^30
+                             (4 p < 2^32: lazy butterflies).
                              Transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch,
                              mkt_decompose_batch, mkt_modswitch_batch, mkt_not_batch) for every scheme; the gate path
                              (mkt_load_*, mkt_keygen_device, mkt_gate, mkt_bootstrap, mkt_blindrotate, mkt_keyswitch) for
                              MKT_CGGI / MKT_LMSS (RLWE length 1, 32-bit ring), MKT_CCS (32-bit ring) and MKT_KMS /
-                             MKT_KMS_BLOCK (64-bit ring: every 64-bit table kept as the transforms of its two 32-bit
-                             halves), provided the context's gadgets keep every product sum below P / 2 (checked at the
+                             MKT_KMS_BLOCK (64-bit ring: every 64-bit table kept as the transforms of its two centered
+                             32-bit pieces), provided the context's gadgets keep every product sum below P / 2 (checked at the
                              first key upload: MKT_ERR_UNSUPPORTED otherwise).  The ciphertexts are valid -- on the
                              64-bit ring 3-4x LESS noisy than the Float64 path, whose transform error dominates there --
                              but NOT the reference's words (no Float64 rounding); keys in MKT_FMT_INT_COEFF only.

@@ -60,7 +60,7 @@ struct mkt_ctx {
     hipStream_t own_stream = nullptr;   // a fork's own non-blocking stream (destroyed with the context); `stream` may be re-pointed by mkt_set_stream
     std::string err;
     std::shared_ptr<KeySet> ks;  // shared with the contexts forked from this one
-    bool exact = false;          // MKT_ARITH_EXACT (integer NTT, two 31-bit primes); d_ntt = psi_rev | psiinv_rev | N^-1 | N^-1 2^32, with Shoup companions
+    bool exact = false;          // MKT_ARITH_EXACT (integer NTT, two 30-bit primes); d_ntt = psi_rev (negated) | psiinv_rev | N^-1, N^-1 w | N^-1 2^32, N^-1 2^32 w, with Shoup companions
     uint64_t *d_ntt = nullptr;
     int split = 1;               // EXACT on the 64-bit ring: every resident 64-bit table is kept as (low, high) residue polynomials -> 2 per logical polynomial
     // workspace
