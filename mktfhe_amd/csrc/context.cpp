@@ -285,6 +285,7 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         a.init_mode = 0; a.out_mode = 0; a.acc_io = acc;
         Timer tm(c, 1);
         if (p.k > 1) {   // general RLWE length (CGGI, LMSS)
+            a.ngates = B;
             HIPCHK(c, mktd::launch_blindrotate_kr(c->logM, p.W, p.k, a, B, c->stream));
             return MKT_OK;
         }

@@ -1328,7 +1328,7 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
         if (G == 0) G = (blockg_supported(logM, 4) && logM == 9 && nrot >= 1024) ? 4 : 1;
         if (G > 1 && blockg_supported(logM, G) && a.blk_len >= 2 && a.blk_len <= 4) {
             const size_t nslots = (size_t)a.rows_per_gate;
-            const hipError_t e = W == 64 ? launch_rot_blockg_u64(logM, G, a, nslots, s) : launch_rot_blockg_u32(logM, G, a, nslots, s);
+            const hipError_t e = W == 64 ? launch_rot_blockg_u64(logM, G, 2, a, nslots, s) : launch_rot_blockg_u32(logM, G, 2, a, nslots, s);
             if (e != hipErrorInvalidValue) return e;     // a shape the grouped kernels do not cover (LDS budget): one rotation per workgroup below
         }
         return W == 64 ? launch_rot_block_u64(logM, a, nrot, s) : launch_rot_block_u32(logM, a, nrot, s);
@@ -1338,6 +1338,9 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
 #endif  // TU 0
 
 #if MKT_IN_TU(7)
+#ifndef MKT_KR_BLKG_MIN
+#define MKT_KR_BLKG_MIN 512   // rotations from which the grouped kernel is the default (tools/blkg_ab.sh)
+#endif
 template <int LM, typename WORD, int KR, bool BLK, int BL = 0>
 static hipError_t launch_kr_one(const RotArgs &a, size_t nrot, hipStream_t s) {
     using P = Plan<LM, LOGR>;
@@ -1357,6 +1360,16 @@ static hipError_t launch_kr_word(int kr, const RotArgs &a, size_t nrot, hipStrea
 hipError_t launch_blindrotate_kr(int logM, int W, int kr, const RotArgs &a, size_t nrot, hipStream_t s) {
     if (!nrot) return hipSuccess;
     if (kr < 2 || kr > 3) return hipErrorInvalidValue;
+    // LMSS with RLWE length 2, block length 3, 32-bit ring: four rotations per workgroup share every key element (rot_block.hip);
+    // blk_group (MKT_ROT_BLKG): 0 = by batch size, 1 = never, 4 = always
+    if (kr == 2 && W == 32 && a.blk_len == 3 && a.ngates == nrot) {
+        int G = a.blk_group;
+        if (G == 0) G = (blockg_supported(logM, 4) && nrot >= MKT_KR_BLKG_MIN) ? 4 : 1;
+        if (G == 4 && blockg_supported(logM, 4)) {
+            const hipError_t e = launch_rot_blockg_u32(logM, 4, 3, a, (size_t)a.rows_per_gate, s);
+            if (e != hipErrorInvalidValue) return e;
+        }
+    }
     MKT_DISPATCH_LOGM(logM, {
         if (W == 64) return launch_kr_word<LM, uint64_t>(kr, a, nrot, s);
         return launch_kr_word<LM, uint32_t>(kr, a, nrot, s);

@@ -1,6 +1,6 @@
-// Blind rotation of the block-binary schemes for gfx950: LMSS (bootstrapping.jl:114-165) and the phase-1 rows of
-// KMS_block (:599-659), RLWE length 1.  G rotations that share a key (same party slot, G different ciphertexts) per
-// workgroup of G thread groups.
+// Blind rotation of the block-binary schemes for gfx950: LMSS (bootstrapping.jl:114-165) with RLWE length 1 or 2 (NP = 2 or 3
+// accumulator polynomials) and the phase-1 rows of KMS_block (:599-659).  G rotations that share a key (same party slot, G
+// different ciphertexts) per workgroup of G thread groups.
 //
 // Why its own kernel.  A block of LB key bits multiplies every digit transform into LB * 2 key rows, so the
 // multiply-adds are 45 % of a block's flop (22 % in the plain CMux) and each needs its own 16 bytes of key: with one
@@ -25,7 +25,11 @@
 
 namespace mktd {
 
-template <int LOGM, typename WORD, int LB, int G, int LT, int BT>
+// NP = 3 (RLWE length 2, round 3): the one-rotation kernel of that shape (blindrotate_kr_kernel) waits on memory 73 % of the time --
+// every workgroup pulls the whole 152 MB key through its L1 (64 GB of L2 -> L1 reads per 1024 gates) with (k+1)^2 l rows per key bit
+// and no register left to request them ahead; here each key element is loaded once per G rotations, a digit ahead.  The resident
+// tables of such a context are in device point order 2 (ORDER), which only moves where a group publishes / collects its points.
+template <int LOGM, typename WORD, int LB, int G, int LT, int BT, int NP = 2>
 __global__ __launch_bounds__((G * Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
     using P = Plan<LOGM, LOGR, 1>;
@@ -33,7 +37,10 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
     constexpr int T = G * NT, PTS = M / T;       // multiply-add ownership: PTS = 4 / G stored positions per thread
     static_assert(R == 4 && (G == 1 || G == 2 || G == 4), "G must divide the points per thread");
-    static_assert(MKT_DEVORDER == 1, "a thread's stored positions assume the slot-major device point order");
+    constexpr int ORDER = NP > 2 ? MKT_DEVORDER_KR : MKT_DEVORDER;   // context.cpp: the RLWE-length-k contexts keep their tables in order 2
+    static_assert(MKT_DEVORDER == 1 && MKT_DEVORDER_KR == 2, "device point orders of the resident tables");
+    static_assert(NP == 2 || NP == 3, "accumulator polynomials");
+    static_assert((size_t)NP * G * M <= (size_t)G * P::LDS_CPLX + (size_t)2 * G * M, "the products of a block are published over the staging + digit buffers");
     // LDS: Psi | roots | FFT staging of group r | published digit transforms [parity][rotation][M] (reused for the products)
     cplx *psi_l = reinterpret_cast<cplx *>(mkt_smem);
     cplx *roots_l = psi_l + M;
@@ -73,16 +80,19 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
     const Gadget<WORD> gd(LT ? LT : a.l, (LT && BT) ? BT : a.logB);
     const int l = LT ? LT : a.l;
 
-    WORD acc[2][R][2];                            // rotation `grp`: b and a, words (e*NT + t) and (e*NT + t + M)
-    if (a.init_mode == 0) {
-        const WORD *src = reinterpret_cast<const WORD *>(a.acc_io) + rot * 2 * N;
+    int spos[R];                                  // where this thread's points 4t+e sit in a published transform (device point order)
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+    for (int e = 0; e < R; e++) spos[e] = dev_pos(ORDER, t * R + e, NT);
+    WORD acc[NP][R][2];                           // rotation `grp`: b and a (a_0, a_1), words (e*NT + t) and (e*NT + t + M)
+    if (a.init_mode == 0) {
+        const WORD *src = reinterpret_cast<const WORD *>(a.acc_io) + rot * NP * N;
+#pragma unroll
+        for (int c = 0; c < NP; c++)
 #pragma unroll
             for (int e = 0; e < R; e++) { acc[c][e][0] = src[c * N + e * NT + t]; acc[c][e][1] = src[c * N + M + e * NT + t]; }
     } else {                                      // bootstrapping.jl:609-612: b = gvec_lev[row] at X^0, a = 0
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+        for (int c = 0; c < NP; c++)
 #pragma unroll
             for (int e = 0; e < R; e++) { acc[c][e][0] = 0; acc[c][e][1] = 0; }
         if (t == 0) acc[0][0][0] = (WORD)1 << (W - (row + 1) * a.logB_lev);
@@ -105,13 +115,13 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
 
     // this thread's key elements of one digit: all key bits of the block, both polynomials, PTS stored positions -- each
     // serves all G rotations.  Requested a whole forward transform before they are used.
-    cplx K[LB][2][PTS];
+    cplx K[LB][NP][PTS];
     auto load_keys = [&](int kb, int g) {
 #pragma unroll
         for (int q = 0; q < LB; q++) {
-            const unsigned so_row = (unsigned)((((size_t)(kb * LB + q) * 2 * l + (size_t)g) * 2) * M * sizeof(cplx));
+            const unsigned so_row = (unsigned)((((size_t)(kb * LB + q) * NP * l + (size_t)g) * NP) * M * sizeof(cplx));
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < NP; c++)
 #pragma unroll
                 for (int p = 0; p < PTS; p++) K[q][c][p] = table_load(rs_brk, vo[p], so_row + (unsigned)(c * M * sizeof(cplx)));
         }
@@ -139,13 +149,13 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
         if (!any) continue;                       // :145 / :638 for every rotation of the workgroup: the block adds native(0) = 0
         if (kblk != blk) load_keys(blk, 0);       // the first block, or the block after skipped ones
 
-        cplx tacc[G][LB][2][PTS];
+        cplx tacc[G][LB][NP][PTS];
 #pragma unroll
         for (int r = 0; r < G; r++)
 #pragma unroll
             for (int q = 0; q < LB; q++)
 #pragma unroll
-                for (int c = 0; c < 2; c++)
+                for (int c = 0; c < NP; c++)
 #pragma unroll
                     for (int p = 0; p < PTS; p++) { tacc[r][q][c][p].re = 0.0; tacc[r][q][c][p].im = 0.0; }
         cplx mv[G][LB][PTS];                      // monomial rows of the block (:157), requested during the last digit's multiply-adds
@@ -170,14 +180,16 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
             cplx *xb = xbuf + (size_t)(g & 1) * G * M;
             cplx zr[G][PTS];
 #pragma unroll
-            for (int e = 0; e < R; e++) xb[grp * M + e * NT + t] = z[0][e];       // stored position of point 4t+e = e*NT + t (device order 1)
+            for (int e = 0; e < R; e++) xb[grp * M + spos[e]] = z[0][e];          // stored position of point 4t+e (order 1: e*NT + t)
             __syncthreads();
+            if constexpr (NP == 2) {
 #pragma unroll
-            for (int r = 0; r < G; r++)
+                for (int r = 0; r < G; r++)
 #pragma unroll
-                for (int p = 0; p < PTS; p++) zr[r][p] = xb[r * M + tid + p * T];
-            // the products below are published in the same buffers: every thread must be done with both parities first
-            if (LAST) __syncthreads();
+                    for (int p = 0; p < PTS; p++) zr[r][p] = xb[r * M + tid + p * T];
+                // the products below are published in the same buffers: every thread must be done with both parities first
+                if (LAST) __syncthreads();
+            }
             auto load_mono = [&]() {                                     // :157 monomial rows of every rotation and key bit
 #pragma unroll
                 for (int r = 0; r < G; r++)
@@ -189,53 +201,84 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
                     }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            if (LAST && G == 4) load_mono();                             // in flight during the multiply-adds where the registers allow
+            if (LAST && G == 4 && NP == 2) load_mono();                  // in flight during the multiply-adds where the registers allow
+            if constexpr (NP == 2) {
 #pragma unroll
-            for (int q = 0; q < LB; q++)
+                for (int q = 0; q < LB; q++)
 #pragma unroll
-                for (int c = 0; c < 2; c++)
+                    for (int c = 0; c < NP; c++)
 #pragma unroll
-                    for (int p = 0; p < PTS; p++)
+                        for (int p = 0; p < PTS; p++)
 #pragma unroll
-                        for (int r = 0; r < G; r++)                      // :146-154 muladdto!(tacc[q], digit, row); a key bit with atilde = 0 is dropped below
-                            tacc[r][q][c][p] = cadd(tacc[r][q][c][p], cmul(zr[r][p], K[q][c][p]));
+                            for (int r = 0; r < G; r++)                  // :146-154 muladdto!(tacc[q], digit, row); a key bit with atilde = 0 is dropped below
+                                tacc[r][q][c][p] = cadd(tacc[r][q][c][p], cmul(zr[r][p], K[q][c][p]));
+            } else {
+                // three polynomials: 36 accumulators + 9 key elements leave no room to hold all G digit points -- one rotation at a
+                // time, its points read from LDS as they are used (the parity buffers keep them until the step after next)
+#pragma unroll
+                for (int r = 0; r < G; r++) {
+#pragma unroll
+                    for (int p = 0; p < PTS; p++) {
+                        const cplx zz = xb[r * M + tid + p * T];
+#pragma unroll
+                        for (int q = 0; q < LB; q++)
+#pragma unroll
+                            for (int c = 0; c < NP; c++) tacc[r][q][c][p] = cadd(tacc[r][q][c][p], cmul(zz, K[q][c][p]));
+                    }
+                }
+                if (LAST) __syncthreads();                               // the products are published over these buffers
+            }
             if (!LAST) { __builtin_amdgcn_sched_barrier(0); load_keys(blk, g + 1); __builtin_amdgcn_sched_barrier(0); }
-            if (LAST && G != 4) { __builtin_amdgcn_sched_barrier(0); load_mono(); }
+            if (LAST && !(G == 4 && NP == 2) && NP == 2) { __builtin_amdgcn_sched_barrier(0); load_mono(); }
         };
-        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using CL = std::integral_constant<int, NP - 1>;
 #pragma unroll 1
         for (int j = 0; j < l; j++) digit_step(C0{}, j, std::false_type{});       // b digits (:131-140, :146-154: b rows first)
+        if constexpr (NP == 3) {
 #pragma unroll 1
-        for (int j = 0; j < l - 1; j++) digit_step(C1{}, j, std::false_type{});   // a digits
-        digit_step(C1{}, l - 1, std::true_type{});
+            for (int j = 0; j < l; j++) digit_step(C1{}, j, std::false_type{});   // a_0 digits
+        }
+#pragma unroll 1
+        for (int j = 0; j < l - 1; j++) digit_step(CL{}, j, std::false_type{});   // a digits (the last a polynomial)
+        digit_step(CL{}, l - 1, std::true_type{});
 
         // :157 / :648 tacc2 += monomial[atilde_q] * tacc[q], q ascending from zero, per rotation; published for the inverse
+        // (NP = 3: over the staging and digit buffers together -- every group is past its last forward transform, barrier above)
+        cplx *pub = NP > 2 ? stg_all : xbuf;
 #pragma unroll
         for (int r = 0; r < G; r++) {
-            cplx t2[2][PTS];
+            cplx t2[NP][PTS];
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < NP; c++)
 #pragma unroll
                 for (int p = 0; p < PTS; p++) { t2[c][p].re = 0.0; t2[c][p].im = 0.0; }
+            if constexpr (NP > 2) {                                      // the rotation's monomial rows now (no register to hold all G * LB of them)
+#pragma unroll
+                for (int q = 0; q < LB; q++) {
+                    const unsigned so_m = (unsigned)((size_t)(ats[r][q] ? ats[r][q] - 1 : 0) * M * sizeof(cplx));
+#pragma unroll
+                    for (int p = 0; p < PTS; p++) mv[r][q][p] = table_load(rs_mono, vo[p], so_m);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < LB; q++) {
                 if (ats[r][q] == 0) continue;
 #pragma unroll
                 for (int p = 0; p < PTS; p++)
 #pragma unroll
-                    for (int c = 0; c < 2; c++) t2[c][p] = cadd(t2[c][p], cmul(mv[r][q][p], tacc[r][q][c][p]));
+                    for (int c = 0; c < NP; c++) t2[c][p] = cadd(t2[c][p], cmul(mv[r][q][p], tacc[r][q][c][p]));
             }
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < NP; c++)
 #pragma unroll
-                for (int p = 0; p < PTS; p++) xbuf[(size_t)(c * G + r) * M + tid + p * T] = t2[c][p];
+                for (int p = 0; p < PTS; p++) pub[(size_t)(c * G + r) * M + tid + p * T] = t2[c][p];
         }
         __syncthreads();
-        cplx s[2][R];
+        cplx s[NP][R];
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+        for (int c = 0; c < NP; c++)
 #pragma unroll
-            for (int e = 0; e < R; e++) s[c][e] = xbuf[(size_t)(c * G + grp) * M + e * NT + t];
+            for (int e = 0; e < R; e++) s[c][e] = pub[(size_t)(c * G + grp) * M + spos[e]];
         __syncthreads();                          // the buffers are free for the next block's first digit
         // requested before the inverse transforms that hide them: the untwist factors, then (younger, so the wait for the
         // factors leaves them in flight) the key elements of the next block's first digit
@@ -246,12 +289,12 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
         if (blk + 1 < nblk) { load_keys(blk + 1, 0); kblk = blk + 1; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < 2; c++)               // :162-163 ifftto!, add!
+        for (int c = 0; c < NP; c++)              // :162-163 ifftto!, add!
             fft_inverse<LOGM, LOGR, 1, true, MO>(reinterpret_cast<cplx(&)[1][R]>(s[c]), psi_l, stg, t, xs.lx);
 #pragma unroll
         for (int e = 0; e < R; e++) {
 #pragma unroll
-            for (int c = 0; c < 2; c++) {         // fft.jl:76-80 untwist + native
+            for (int c = 0; c < NP; c++) {        // fft.jl:76-80 untwist + native
                 const cplx v = cmul(s[c][e], ri[e]);
                 acc[c][e][0] = (WORD)(acc[c][e][0] + native<WORD>(v.re));
                 acc[c][e][1] = (WORD)(acc[c][e][1] + native<WORD>(-v.im));
@@ -261,13 +304,13 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
 
     if (a.out_mode == 0) {
         if (mine_valid) {
-            WORD *dst = reinterpret_cast<WORD *>(a.acc_io) + rot * 2 * N;
+            WORD *dst = reinterpret_cast<WORD *>(a.acc_io) + rot * NP * N;
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < NP; c++)
 #pragma unroll
                 for (int e = 0; e < R; e++) { dst[c * N + e * NT + t] = acc[c][e][0]; dst[c * N + M + e * NT + t] = acc[c][e][1]; }
         }
-    } else {                                      // :657 fftto!(tacc, acc): every group runs it (workgroup barriers), valid ones store
+    } else if constexpr (NP == 2) {                                      // :657 fftto!(tacc, acc): every group runs it (workgroup barriers), valid ones store
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             cplx z[1][R];
@@ -286,15 +329,15 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
     }
 }
 
-template <int LM, typename WORD, int LB, int G, int LT, int BT>
+template <int LM, typename WORD, int LB, int G, int LT, int BT, int NP = 2>
 static hipError_t launch_blk_lt(const RotArgs &a, size_t nslots, hipStream_t s) {
     using P = Plan<LM, LOGR, 1>;
     constexpr size_t lds_bytes = ((size_t)2 * P::M + (size_t)G * P::LDS_CPLX + (size_t)2 * G * P::M) * sizeof(cplx);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    hipError_t e = set_lds(blindrotate_blk_kernel<LM, WORD, LB, G, LT, BT>, lds_bytes);
+    hipError_t e = set_lds(blindrotate_blk_kernel<LM, WORD, LB, G, LT, BT, NP>, lds_bytes);
     if (e != hipSuccess) return e;
     const size_t wg_per_slot = (a.ngates + G - 1) / G;
-    hipLaunchKernelGGL((blindrotate_blk_kernel<LM, WORD, LB, G, LT, BT>), dim3((unsigned)(wg_per_slot * nslots)), dim3(G * P::NT), lds_bytes, s, a, (int)wg_per_slot);
+    hipLaunchKernelGGL((blindrotate_blk_kernel<LM, WORD, LB, G, LT, BT, NP>), dim3((unsigned)(wg_per_slot * nslots)), dim3(G * P::NT), lds_bytes, s, a, (int)wg_per_slot);
     return hipGetLastError();
 }
 
@@ -305,6 +348,17 @@ static hipError_t launch_blk_g(const RotArgs &a, size_t nslots, hipStream_t s) {
     if constexpr (LB == 3 && LM == 9 && sizeof(WORD) == 4) { if (a.l == 3 && a.logB == 9) return launch_blk_lt<LM, WORD, LB, G, 3, 9>(a, nslots, s); }
     if constexpr (LB == 3 && LM == 10 && sizeof(WORD) == 8) { if (a.l == 3 && a.logB == 12) return launch_blk_lt<LM, WORD, LB, G, 3, 12>(a, nslots, s); }
     return launch_blk_lt<LM, WORD, LB, G, 0, 0>(a, nslots, s);
+}
+
+// RLWE length 2 (three accumulator polynomials): block length 3 on the 32-bit ring, four rotations per workgroup (Blockparam's shape,
+// BASELINE.json configs[4]); anything else stays on blindrotate_kr_kernel
+template <int LM, typename WORD, int G>
+static hipError_t launch_blk_np3(const RotArgs &a, size_t nslots, hipStream_t s) {
+    if constexpr (G != 4 || sizeof(WORD) != 4 || G * (1 << LM) / 4 > 1024 || ((size_t)2 + 2 * G + 2 * G) * (1 << LM) * 16 > 160 * 1024) { return hipErrorInvalidValue; } else {
+        if (a.blk_len != 3) return hipErrorInvalidValue;
+        if constexpr (LM == 9) { if (a.l == 3 && a.logB == 7) return launch_blk_lt<LM, WORD, 3, G, 3, 7, 3>(a, nslots, s); }
+        return launch_blk_lt<LM, WORD, 3, G, 0, 0, 3>(a, nslots, s);
+    }
 }
 
 template <int LM, typename WORD, int G>
@@ -337,8 +391,16 @@ bool blockg_supported(int logM, int G) {
 #define MKT_BLK_T uint64_t
 #define MKT_BLK_FN launch_rot_blockg_u64
 #endif
-hipError_t MKT_BLK_FN(int logM, int G, const RotArgs &a, size_t nslots, hipStream_t s) {
+hipError_t MKT_BLK_FN(int logM, int G, int npolys, const RotArgs &a, size_t nslots, hipStream_t s) {
     if (!a.ngates || !nslots) return hipSuccess;
+    if (npolys != 2 && npolys != 3) return hipErrorInvalidValue;
+    if (npolys == 3) {
+        MKT_DISPATCH_LOGM(logM, {
+            if (G == 4) return launch_blk_np3<LM, MKT_BLK_T, 4>(a, nslots, s);
+            return hipErrorInvalidValue;
+        });
+        return hipSuccess;
+    }
     MKT_DISPATCH_LOGM(logM, {
         if (G == 2) return launch_blk_lb<LM, MKT_BLK_T, 2>(a, nslots, s);
         if (G == 4) return launch_blk_lb<LM, MKT_BLK_T, 4>(a, nslots, s);

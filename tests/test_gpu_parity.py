@@ -214,6 +214,8 @@ BLOCK_SETS = [
     mk.KMS2partyblock.scaled(n=24, N=256, blk_d=8),
     mk.KMS2partyblock.scaled(n=12, N=2048, blk_d=4),                   # the shipped 64-bit shape (M = 1024, l = 3, 2^12)
     mk.KMS4partyblock.scaled(n=6, N=512, blk_d=2),
+    mk.Blockparam_k2.scaled(n=12, N=1024, blk_d=4),                     # RLWE length 2 (BASELINE configs[4]): three accumulator polynomials, G = 4 only
+    mk.Blockparam_k2.scaled(n=18, N=128, blk_d=6),
 ]
 
 
