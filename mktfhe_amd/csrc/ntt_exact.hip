@@ -564,11 +564,6 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
             any |= (pre_switched ? v0 : divbits<uint32_t>(v0, msbit)) != 0;
         }
         if (!__builtin_amdgcn_readfirstlane((int)any)) continue;                   // :413 / :638
-        uint64_t tp[2][8];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) tp[c][e] = gd.prep(acc[c][e]);              // :415-425 / :625-633 decompto!
         Pt sum[2][2][8];                                                           // [output polynomial][half]; BLK only (one key bit: the product itself)
         if (BLK) {
 #pragma unroll
@@ -594,7 +589,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
                 for (int j = 0; j < l; j++) {
                     Pt z[8];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(c ? tp[1][e] : tp[0][e], j));
+                    for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(gd.prep(c ? acc[1][e] : acc[0][e]), j));   // :415-425 / :625-633 decompto! (the rounding offset re-applied per digit: two instructions, sixteen registers less)
                     ntt_forward<LOGN>(z, tw[0], lds, t);
                     const uint64_t *rowp = brk + (((size_t)i * 2 * l + (size_t)(c * l + j)) * 4) * N + 8 * t;   // [poly][half][N]
 #pragma unroll
