@@ -26,6 +26,7 @@ Prints ONE JSON line on rank 0.  Extra objects:
   roofline_transform -- the batched negacyclic transforms HBM -> HBM (BASELINE.json's second metric), forward and
                         inverse at N = 1024 and N = 2048, working set >= 4 GiB, against 8 TB/s.
   secondary          -- the same measurement on the reference's own two-party set KMS2party (params.jl:47-53).
+  exact_mode         -- the headline workload in MKT_ARITH_EXACT (the integer NTT the north star names), N = 1 only.
   cpu_baseline       -- the C oracle (restatement of the reference CPU path, F64REF) timed on this box's host cores
                         on a bounded sample of the same workload; kind "port".
 """
@@ -434,6 +435,20 @@ def main():
             line["secondary"] = sec
         sch2.close()
         del x2, y2
+        torch.cuda.empty_cache()
+
+    # ---- the same workload in the integer-NTT arithmetic the north star names (MKT_ARITH_EXACT), short; N = 1 only ----
+    if rank == 0 and world == 1 and not args.no_secondary and args.arith == "f64ref" and args.workload == "kms2_n1024":
+        crsx, keysx, schx = make_scheme(mk, p, local, False, mk.ARITH_EXACT)
+        bitsx, xx, yx = make_inputs(mk, torch, p, keysx, schx, B, rank, dev, args.inputs)
+        stx = max(2, args.steps // 2)
+        tx = time_gates(mk, torch, dist, D, schx, p, keysx, xx, yx, bitsx, B, stx, 1, world, red_dev)
+        line["exact_mode"] = {"arith": "EXACT (two-prime integer NTT, exact products; DESIGN.md section 2)", "value": B * stx / tx["elapsed"], "unit": "gates/s", "steps": stx,
+                              "ms_per_step": 1e3 * tx["elapsed"] / stx, "batch_per_gpu": B, "decrypt_errors": tx["decrypt_errors"], "decrypt_checked": B,
+                              "kernels_ms_per_step": {"blindrotate": tx["rot_ms"] / stx, "keyswitch": tx["ks_ms"] / stx},
+                              "note": "valid ciphertexts, bitwise unrelated to the Float64 reference's (not the parity mode); word-identical to a big-integer restatement (tests/ref_exact.py)"}
+        schx.close()
+        del xx, yx
         torch.cuda.empty_cache()
 
     # ---- transform roofline legs (BASELINE.json metric 2) ----

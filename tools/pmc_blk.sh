@@ -1,20 +1,21 @@
-# usage (GPU box): GS="1 2 4" WL=lmss [BATCH=1024] bash tools/pmc_blk.sh  -- SQ / TCP / TCC counters of the block rotation kernel under each grouping (MKT_ROT_BLKG)
+# usage (GPU box): GS="1 2 4" WL=lmss [BATCH=1024] [XARGS="--arith exact"] [KERN=exact_kms_phase1] bash tools/pmc_blk.sh  -- SQ / TCP counters of the rotation kernel under each grouping (MKT_ROT_BLKG)
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
 for g in ${GS:-1 2 4}; do
  export MKT_ROT_BLKG=$g
  D=$R/gpurun_out/pmcblk_${WL:-lmss}_$g; rm -rf $D; mkdir -p $D
- ARGS="--workload ${WL:-lmss} --batch ${BATCH:-1024} --steps 2 --warmup 0 --no-cpu-baseline --no-secondary --no-roofline"
+ ARGS="--workload ${WL:-lmss} --batch ${BATCH:-1024} --steps 2 --warmup 0 --no-cpu-baseline --no-secondary --no-roofline ${XARGS:-}"
  timeout 150 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $D/a -- python3 $R/bench.py $ARGS > /dev/null 2>&1
  timeout 150 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_WAVES --output-format csv -d $D/b -- python3 $R/bench.py $ARGS > /dev/null 2>&1
  timeout 150 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum --output-format csv -d $D/c -- python3 $R/bench.py $ARGS > /dev/null 2>&1
- python3 - "$D" "$g" <<'PY'
-import csv, glob, sys
+ KERN=${KERN:-} python3 - "$D" "$g" <<'PY'
+import csv, glob, os, sys
 d, g = sys.argv[1], sys.argv[2]
+kern = os.environ.get('KERN', '')
 agg = {}
 for f in glob.glob(d + '/*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'blindrotate' not in k and 'ccs_' not in k: continue
+        if (kern not in k) if kern else ('blindrotate' not in k and 'ccs_' not in k): continue
         agg.setdefault(r['Counter_Name'], []).append((float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6, r.get('VGPR_Count', '?'), r.get('LDS_Block_Size', '?')))
 o = {c: sum(x[0] for x in v) / len(v) for c, v in agg.items()}
 ms = {c: sum(x[1] for x in v) / len(v) for c, v in agg.items()}
