@@ -236,6 +236,34 @@ def test_exact_ntt_restatement_against_schoolbook():
         assert R.inv(R.fwd(aw, W), W) == [int(x) for x in aw]
 
 
+def test_every_shipped_set_fits_the_exact_modulus():
+    """MKT_ARITH_EXACT is exact only while every transform-domain product sum stays below P / 2 (context.cpp exact_gate_ok, restated
+    here): centered 32-bit words / pieces (magnitude <= 2^31) against balanced digits (<= 2^(logB-1)), N terms per product.  With the
+    two 30-bit primes (P = 2^59.9998) every parameter set of params.jl must still fit -- the tightest are the headline shape
+    KMS k=2 N=1024 l=2 base 2^16 (2^58, thanks to the coefficient-domain monomial of KMS phase 1) and KMS2partyblock (2^58.2)."""
+    import ref_ntt as R
+    half_P = R.P / 2
+    assert all(q < 2**30 and (q - 1) % 8192 == 0 for q in R.PRIMES) and R.PRIMES[0] < R.PRIMES[1]
+    worst = {}
+    for name in dir(mk):
+        p = getattr(mk, name)
+        if not isinstance(p, mk.Params):
+            continue
+        n31 = p.N * 2.0**31
+        if p.scheme in (mk.KMS, mk.KMS_BLOCK):
+            ph1 = (2.0 * p.blk_len if p.scheme == mk.KMS_BLOCK else 1.0) * 2.0 * p.l_gsw * 2.0**(p.logB_gsw - 1) * n31
+            acc = (p.l_lev * 2.0**(p.logB_lev - 1) + 2.0 * p.l_uni * 2.0**(p.logB_uni - 1)) * n31
+            tv = p.k * p.l_uni * 2.0**(p.logB_uni - 1) * n31
+            b = max(ph1, acc, tv)
+        elif p.scheme == mk.CCS:
+            b = 2.0 * (p.k + 2.0) * p.l_uni * 2.0**(p.logB_uni - 1) * n31
+        else:
+            b = (2.0 * p.blk_len if p.scheme == mk.LMSS else 1.0) * 2.0 * p.l_gsw * 2.0**(p.logB_gsw - 1) * n31
+        worst[name] = b
+        assert b < half_P, (name, np.log2(b))
+    assert len(worst) >= 19 and abs(np.log2(worst["KMS2party_N1024_l2"]) - 58.0) < 1e-9
+
+
 @pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=9, N=128), mk.Blockparam.scaled(n=9, N=128, blk_d=3)], ids=lambda p: p.name)
 def test_exact_gate_restatement_decrypts(p):
     """tests/ref_exact.py (the checker of the MKT_ARITH_EXACT gate path on the GPU): gates bootstrapped with exact products
