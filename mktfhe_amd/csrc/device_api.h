@@ -119,7 +119,7 @@ hipError_t launch_modswitch(const uint32_t *lwe, uint32_t *atilde, uint32_t *bti
 hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int logN, int kacc, void *acc, size_t B, hipStream_t s);
 hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot, hipStream_t s);
 bool blockg_supported(int logM, int G);
-hipError_t launch_rot_blockg_u32(int logM, int G, int npolys, const RotArgs &a, size_t nslots, hipStream_t s);   // npolys = RLWE length + 1 (2, or 3 at block length 3, G = 4)
+hipError_t launch_rot_blockg_u32(int logM, int G, int npolys, const RotArgs &a, size_t nslots, hipStream_t s);   // npolys = RLWE length + 1 (2; 3 at block length 1 or 3 and 4 at block length 1, 32-bit ring, G = 4)
 hipError_t launch_rot_blockg_u64(int logM, int G, int npolys, const RotArgs &a, size_t nslots, hipStream_t s);
 hipError_t launch_blindrotate_kr(int logM, int W, int kr, const RotArgs &a, size_t nrot, hipStream_t s);
 hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hipStream_t s);

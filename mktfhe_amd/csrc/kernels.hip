@@ -1360,13 +1360,16 @@ static hipError_t launch_kr_word(int kr, const RotArgs &a, size_t nrot, hipStrea
 hipError_t launch_blindrotate_kr(int logM, int W, int kr, const RotArgs &a, size_t nrot, hipStream_t s) {
     if (!nrot) return hipSuccess;
     if (kr < 2 || kr > 3) return hipErrorInvalidValue;
-    // LMSS with RLWE length 2, block length 3, 32-bit ring: four rotations per workgroup share every key element (rot_block.hip);
-    // blk_group (MKT_ROT_BLKG): 0 = by batch size, 1 = never, 4 = always
-    if (kr == 2 && W == 32 && a.blk_len == 3 && a.ngates == nrot) {
+    // 32-bit ring, LMSS with RLWE length 2 and block length 3, CGGI with RLWE length 2 or 3: four rotations per workgroup share every
+    // key element (rot_block.hip); blk_group (MKT_ROT_BLKG): 0 = by batch size, 1 = never, 4 = always
+    if (W == 32 && a.ngates == nrot && ((kr == 2 && (a.blk_len == 3 || a.blk_len == 1)) || (kr == 3 && a.blk_len == 1))) {
         int G = a.blk_group;
-        if (G == 0) G = (blockg_supported(logM, 4) && nrot >= MKT_KR_BLKG_MIN) ? 4 : 1;
+        // by default where it measured ahead (tools/blkg_ab.sh, tools/kr_time.py): block length 3 at RLWE length 2 (14.1 -> 10.0 ms per 1024
+        // gates) and the plain CMux at RLWE length 3 (38.8 -> 24.3 ms); the plain CMux at RLWE length 2 stays on the one-rotation kernel
+        // (17.0 vs 17.9 ms at 1024 gates, 13.0 vs 17.8 at 256)
+        if (G == 0) G = (blockg_supported(logM, 4) && nrot >= MKT_KR_BLKG_MIN && !(kr == 2 && a.blk_len == 1)) ? 4 : 1;
         if (G == 4 && blockg_supported(logM, 4)) {
-            const hipError_t e = launch_rot_blockg_u32(logM, 4, 3, a, (size_t)a.rows_per_gate, s);
+            const hipError_t e = launch_rot_blockg_u32(logM, 4, kr + 1, a, (size_t)a.rows_per_gate, s);
             if (e != hipErrorInvalidValue) return e;
         }
     }

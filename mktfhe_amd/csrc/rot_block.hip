@@ -39,8 +39,8 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
     static_assert(R == 4 && (G == 1 || G == 2 || G == 4), "G must divide the points per thread");
     constexpr int ORDER = NP > 2 ? MKT_DEVORDER_KR : MKT_DEVORDER;   // context.cpp: the RLWE-length-k contexts keep their tables in order 2
     static_assert(MKT_DEVORDER == 1 && MKT_DEVORDER_KR == 2, "device point orders of the resident tables");
-    static_assert(NP == 2 || NP == 3, "accumulator polynomials");
-    static_assert((size_t)NP * G * M <= (size_t)G * P::LDS_CPLX + (size_t)2 * G * M, "the products of a block are published over the staging + digit buffers");
+    static_assert(NP >= 2 && NP <= 4, "accumulator polynomials");
+    // (NP > 2: the products of a block are published over the staging + digit buffers together; the launcher sizes the region for them)
     // LDS: Psi | roots | FFT staging of group r | published digit transforms [parity][rotation][M] (reused for the products)
     cplx *psi_l = reinterpret_cast<cplx *>(mkt_smem);
     cplx *roots_l = psi_l + M;
@@ -234,9 +234,13 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
         using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using CL = std::integral_constant<int, NP - 1>;
 #pragma unroll 1
         for (int j = 0; j < l; j++) digit_step(C0{}, j, std::false_type{});       // b digits (:131-140, :146-154: b rows first)
-        if constexpr (NP == 3) {
+        if constexpr (NP >= 3) {
 #pragma unroll 1
             for (int j = 0; j < l; j++) digit_step(C1{}, j, std::false_type{});   // a_0 digits
+        }
+        if constexpr (NP >= 4) {
+#pragma unroll 1
+            for (int j = 0; j < l; j++) digit_step(std::integral_constant<int, 2>{}, j, std::false_type{});   // a_1 digits
         }
 #pragma unroll 1
         for (int j = 0; j < l - 1; j++) digit_step(CL{}, j, std::false_type{});   // a digits (the last a polynomial)
@@ -332,7 +336,8 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
 template <int LM, typename WORD, int LB, int G, int LT, int BT, int NP = 2>
 static hipError_t launch_blk_lt(const RotArgs &a, size_t nslots, hipStream_t s) {
     using P = Plan<LM, LOGR, 1>;
-    constexpr size_t lds_bytes = ((size_t)2 * P::M + (size_t)G * P::LDS_CPLX + (size_t)2 * G * P::M) * sizeof(cplx);
+    constexpr size_t region = (size_t)G * P::LDS_CPLX + (size_t)2 * G * P::M, products = (size_t)NP * G * P::M;
+    constexpr size_t lds_bytes = ((size_t)2 * P::M + (region > products ? region : products)) * sizeof(cplx);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     hipError_t e = set_lds(blindrotate_blk_kernel<LM, WORD, LB, G, LT, BT, NP>, lds_bytes);
     if (e != hipSuccess) return e;
@@ -350,14 +355,19 @@ static hipError_t launch_blk_g(const RotArgs &a, size_t nslots, hipStream_t s) {
     return launch_blk_lt<LM, WORD, LB, G, 0, 0>(a, nslots, s);
 }
 
-// RLWE length 2 (three accumulator polynomials): block length 3 on the 32-bit ring, four rotations per workgroup (Blockparam's shape,
-// BASELINE.json configs[4]); anything else stays on blindrotate_kr_kernel
-template <int LM, typename WORD, int G>
-static hipError_t launch_blk_np3(const RotArgs &a, size_t nslots, hipStream_t s) {
+// RLWE length 2 and 3 (three / four accumulator polynomials) on the 32-bit ring, four rotations per workgroup: block length 3 at
+// RLWE length 2 (Blockparam's shape, BASELINE.json configs[4]) and the plain CMux (CGGI, block length 1: bootstrapping.jl:32-76 is the
+// block loop with one key bit per block) at RLWE length 2 and 3; anything else stays on blindrotate_kr_kernel
+template <int LM, typename WORD, int G, int NP>
+static hipError_t launch_blk_np(const RotArgs &a, size_t nslots, hipStream_t s) {
     if constexpr (G != 4 || sizeof(WORD) != 4 || G * (1 << LM) / 4 > 1024 || ((size_t)2 + 2 * G + 2 * G) * (1 << LM) * 16 > 160 * 1024) { return hipErrorInvalidValue; } else {
-        if (a.blk_len != 3) return hipErrorInvalidValue;
-        if constexpr (LM == 9) { if (a.l == 3 && a.logB == 7) return launch_blk_lt<LM, WORD, 3, G, 3, 7, 3>(a, nslots, s); }
-        return launch_blk_lt<LM, WORD, 3, G, 0, 0, 3>(a, nslots, s);
+        if (a.blk_len == 1) return launch_blk_lt<LM, WORD, 1, G, 0, 0, NP>(a, nslots, s);
+        if constexpr (NP == 3) {
+            if (a.blk_len != 3) return hipErrorInvalidValue;
+            if constexpr (LM == 9) { if (a.l == 3 && a.logB == 7) return launch_blk_lt<LM, WORD, 3, G, 3, 7, 3>(a, nslots, s); }
+            return launch_blk_lt<LM, WORD, 3, G, 0, 0, 3>(a, nslots, s);
+        }
+        return hipErrorInvalidValue;
     }
 }
 
@@ -393,11 +403,12 @@ bool blockg_supported(int logM, int G) {
 #endif
 hipError_t MKT_BLK_FN(int logM, int G, int npolys, const RotArgs &a, size_t nslots, hipStream_t s) {
     if (!a.ngates || !nslots) return hipSuccess;
-    if (npolys != 2 && npolys != 3) return hipErrorInvalidValue;
-    if (npolys == 3) {
+    if (npolys < 2 || npolys > 4) return hipErrorInvalidValue;
+    if (npolys > 2) {
         MKT_DISPATCH_LOGM(logM, {
-            if (G == 4) return launch_blk_np3<LM, MKT_BLK_T, 4>(a, nslots, s);
-            return hipErrorInvalidValue;
+            if (G != 4) return hipErrorInvalidValue;
+            if (npolys == 3) return launch_blk_np<LM, MKT_BLK_T, 4, 3>(a, nslots, s);
+            return launch_blk_np<LM, MKT_BLK_T, 4, 4>(a, nslots, s);
         });
         return hipSuccess;
     }

@@ -216,6 +216,9 @@ BLOCK_SETS = [
     mk.KMS4partyblock.scaled(n=6, N=512, blk_d=2),
     mk.Blockparam_k2.scaled(n=12, N=1024, blk_d=4),                     # RLWE length 2 (BASELINE configs[4]): three accumulator polynomials, G = 4 only
     mk.Blockparam_k2.scaled(n=18, N=128, blk_d=6),
+    mk.CGGIparam.scaled(n=16, N=256, k=2),                             # the plain CMux with RLWE length 2 / 3 on the same kernel (one key bit per block)
+    mk.CGGIparam.scaled(n=8, N=1024, k=2),
+    mk.CGGIparam.scaled(n=12, N=512, k=3, l_gsw=2, logB_gsw=10),
 ]
 
 
