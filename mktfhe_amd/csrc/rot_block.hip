@@ -37,6 +37,9 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
     constexpr int T = G * NT, PTS = M / T;       // multiply-add ownership: PTS = 4 / G stored positions per thread
     static_assert(R == 4 && (G == 1 || G == 2 || G == 4), "G must divide the points per thread");
+    // register-lean multiply-add / monomial stages: digit points and monomial rows fetched per rotation as they are used (three or four
+    // polynomials; and G = 2 on the 64-bit ring, where holding them spilled 228 B per lane: KMS2partyblock 39.9 -> 34.1 ms, on par with G = 1)
+    constexpr bool LEAN = NP > 2 || (G == 2 && sizeof(WORD) == 8);
     constexpr int ORDER = NP > 2 ? MKT_DEVORDER_KR : MKT_DEVORDER;   // context.cpp: the RLWE-length-k contexts keep their tables in order 2
     static_assert(MKT_DEVORDER == 1 && MKT_DEVORDER_KR == 2, "device point orders of the resident tables");
     static_assert(NP >= 2 && NP <= 4, "accumulator polynomials");
@@ -182,7 +185,7 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
 #pragma unroll
             for (int e = 0; e < R; e++) xb[grp * M + spos[e]] = z[0][e];          // stored position of point 4t+e (order 1: e*NT + t)
             __syncthreads();
-            if constexpr (NP == 2) {
+            if constexpr (!LEAN) {
 #pragma unroll
                 for (int r = 0; r < G; r++)
 #pragma unroll
@@ -201,8 +204,8 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
                     }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            if (LAST && G == 4 && NP == 2) load_mono();                  // in flight during the multiply-adds where the registers allow
-            if constexpr (NP == 2) {
+            if (LAST && G == 4 && !LEAN) load_mono();                  // in flight during the multiply-adds where the registers allow
+            if constexpr (!LEAN) {
 #pragma unroll
                 for (int q = 0; q < LB; q++)
 #pragma unroll
@@ -229,7 +232,7 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
                 if (LAST) __syncthreads();                               // the products are published over these buffers
             }
             if (!LAST) { __builtin_amdgcn_sched_barrier(0); load_keys(blk, g + 1); __builtin_amdgcn_sched_barrier(0); }
-            if (LAST && !(G == 4 && NP == 2) && NP == 2) { __builtin_amdgcn_sched_barrier(0); load_mono(); }
+            if (LAST && G != 4 && !LEAN) { __builtin_amdgcn_sched_barrier(0); load_mono(); }
         };
         using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using CL = std::integral_constant<int, NP - 1>;
 #pragma unroll 1
@@ -256,7 +259,7 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
             for (int c = 0; c < NP; c++)
 #pragma unroll
                 for (int p = 0; p < PTS; p++) { t2[c][p].re = 0.0; t2[c][p].im = 0.0; }
-            if constexpr (NP > 2) {                                      // the rotation's monomial rows now (no register to hold all G * LB of them)
+            if constexpr (LEAN) {                                        // the rotation's monomial rows now (no register to hold all G * LB of them)
 #pragma unroll
                 for (int q = 0; q < LB; q++) {
                     const unsigned so_m = (unsigned)((size_t)(ats[r][q] ? ats[r][q] - 1 : 0) * M * sizeof(cplx));
