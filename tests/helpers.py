@@ -39,10 +39,10 @@ def oracle_scheme(p: mk.Params, crs, keys):
     return s
 
 
-def gpu_scheme(p: mk.Params, crs, keys, device=0):
+def gpu_scheme(p: mk.Params, crs, keys, device=0, arith=0):
     if p.multikey:
-        return mk.setup(p, keys=keys, a=crs, device=device)
-    return mk.setup(p, keys=keys[0], device=device)[1]
+        return mk.setup(p, keys=keys, a=crs, device=device, arith=arith)
+    return mk.setup(p, keys=keys[0], device=device, arith=arith)[1]
 
 
 def encrypt_bits(p: mk.Params, keys, bits, seed=100):
