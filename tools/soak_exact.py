@@ -56,5 +56,18 @@ for N in (32, 64, 128, 256):
                         bad += 1; print('polymul mismatch', N, W, it, logB, b)
         ex.close()
         print('N', N, 'W', W, 'done, mismatches so far', bad, flush=True)
+# the worst case the modulus admits: N = 4096, every digit -2^15, every centered piece -2^31 -> coefficient N - 1 of each piece product
+# is 4096 * 2^46 = 2^58 (P / 2 = 2^58.9998); also the mirrored signs
+p = mk.CGGIparam.scaled(n=8, N=4096, W=64)
+ex = mk.Scheme(p, arith=mk.ARITH_EXACT)
+for sa, sb in ((-(1 << 15), 0x8000000080000000), ((1 << 15) - 1, 0x8000000080000000), (-(1 << 15), 0x7FFFFFFF7FFFFFFF)):
+    aw = np.full((1, 4096), sa, dtype=np.int64).astype(np.uint64)
+    bw = np.full((1, 4096), sb, dtype=np.uint64)
+    got = ex.exact_polymul(aw, bw)
+    ref = O.negacyclic(aw[0], bw[0], 64)
+    if not np.array_equal(got[0].astype(np.uint64), ref):
+        bad += 1; print('worst-case polymul mismatch', sa, hex(sb))
+ex.close()
+print('worst-case products at N = 4096 done, mismatches so far', bad)
 print('soak_exact:', 'OK' if bad == 0 else f'{bad} MISMATCHES')
 sys.exit(1 if bad else 0)
