@@ -970,6 +970,19 @@ def test_exact_mode_integer_ntt(require_gpu, N, W):
     ex.close()
 
 
+def test_exact_products_at_the_modulus_edge(require_gpu):
+    """The largest product the two-prime modulus admits: N = 4096, every digit -2^15, every centered 32-bit piece -2^31, so that
+    coefficient N - 1 of a piece product is 4096 * 2^46 = 2^58 (P / 2 = 2^58.9998) -- and the mirrored signs.  Exact, i.e. equal to
+    the oracle's schoolbook product mod 2^64 (the lazy ranges of the transforms and the Garner lift at their far end)."""
+    p = mk.CGGIparam.scaled(n=8, N=4096, W=64)
+    ex = mk.Scheme(p, arith=mk.ARITH_EXACT)
+    for sa, sb in ((-(1 << 15), 0x8000000080000000), ((1 << 15) - 1, 0x8000000080000000), (-(1 << 15), 0x7FFFFFFF7FFFFFFF)):
+        aw = np.full((1, 4096), sa, dtype=np.int64).astype(np.uint64)
+        bw = np.full((1, 4096), sb, dtype=np.uint64)
+        assert np.array_equal(ex.exact_polymul(aw, bw)[0].astype(np.uint64), O.negacyclic(aw[0], bw[0], 64)), (sa, hex(sb))
+    ex.close()
+
+
 @pytest.mark.parametrize("p", [mk.KMS2party.scaled(n=8, N=256), mk.KMS2party_N1024_l2.scaled(n=8), mk.KMS2party.scaled(n=6), mk.KMS4party.scaled(n=4, N=512),
                                mk.KMS8party.scaled(n=3, N=256, k=3), mk.KMS2partyblock.scaled(n=12, N=256, blk_d=4), mk.KMS2partyblock.scaled(n=6, blk_d=2)],
                          ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
