@@ -325,10 +325,17 @@ def transform_roofline(mk, torch, local, dev):
             ms, cnt = sx.kernel_ms(3)
             sx.enable_timing(False)
             achieved = nb * 16 * N / (ms / cnt * 1e-3) / 1e9
-            out.append({"bound": "hbm", "kernel": "ntt_fwd_kernel" if direction == "forward" else "ntt_inv_kernel", "arith": "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)",
-                        "direction": direction, "N": N, "ring_bits": 64, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                        "traffic": None, "algorithmic_bytes_per_launch": nb * 16 * N, "bytes_per_transform": 16 * N, "transforms_per_launch": nb,
-                        "avg_launch_ms": ms / cnt})
+            kern = "ntt_fwd_kernel" if direction == "forward" else "ntt_inv_kernel"
+            e = {"bound": "hbm", "kernel": kern, "arith": "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)",
+                 "direction": direction, "N": N, "ring_bits": 64, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                 "traffic": None, "algorithmic_bytes_per_launch": nb * 16 * N, "bytes_per_transform": 16 * N, "transforms_per_launch": nb,
+                 "avg_launch_ms": ms / cnt, "bound_note": "integer issue, not HBM: VALU ~0.95 busy per SIMD at a 1.6-1.8 GHz clock (profiles/r03_ntt_pmc.txt)"}
+            prof = profiled_counters(f"mktd::{kern}<{int(np.log2(N))}", "kms2_n1024")
+            if prof:
+                c, src, _ = prof
+                e["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                e["traffic_source"] = src
+            out.append(e)
         sx.close()
         del polys, tr, back
         torch.cuda.empty_cache()

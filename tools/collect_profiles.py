@@ -23,7 +23,7 @@ if dirs:
                 for r in csv.DictReader(open(f)):
                     k = r["Kernel_Name"]
                     if "mktd" not in k: continue
-                    key = (k.split("(")[0].replace("void ", ""), r["Grid_Size"], r["Counter_Name"])
+                    key = (k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0], r["Grid_Size"], r["Counter_Name"])   # kernels of unnamed namespaces keep their own rows
                     agg.setdefault(key, []).append((float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
             for (k, g, c), v in sorted(agg.items()):
                 out.write(f"{k},{g},{c},{sum(x[0] for x in v)/len(v):.6g},{sum(x[1] for x in v)/len(v):.4f},{len(v)}\n")
