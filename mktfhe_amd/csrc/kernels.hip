@@ -1426,10 +1426,10 @@ hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, h
 hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
     int G = 32, target_blocks = 1024;   // swept on MI355X (tools/ks_sweep.sh): 1.6 ms vs 4.7 ms single-gate at KMS k=2 N=1024
-    // the balanced-digit variant (block schemes) does its sign handling on the scalar unit and wants four times the workgroups once
-    // the batch leaves few slabs: Blockparam 4096 gates 2.12 -> 1.32 ms, 16 384 gates 8.49 -> 4.94 ms, KMS2partyblock 1024 gates
+    // the balanced-digit variant (block schemes) does its sign handling on the scalar unit and wants four to eight times the workgroups once
+    // the batch leaves few slabs (and one wave per staged table, below): Blockparam 4096 gates 2.12 -> 1.32 ms, 16 384 gates 8.49 -> 4.94 ms, KMS2partyblock 1024 gates
     // 2.73 -> 2.35 ms, neutral at 1024 LMSS gates; the unbalanced variant is fastest at 1024 at every batch size (tools/ks_blocks_sweep*.sh)
-    if (a.balanced) target_blocks = 4096;
+    if (a.balanced) target_blocks = a.mk ? 4096 : 8192;
     if (const char *e = getenv("MKT_KS_G")) G = atoi(e);
     if (const char *e = getenv("MKT_KS_BLOCKS")) target_blocks = atoi(e);
     const int ngroups = (int)((B + G - 1) / G);
@@ -1444,7 +1444,7 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     if (const char *e = getenv("MKT_KS_WAVES")) waves = atoi(e);
     if (waves != 2 && waves != 4) waves = 1;
     if (G != 32) waves = 1;
-    if (a.balanced && a.mk && !getenv("MKT_KS_WAVES")) waves = 1;   // KMS_block: measured 2.7 ms alone vs 4.0 ms shared (KMS2partyblock)
+    if (a.balanced && !getenv("MKT_KS_WAVES")) waves = 1;   // balanced digits: every wave stages its own table (KMS2partyblock 2.7 ms alone vs 4.0 ms shared; Blockparam 16 384 gates 4.98 -> 4.11 ms, RLWE length 2 19.3 -> 14.9 ms)
     const int gblocks = (ngroups + waves - 1) / waves;
     if (waves > 1) {   // same number of waves in flight as the single-wave launch
         slabs = (target_blocks + ngroups * parties - 1) / (ngroups * parties);
