@@ -1325,7 +1325,7 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
         // chip with one workgroup per compute unit (measured: Blockparam 5.54 -> 5.39 ms per 1024 gates; one rotation per
         // workgroup below that, and at M = 1024 where only two rotations fit and run 15 % slower)
         int G = a.blk_group;
-        if (G == 0) G = (blockg_supported(logM, 4) && logM == 9 && nrot >= 1024) ? 4 : 1;
+        if (G == 0) G = (blockg_supported(logM, 4) && logM == 9 && nrot >= 1024) ? ((W == 32 && nrot >= 4096) ? 2 : 4) : 1;   // from 4096 rotations two rotations per workgroup, two workgroups per CU: 204 k against 196 k gates/s (Blockparam, 8192 and 16 384 gates)
         if (G > 1 && blockg_supported(logM, G) && a.blk_len >= 2 && a.blk_len <= 4) {
             const size_t nslots = (size_t)a.rows_per_gate;
             const hipError_t e = W == 64 ? launch_rot_blockg_u64(logM, G, 2, a, nslots, s) : launch_rot_blockg_u32(logM, G, 2, a, nslots, s);

@@ -38,8 +38,10 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
     constexpr int T = G * NT, PTS = M / T;       // multiply-add ownership: PTS = 4 / G stored positions per thread
     static_assert(R == 4 && (G == 1 || G == 2 || G == 4), "G must divide the points per thread");
     // register-lean multiply-add / monomial stages: digit points and monomial rows fetched per rotation as they are used (three or four
-    // polynomials; and G = 2 on the 64-bit ring, where holding them spilled 228 B per lane: KMS2partyblock 39.9 -> 34.1 ms, on par with G = 1)
-    constexpr bool LEAN = NP > 2 || (G == 2 && sizeof(WORD) == 8);   // (on the shipped Blockparam kernel, G = 4: 5.27 - 5.35 ms either way)
+    // polynomials; and G = 2, where holding them spilled: 64-bit ring 228 -> 56 B per lane, KMS2partyblock 39.9 -> 34.1 ms, on par with G = 1;
+    // 32-bit ring 168 -> 36 B, Blockparam 6.18 -> 5.65 ms per 1024 gates and -- TWO independent workgroups per compute unit -- 75.8 ms per
+    // 16 384 gates against 79.2 ms for G = 4, whose one eight-wave workgroup idles all four SIMDs at every barrier)
+    constexpr bool LEAN = NP > 2 || G == 2;   // (on the shipped Blockparam kernel, G = 4: 5.27 - 5.35 ms either way)
     constexpr int ORDER = NP > 2 ? MKT_DEVORDER_KR : MKT_DEVORDER;   // context.cpp: the RLWE-length-k contexts keep their tables in order 2
     static_assert(MKT_DEVORDER == 1 && MKT_DEVORDER_KR == 2, "device point orders of the resident tables");
     static_assert(NP >= 2 && NP <= 4, "accumulator polynomials");
