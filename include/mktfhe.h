@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MKT_ABI_VERSION 2
+#define MKT_ABI_VERSION 3
 
 typedef enum {
     MKT_OK = 0,
@@ -55,6 +55,9 @@ typedef enum {
 enum { MKT_CGGI = 0, MKT_LMSS = 1, MKT_CCS = 2, MKT_KMS = 3, MKT_KMS_BLOCK = 4 };
 /* gates: gate.jl:1-53 */
 enum { MKT_NAND = 0, MKT_AND = 1, MKT_OR = 2, MKT_XOR = 3, MKT_XNOR = 4, MKT_NOR = 5 };
+/* per-gate codes of mkt_gate_batch_ops / _gather: a gate of the enum above, optionally with one or both inputs negated first
+ * (NOT!, gate.jl:55-58, folded into the gate's linear part: the same words as NOT! followed by the gate) */
+enum { MKT_OP_NOT_X = 8, MKT_OP_NOT_Y = 16 };
 /* arithmetic modes of the negacyclic transform */
 enum {
     MKT_ARITH_F64REF = 0, /* the reference's Float64 twisted FFT, operation for operation (fft.jl) */
@@ -104,16 +107,28 @@ typedef struct mkt_client_party mkt_client_party;   /* one party's keys (client 
 int mkt_abi_version(void);
 int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx **out);
 int mkt_ctx_destroy(mkt_ctx *ctx);
-/* a second context over the SAME resident keys and tables (no copy; freed with the last context that holds them): own
- * stream, workspace and timing -- one per concurrent caller, matching the reference's contract of one read-only scheme
+/* a second context over the SAME resident keys and tables (no copy; freed with the last context that holds them; both
+ * arithmetic modes): own stream, workspace and timing -- one per concurrent caller, matching the reference's contract of one read-only scheme
  * shared by concurrent bootstrapping! calls (bootstrapping.jl:38-45: all scratch is per call).  Once forked, the key set
  * is immutable: mkt_load_*, mkt_set_twiddles and mkt_keygen_device return MKT_ERR_STATE on every sharer. */
 int mkt_ctx_fork(mkt_ctx *ctx, mkt_ctx **out);
 const char *mkt_last_error(const mkt_ctx *ctx); /* ctx may be NULL: last creation error */
 /* HIP stream (hipStream_t) all subsequent batch calls are enqueued on; NULL = default stream.  The per-batch workspace
- * belongs to the context: calls on one context must not overlap (one context per host thread / stream: mkt_ctx_fork). */
+ * belongs to the context: calls on one context must not overlap (one context per host thread / stream: mkt_ctx_fork).
+ * STREAM ORDER.  A context made by mkt_ctx_create starts on the NULL stream.  A context made by mkt_ctx_fork starts on its
+ * OWN stream, created hipStreamNonBlocking: its calls are NOT ordered against work on the NULL stream or on any other
+ * stream.  A caller that hands MKT_MEM_DEVICE buffers to a fork must order producer and consumer itself: point the fork at
+ * the producing stream (mkt_set_stream), or wait on the fork's stream (mkt_get_stream + events, or mkt_synchronize). */
 int mkt_set_stream(mkt_ctx *ctx, void *hip_stream);
+int mkt_get_stream(mkt_ctx *ctx, void **hip_stream);   /* the stream the context enqueues on right now */
 int mkt_synchronize(mkt_ctx *ctx);
+/* kernel-selection switches (where a step has more than one kernel, parity tests force each; A/B tools): name one of
+ * "rot_variant", "rot_stagger", "rot_split", "rot_wide" (latency variant: 0 auto, 1 never, 2 always), "rot_blkg" (block
+ * schemes, rotations per workgroup: 0 auto, 1, 2, 4), "ccs_stagger", "ccs_pipe" (-1 auto, 0 never, 1 always).  Results never
+ * depend on them.  The environment (MKT_ROT_*, MKT_CCS_*) seeds them once, at mkt_ctx_create; no batch call reads it. */
+int mkt_set_option(mkt_ctx *ctx, const char *name, int value);
+/* base name of the blind-rotation kernel the last batch call of this context launched ("" before the first) */
+const char *mkt_last_kernel_name(const mkt_ctx *ctx);
 
 /* twiddle tables (fft.jl:31-41): which = 0 Psi, 1 Psiinv, 2 roots, 3 rootsinv; M complex each.
  * mkt_set_twiddles lets a caller install the reference's own ffter tables verbatim. */
@@ -153,6 +168,14 @@ int mkt_get_ksk(mkt_ctx *ctx, int party, uint32_t *out_host);                   
 /* ---- hot path, batched: B independent ciphertexts per call (the reference does one per call) ---- */
 /* gate.jl:1-53: out = bootstrapping!(linear(op, x, y)); x, y, out: [B][k*n+1] */
 int mkt_gate_batch(mkt_ctx *ctx, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem);
+/* a different gate per ciphertext pair, one launch sequence for the batch -- the shape of the reference's tests, which draw a
+ * random gate per step (test/KMS.jl:29-34): ops[j] = MKT_NAND .. MKT_NOR, optionally | MKT_OP_NOT_X / MKT_OP_NOT_Y; ops
+ * lives where x, y, out live (`mem`) */
+int mkt_gate_batch_ops(mkt_ctx *ctx, const uint8_t *ops, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem);
+/* one level of a gate circuit: gate j reads rows ix[j] and iy[j] of pool [pool_rows][k*n+1] and writes out[j]; out may be a
+ * later region of the same pool provided no gate of this call reads a row this call writes */
+int mkt_gate_batch_gather(mkt_ctx *ctx, const uint8_t *ops, const uint32_t *pool, size_t pool_rows, const uint32_t *ix,
+                          const uint32_t *iy, uint32_t *out, size_t B, int mem);
 /* gate.jl:55-58 NOT!: in-place negation, no bootstrap */
 int mkt_not_batch(mkt_ctx *ctx, uint32_t *x, size_t B, int mem);
 /* bootstrapping.jl:4-27 bootstrapping!: in place on [B][k*n+1] */
@@ -184,6 +207,40 @@ int mkt_decompose_batch(mkt_ctx *ctx, const void *p, void *digits, int l, int lo
 int mkt_exact_polymul_batch(mkt_ctx *ctx, const void *a, const void *b, void *out, size_t B, int mem);
 /* scheme.jl:121-146: copy monomial table entry e (1..2N) to host, M complex */
 int mkt_get_monomial(mkt_ctx *ctx, int e, double *out_host);
+
+/* ---- one evaluator over several GPUs, one caller process (the reference's caller is ONE process whose threads
+ *      share one read-only scheme: README.md:38-44, bootstrapping.jl:38-45).  Shard i runs on HIP device devices[i]; naming a
+ *      device more than once makes logical shards that share that device's ONE key set (forked contexts).  Keys are loaded /
+ *      generated once, on devices[0]; mkt_multi_replicate copies the resident pre-transformed tables to the other devices
+ *      (hipMemcpyPeer over xGMI; host bounce if refused) and seals them.  A batch call cuts [0, B) into contiguous balanced
+ *      slices (the first B mod nshards slices hold one more: mkt_multi_shard_range), one host thread per shard, every shard
+ *      writing its slice of the caller's ONE output array; no collective.  MKT_MEM_DEVICE arrays may live on any of the
+ *      devices (slices are peer-copied to and from the shards on other devices).  Calls return when all shards are done. ---- */
+typedef struct mkt_multi mkt_multi;
+/* flags: MKT_MULTI_PRIVATE_KEYS = shards that share a device do NOT share its key set: each gets its own replicated copy, as
+ * shards on distinct devices do (exercises the device-to-device replication on a one-GPU box; costs one key copy per shard) */
+enum { MKT_MULTI_PRIVATE_KEYS = 1 };
+int mkt_multi_create(const mkt_params *params, int arith_mode, const int *devices, int nshards, int flags, mkt_multi **out);
+int mkt_multi_destroy(mkt_multi *m);
+const char *mkt_multi_last_error(const mkt_multi *m);  /* m may be NULL: last creation error */
+int mkt_multi_nshards(const mkt_multi *m);
+int mkt_multi_device(const mkt_multi *m, int shard);
+mkt_ctx *mkt_multi_ctx(mkt_multi *m, int shard);        /* borrowed: timing (mkt_enable_timing), kernel names; NULL for a logical shard before mkt_multi_replicate */
+int mkt_multi_shard_range(const mkt_multi *m, size_t B, int shard, size_t *lo, size_t *hi);
+int mkt_multi_load_brk(mkt_multi *m, int party, const void *data, int fmt);
+int mkt_multi_load_ksk(mkt_multi *m, int party, const uint32_t *data);
+int mkt_multi_load_rlk(mkt_multi *m, int party, const void *d, const void *f, int fmt);
+int mkt_multi_load_pubkey(mkt_multi *m, int party, const void *b, int fmt);
+int mkt_multi_load_crs(mkt_multi *m, const void *a, int fmt);
+int mkt_multi_keygen_device(mkt_multi *m, int party, const mkt_client_party *keys, const void *crs);
+int mkt_multi_replicate(mkt_multi *m);
+int mkt_multi_set_option(mkt_multi *m, const char *name, int value);
+int mkt_multi_gate_batch(mkt_multi *m, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem);
+int mkt_multi_gate_batch_ops(mkt_multi *m, const uint8_t *ops, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem);
+int mkt_multi_bootstrap_batch(mkt_multi *m, uint32_t *lwe, size_t B, int mem);
+int mkt_multi_not_batch(mkt_multi *m, uint32_t *x, size_t B, int mem);
+int mkt_multi_blindrotate_batch(mkt_multi *m, const uint32_t *atilde, void *acc, size_t B, int mem);
+int mkt_multi_keyswitch_batch(mkt_multi *m, const void *acc, uint32_t *out, size_t B, int mem);
 
 /* Device-time accounting with hipEvents recorded on the context's stream around each kernel class:
  * mkt_enable_timing(ctx, 1) clears and starts recording, mkt_last_kernel_ms stores the TOTAL ms of

@@ -7,7 +7,7 @@ path (bootstrapping!, blindrotate!, keyswitch!, NAND/AND/OR/XOR/XNOR/NOR/NOT!) b
 from .params import *  # noqa: F401,F403
 from .params import Params  # noqa: F401
 from .scheme import (  # noqa: F401
-    CRS, PartyKeys, Scheme, party_keygen, setup, lwe_encrypt, lwe_ith_encrypt, lwe_decrypt,
+    CRS, PartyKeys, Scheme, MultiScheme, party_keygen, setup, setup_multi, OP_NOT_X, OP_NOT_Y, lwe_encrypt, lwe_ith_encrypt, lwe_decrypt,
     bootstrapping_, blindrotate_, keyswitch, NAND, AND, OR, XOR, XNOR, NOR, NOT_, MUX,
     MEM_DEVICE, MEM_HOST, FMT_INT_COEFF, FMT_F64_FFT, ARITH_F64REF, ARITH_EXACT,
 )

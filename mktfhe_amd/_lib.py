@@ -34,7 +34,10 @@ SYMBOLS = {
     "mkt_ctx_fork": (_i, [_vp, C.POINTER(_vp)]),
     "mkt_last_error": (C.c_char_p, [_vp]),
     "mkt_set_stream": (_i, [_vp, _vp]),
+    "mkt_get_stream": (_i, [_vp, C.POINTER(_vp)]),
     "mkt_synchronize": (_i, [_vp]),
+    "mkt_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "mkt_last_kernel_name": (C.c_char_p, [_vp]),
     "mkt_get_twiddles": (_i, [_vp, _i, _vp]),
     "mkt_set_twiddles": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mkt_make_twiddles": (_i, [_i, _i, _vp]),
@@ -47,6 +50,8 @@ SYMBOLS = {
     "mkt_keygen_device_export": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "mkt_get_ksk": (_i, [_vp, _i, _vp]),
     "mkt_gate_batch": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "mkt_gate_batch_ops": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "mkt_gate_batch_gather": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _i]),
     "mkt_not_batch": (_i, [_vp, _vp, _sz, _i]),
     "mkt_bootstrap_batch": (_i, [_vp, _vp, _sz, _i]),
     "mkt_modswitch_batch": (_i, [_vp, _vp, _vp, _vp, _sz, _i]),
@@ -58,6 +63,27 @@ SYMBOLS = {
     "mkt_decompose_batch": (_i, [_vp, _vp, _vp, _i, _i, _sz, _i]),
     "mkt_exact_polymul_batch": (_i, [_vp, _vp, _vp, _vp, _sz, _i]),
     "mkt_get_monomial": (_i, [_vp, _i, _vp]),
+    "mkt_multi_create": (_i, [_pp, _i, C.POINTER(_i), _i, _i, C.POINTER(_vp)]),
+    "mkt_multi_destroy": (_i, [_vp]),
+    "mkt_multi_last_error": (C.c_char_p, [_vp]),
+    "mkt_multi_nshards": (_i, [_vp]),
+    "mkt_multi_device": (_i, [_vp, _i]),
+    "mkt_multi_ctx": (_vp, [_vp, _i]),
+    "mkt_multi_shard_range": (_i, [_vp, _sz, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "mkt_multi_load_brk": (_i, [_vp, _i, _vp, _i]),
+    "mkt_multi_load_ksk": (_i, [_vp, _i, _vp]),
+    "mkt_multi_load_rlk": (_i, [_vp, _i, _vp, _vp, _i]),
+    "mkt_multi_load_pubkey": (_i, [_vp, _i, _vp, _i]),
+    "mkt_multi_load_crs": (_i, [_vp, _vp, _i]),
+    "mkt_multi_keygen_device": (_i, [_vp, _i, _vp, _vp]),
+    "mkt_multi_replicate": (_i, [_vp]),
+    "mkt_multi_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "mkt_multi_gate_batch": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "mkt_multi_gate_batch_ops": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "mkt_multi_bootstrap_batch": (_i, [_vp, _vp, _sz, _i]),
+    "mkt_multi_not_batch": (_i, [_vp, _vp, _sz, _i]),
+    "mkt_multi_blindrotate_batch": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "mkt_multi_keyswitch_batch": (_i, [_vp, _vp, _vp, _sz, _i]),
     "mkt_enable_timing": (_i, [_vp, _i]),
     "mkt_last_kernel_ms": (_i, [_vp, _i, C.POINTER(_dbl)]),
     "mkt_client_random_seed": (_i, [_vp]),

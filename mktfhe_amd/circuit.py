@@ -1,9 +1,10 @@
 """Levelised gate-circuit evaluation on top of the batched gate primitive.
 
-The reference's tests fold gates one at a time (test/KMS.jl:29-34).  Here a circuit is a DAG of two-input
-bootstrapped gates (gate.jl:1-53) and free NOTs (gate.jl:55-58); gates of equal depth and equal type are
-evaluated in ONE mkt_gate_batch call, over all `B` independent input sets at once, with ciphertexts staying
-where they are (GPU tensors stay in HBM between levels).
+The reference's tests fold gates one at a time, a random gate per step (test/KMS.jl:29-34).  Here a circuit is a DAG of
+two-input bootstrapped gates (gate.jl:1-53) and free NOTs (gate.jl:55-58); ALL gates of equal depth -- whatever their
+type -- are evaluated in ONE engine call over all `B` independent input sets at once (mkt_gate_batch_gather: a per-gate op
+code, operands picked by row index from a ciphertext pool that stays in HBM, NOTs folded into the gate's linear part), so a
+level costs one round of launches however many gate kinds it mixes.
 """
 from collections import defaultdict
 
@@ -108,13 +109,80 @@ def evaluate(circ: Circuit, inputs, gate_fn, not_fn):
     return [resolve(w) for w in circ.outputs]
 
 
-def evaluate_on(circ: Circuit, inputs, scheme):
-    """evaluate with an engine Scheme (GPU tensors or numpy arrays)"""
-    def not_fn(x):
-        y = x.clone() if hasattr(x, "clone") else x.copy()
-        scheme.not_(y)
-        return y
-    return evaluate(circ, inputs, lambda op, x, y: scheme.gate(op, x, y), not_fn)
+class Plan:
+    """The launch schedule of a circuit over B instances: one mkt_gate_batch_gather per level.  Pool rows: node slot s,
+    instance b -> row s * B + b; slots 0 .. n_inputs-1 are the inputs, then the gates level by level (so a level's outputs
+    are one contiguous region of the pool); NOT nodes own no slot -- they resolve to (slot of their source, negated)."""
+
+    def __init__(self, circ: Circuit, B):
+        depth, sched = circ.levels()
+        self.B, self.n_inputs = B, circ.n_inputs
+        slot, neg = [None] * len(circ.nodes), [False] * len(circ.nodes)
+        for i, (op, a, _) in enumerate(circ.nodes):
+            if op == "in":
+                slot[i] = a
+        nslots = circ.n_inputs
+        order = []
+        for lvl in sorted(sched):
+            ids = sorted(i for lst in sched[lvl].values() for i in lst)
+            for i in ids:
+                slot[i] = nslots
+                nslots += 1
+            order.append(ids)
+
+        def src(i):                      # -> (slot, negated) through chains of NOTs
+            n = False
+            while circ.nodes[i][0] == _NOT:
+                n = not n
+                i = circ.nodes[i][1]
+            return slot[i], n
+
+        inst = np.arange(B, dtype=np.uint32)
+        self.levels = []
+        for ids in order:
+            ops = np.empty((len(ids), B), dtype=np.uint8)
+            ix = np.empty((len(ids), B), dtype=np.uint32)
+            iy = np.empty((len(ids), B), dtype=np.uint32)
+            for j, i in enumerate(ids):
+                op, a, b = circ.nodes[i]
+                (sa, na), (sb, nb) = src(a), src(b)
+                ops[j] = op | (8 if na else 0) | (16 if nb else 0)
+                ix[j] = sa * B + inst
+                iy[j] = sb * B + inst
+            self.levels.append((slot[ids[0]], len(ids), ops.ravel(), ix.ravel(), iy.ravel()))
+        self.rows = nslots * B
+        self.gates = sum(n for _, n, _, _, _ in self.levels) * B
+        self.outputs = [src(w) for w in circ.outputs]
+
+
+def evaluate_on(circ: Circuit, inputs, scheme, plan: Plan = None):
+    """evaluate with an engine Scheme (GPU tensors or numpy arrays): one engine call per LEVEL (all gate kinds merged)."""
+    B = inputs[0].shape[0]
+    plan = plan or Plan(circ, B)
+    assert plan.B == B and len(inputs) == plan.n_inputs
+    lwe_len = inputs[0].shape[1]
+    on_gpu = type(inputs[0]).__module__.startswith("torch")
+    if on_gpu:
+        import torch
+        dev = inputs[0].device
+        pool = torch.empty((plan.rows, lwe_len), dtype=inputs[0].dtype, device=dev)
+        up = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev)   # noqa: E731
+    else:
+        pool = np.empty((plan.rows, lwe_len), dtype=np.uint32)
+        up = lambda a: a                                                                              # noqa: E731
+    for s, x in enumerate(inputs):
+        pool[s * B:(s + 1) * B] = x
+    for slot0, ngates, ops, ix, iy in plan.levels:
+        out = pool[slot0 * B:(slot0 + ngates) * B]
+        scheme.gate_gather(up(ops), pool, up(ix), up(iy), out)
+    res = []
+    for sl, negated in plan.outputs:
+        o = pool[sl * B:(sl + 1) * B]
+        o = o.clone() if on_gpu else o.copy()
+        if negated:
+            scheme.not_(o)
+        res.append(o)
+    return res
 
 
 def ripple_adder(nbits):

@@ -210,6 +210,7 @@ static hipError_t launch_ccs_pipe_one(const CcsArgs &a, size_t B, hipStream_t s)
     constexpr size_t LB = ((size_t)P::M + 2 * P::LDS_CPLX) * sizeof(cplx);
     if constexpr (2 * P::NT > 1024 || LB > 160 * 1024) { return hipErrorInvalidValue; } else {
         hipError_t e = set_lds(ccs_pipe_kernel<LM, WORD, LT, BT>, LB); if (e != hipSuccess) return e;
+        last_rot_kernel = "ccs_pipe_kernel";
         hipLaunchKernelGGL((ccs_pipe_kernel<LM, WORD, LT, BT>), dim3((unsigned)B), dim3(2 * P::NT), LB, s, a);
         return hipGetLastError();
     }

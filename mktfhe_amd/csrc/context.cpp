@@ -22,7 +22,42 @@ namespace {
 thread_local std::string g_create_error;
 
 struct TimedSpan { int cls; hipEvent_t a, b; };
+
+int env_int(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+
+// Kernel-selection switches of one context (A/B runs and the parity tests that force every kernel variant).  The
+// environment seeds them ONCE, at mkt_ctx_create; afterwards only mkt_set_option changes them -- the call path never
+// reads the environment.
+struct Tune {
+    int rot_variant = 0;
+    int rot_stagger = 16;   // tools/stagger.sh: 16.99 -> 15.63 ms at KMS k=2 N=1024 on one device, neutral elsewhere
+    int rot_split = 0;
+    int rot_wide = 0;       // latency variant: 0 automatic, 1 never, 2 always where supported
+    int rot_blkg = 0;       // block schemes: rotations per workgroup, 0 automatic
+    int ccs_stagger = 0;
+    int ccs_pipe = -1;      // two-group CCS kernel: -1 automatic (below one chip-fill), 0 never, 1 always
+    void from_env() {
+        rot_variant = env_int("MKT_ROT_VARIANT", rot_variant); rot_stagger = env_int("MKT_ROT_STAGGER", rot_stagger);
+        rot_split = env_int("MKT_ROT_SPLIT", rot_split); rot_wide = env_int("MKT_ROT_WIDE", rot_wide);
+        rot_blkg = env_int("MKT_ROT_BLKG", rot_blkg); ccs_stagger = env_int("MKT_CCS_STAGGER", ccs_stagger);
+        ccs_pipe = env_int("MKT_CCS_PIPE", ccs_pipe);
+    }
+};
 }  // namespace
+
+thread_local const char *mktd::last_rot_kernel = "";
+
+// launcher-level switches (grid shapes of the transform and key-switch kernels): process-wide, read from the environment
+// on first use only (device_api.h)
+const mktd::LaunchTuning &mktd::launch_tuning() {
+    static const LaunchTuning t = [] {
+        LaunchTuning q{};
+        q.fft_grid = env_int("MKT_FFT_GRID", 0); q.fft_nb = env_int("MKT_FFT_NB", 1); q.fft_igrid = env_int("MKT_FFT_IGRID", 0);
+        q.ks_g = env_int("MKT_KS_G", 32); q.ks_blocks = env_int("MKT_KS_BLOCKS", 0); q.ks_waves = env_int("MKT_KS_WAVES", 0);
+        return q;
+    }();
+    return t;
+}
 
 // The evaluation keys and tables of one scheme on one device: immutable once a second context shares them
 // (mkt_ctx_fork), freed when the last context that holds them is destroyed.  This is the reference's scheme object
@@ -40,11 +75,12 @@ struct KeySet {
     // rotation slots (KMS phase 1: party-major rows)
     int rtot = 1;
     int *d_slot_party = nullptr, *d_slot_row = nullptr;
+    uint64_t *d_ntt = nullptr;   // MKT_ARITH_EXACT: psi_rev (negated) | psiinv_rev | N^-1, N^-1 w | N^-1 2^32, N^-1 2^32 w, with Shoup companions
     ~KeySet() {
         int prev = -1;
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != device) (void)hipSetDevice(device);
-        void *ptrs[] = {d_tw, d_monomial, d_brk, d_ksk, d_rlk_d, d_rlk_f, d_pub, d_crs, d_slot_party, d_slot_row};
+        void *ptrs[] = {d_tw, d_monomial, d_brk, d_ksk, d_rlk_d, d_rlk_f, d_pub, d_crs, d_slot_party, d_slot_row, d_ntt};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     }
@@ -60,8 +96,8 @@ struct mkt_ctx {
     hipStream_t own_stream = nullptr;   // a fork's own non-blocking stream (destroyed with the context); `stream` may be re-pointed by mkt_set_stream
     std::string err;
     std::shared_ptr<KeySet> ks;  // shared with the contexts forked from this one
-    bool exact = false;          // MKT_ARITH_EXACT (integer NTT, two 30-bit primes); d_ntt = psi_rev (negated) | psiinv_rev | N^-1, N^-1 w | N^-1 2^32, N^-1 2^32 w, with Shoup companions
-    uint64_t *d_ntt = nullptr;
+    bool exact = false;          // MKT_ARITH_EXACT (integer NTT, two 30-bit primes)
+    uint64_t *d_ntt = nullptr;   // = ks->d_ntt (owned by the key set: shared by forks)
     int split = 1;               // EXACT on the 64-bit ring: every resident 64-bit table is kept as (low, high) residue polynomials -> 2 per logical polynomial
     // workspace
     size_t ws_gates = 0;
@@ -71,6 +107,8 @@ struct mkt_ctx {
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;
+    Tune tune;
+    const char *last_rot_kernel = "";   // name of the blind-rotation kernel the last call launched (mkt_last_kernel_name)
 
     mktd::TwPtrs twp() const { return mktd::TwPtrs{ks->d_tw, ks->d_tw + M, ks->d_tw + 2 * (size_t)M, ks->d_tw + 3 * (size_t)M}; }
     bool keys_shared() const { return ks.use_count() > 1; }
@@ -96,7 +134,10 @@ struct Timer {
         if (c->timing && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, c->stream);
         else a = b = nullptr;
     }
-    ~Timer() { if (a && b) { (void)hipEventRecord(b, c->stream); c->spans.push_back(TimedSpan{cls, a, b}); } }
+    ~Timer() {
+        if (cls == 1) c->last_rot_kernel = mktd::last_rot_kernel;   // the blind-rotation launcher noted which kernel it picked
+        if (a && b) { (void)hipEventRecord(b, c->stream); c->spans.push_back(TimedSpan{cls, a, b}); }
+    }
 };
 
 void clear_spans(mkt_ctx *c) {
@@ -217,12 +258,8 @@ mktd::RotArgs rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
     a.blk_accum = mkt::is_block(p.scheme) ? 1 : 0;
     a.rows_per_gate = c->ks->rtot; a.slot_party = c->ks->d_slot_party; a.slot_row = c->ks->d_slot_row;
     a.logB_lev = p.logB_lev; a.dev_order = c->dev_order;
-    if (const char *v = getenv("MKT_ROT_VARIANT")) a.variant = atoi(v);
-    a.stagger = 16;   // tools/stagger.sh: 16.99 -> 15.63 ms at KMS k=2 N=1024 on one device, neutral elsewhere
-    if (const char *v = getenv("MKT_ROT_STAGGER")) a.stagger = atoi(v);
-    if (const char *v = getenv("MKT_ROT_SPLIT")) a.split = (unsigned)atoi(v);
-    if (const char *v = getenv("MKT_ROT_WIDE")) a.wide = atoi(v);
-    if (const char *v = getenv("MKT_ROT_BLKG")) a.blk_group = atoi(v);
+    a.variant = c->tune.rot_variant; a.stagger = c->tune.rot_stagger; a.split = (unsigned)c->tune.rot_split;
+    a.wide = c->tune.rot_wide; a.blk_group = c->tune.rot_blkg;
     return a;
 }
 
@@ -244,12 +281,10 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         q.tw = c->twp(); q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.logN = c->logN; q.k = p.k;
         q.l = p.l_uni; q.logB = p.logB_uni; q.brk = c->ks->d_brk; q.brk_party_stride = c->ks->brk_party_cplx; q.pub_b = c->ks->d_pub; q.crs = c->ks->d_crs;
         q.monomial = c->ks->d_monomial; q.acc = acc; q.scratch = scratch; q.vscratch = lev;
-        q.stagger = 0; q.dev_order = c->dev_order;
-        if (const char *v = getenv("MKT_CCS_STAGGER")) q.stagger = atoi(v);
-        // batches that leave compute units idle run each ciphertext on two thread groups (ccs_pipe.hip); MKT_CCS_PIPE: 0 never,
-        // 1 always, unset: below one chip-fill of one-group workgroups (4 per CU at M = 512, 2 at M = 1024)
-        int pipe = -1;
-        if (const char *v = getenv("MKT_CCS_PIPE")) pipe = atoi(v);
+        q.stagger = c->tune.ccs_stagger; q.dev_order = c->dev_order;
+        // batches that leave compute units idle run each ciphertext on two thread groups (ccs_pipe.hip); option ccs_pipe: 0 never,
+        // 1 always, -1: below one chip-fill of one-group workgroups (4 per CU at M = 512, 2 at M = 1024)
+        const int pipe = c->tune.ccs_pipe;
         const size_t fill = (size_t)256 * (c->logM <= 9 ? 4 : 2);
         const bool use_pipe = pipe == 1 || (pipe < 0 && B * 2 <= fill);
         Timer tm(c, 1);
@@ -387,7 +422,8 @@ int upload_ntt_tables(mkt_ctx *c) {
         const uint32_t cs[4] = {ninv, ntt_mulmod(ninv, wlast, p), ninv_r, ntt_mulmod(ninv_r, wlast, p)};
         for (int q = 0; q < 4; q++) { tab[(size_t)(2 * N + q) * 4 + 2 * k] = cs[q]; tab[(size_t)(2 * N + q) * 4 + 2 * k + 1] = ntt_shoup(cs[q], p); }
     }
-    HIPCHK(c, hipMalloc((void **)&c->d_ntt, tab.size() * 4));
+    HIPCHK(c, hipMalloc((void **)&c->ks->d_ntt, tab.size() * 4));
+    c->d_ntt = c->ks->d_ntt;
     HIPCHK(c, hipMemcpy(c->d_ntt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     return MKT_OK;
 }
@@ -413,7 +449,9 @@ bool exact_gate_ok(const mkt_ctx *c) {
     const bool lmss = p.scheme == MKT_LMSS;
     if (!((p.scheme == MKT_CGGI || lmss) && p.k == 1 && p.W == 32)) return false;
     if (lmss && p.blk_len != 3) return false;             // the block length the kernel is instantiated for (params.jl:8-13)
-    const double bound = (lmss ? 2.0 * p.blk_len : 1.0) * 2.0 * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n31;
+    // the kernel multiplies the product sum by the monomial X^a - 1 in the transform domain BEFORE the one lift (ntt_exact.hip
+    // exact_blindrotate_kernel: s2 = tacc * mono), so the lifted integer is up to twice the sum -- for CGGI as for a block
+    const double bound = 2.0 * (lmss ? p.blk_len : 1.0) * 2.0 * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n31;
     return bound < half_P;
 }
 #define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1, 32-bit ring, block length 3) for CCS (32-bit ring) and for KMS / KMS_block (64-bit ring, tables split in 32-bit halves), gadgets within the two-prime modulus; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
@@ -454,6 +492,7 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     c->split = (c->exact && params->W == 64) ? 2 : 1;
     // the RLWE-length-k kernels of the plain schemes want the slot-pair order, everything else the slot-major one (fft_device.h)
     c->dev_order = ((params->scheme == MKT_CGGI || params->scheme == MKT_LMSS) && params->k > 1) ? MKT_DEVORDER_KR : MKT_DEVORDER;
+    c->tune.from_env();   // the one place the MKT_ROT_* / MKT_CCS_* environment is read; mkt_set_option afterwards
     DevGuard dg(device);
     auto bail = [&](int code) { std::string m = c->err; mkt_ctx_destroy(c); g_create_error = m; return code; };
     if (!dg.ok) { c->err = "hipSetDevice failed"; return bail(MKT_ERR_HIP); }
@@ -465,6 +504,9 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     CK(hipMalloc((void **)&c->ks->d_tw, (size_t)4 * M * sizeof(cplx)));
     CK(hipMalloc((void **)&c->ks->d_monomial, (size_t)2 * N * M * sizeof(cplx)));
     c->ks->brk_party_cplx = (size_t)p.n * c->sh.brk_polys * M * c->split;
+    // the rotation kernels read a party's key rows through one buffer descriptor (kernel_common.h table_rsrc: 31-bit record
+    // count, 32-bit row offsets); a larger key would read zeros silently, so it is refused here (largest shipped set: 0.25 GB)
+    if (c->ks->brk_party_cplx * sizeof(cplx) > 0x7fffffffull) { c->err = "per-party bootstrapping key exceeds the 2 GiB window of the rotation kernels' buffer descriptors"; return bail(MKT_ERR_UNSUPPORTED); }
     CK(hipMalloc((void **)&c->ks->d_brk, (size_t)np * c->ks->brk_party_cplx * sizeof(cplx)));
     c->ks->n1p = (p.n + 1 + 3) / 4 * 4;   // device rows padded to 16 B
     c->ks->ksk_party_words = (size_t)c->sh.ksk_kr * N * c->sh.ksk_drows * p.f * c->ks->n1p;
@@ -500,10 +542,11 @@ int mkt_ctx_destroy(mkt_ctx *c) {
     if (!c) return MKT_OK;
     DevGuard dg(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);   // before the workspace goes: work queued on the fork's own stream may still use it
     clear_spans(c);
-    void *ptrs[] = {c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch, c->d_ntt};
+    void *ptrs[] = {c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); (void)hipStreamDestroy(c->own_stream); }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;                      // drops this context's reference to the key set; the last one frees it
     return MKT_OK;
 }
@@ -514,10 +557,9 @@ int mkt_ctx_destroy(mkt_ctx *c) {
 // mkt_keygen_device return MKT_ERR_STATE on every context that shares it).
 int mkt_ctx_fork(mkt_ctx *c, mkt_ctx **out) {
     if (!c || !out) return fail(c, MKT_ERR_ARG, "null argument");
-    MKT_F64_ONLY(c);
     auto *f = new mkt_ctx();
     f->p = c->p; f->sh = c->sh; f->device = c->device; f->logM = c->logM; f->logN = c->logN; f->M = c->M; f->dev_order = c->dev_order;
-    f->ks = c->ks;
+    f->ks = c->ks; f->exact = c->exact; f->split = c->split; f->d_ntt = c->d_ntt; f->tune = c->tune;
     // the fork's own stream: non-blocking, so forks driven from several host threads neither serialise on the NULL stream
     // nor against each other; mkt_set_stream may re-point the context at a caller's stream later
     {
@@ -530,7 +572,73 @@ int mkt_ctx_fork(mkt_ctx *c, mkt_ctx **out) {
     return MKT_OK;
 }
 
+// ---- internal (multi.cpp): replicate the resident, pre-transformed key set of `src` onto `dst`'s device ----
+// dst is a fresh context of the same parameters and arithmetic on another device.  Device-to-device with hipMemcpyPeer (xGMI
+// when the devices are linked; the runtime stages through the host otherwise); if the peer copy is refused, an explicit host
+// bounce.  The key upload and its transforms run ONCE, on src's device ("optional one-time device-to-device key copy").
+static int copy_across(mkt_ctx *dst, void *d, int ddev, const void *s_, int sdev, size_t bytes) {
+    if (!bytes) return MKT_OK;
+    if (hipMemcpyPeer(d, ddev, s_, sdev, bytes) == hipSuccess) return MKT_OK;
+    (void)hipGetLastError();
+    std::vector<unsigned char> bounce(bytes);
+    { DevGuard g(sdev); HIPCHK(dst, hipMemcpy(bounce.data(), s_, bytes, hipMemcpyDeviceToHost)); }
+    { DevGuard g(ddev); HIPCHK(dst, hipMemcpy(d, bounce.data(), bytes, hipMemcpyHostToDevice)); }
+    return MKT_OK;
+}
+int mkt_internal_clone_keys(mkt_ctx *src, mkt_ctx *dst) {
+    if (!src || !dst) return MKT_ERR_ARG;
+    if (std::memcmp(&src->p, &dst->p, sizeof(mkt_params)) != 0 || src->exact != dst->exact) return fail(dst, MKT_ERR_ARG, "key replication between contexts of different parameters");
+    if (dst->keys_shared()) return fail(dst, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
+    { DevGuard g(src->device); HIPCHK(dst, hipStreamSynchronize(src->stream)); }
+    const mkt_params &p = src->p;
+    const int np = src->sh.nparty, M = src->M, N = p.N, sd = src->device, dd = dst->device;
+    KeySet &a = *src->ks, &b = *dst->ks;
+    const size_t cb = sizeof(cplx);
+    int r;
+    // tables a caller may have replaced on src (mkt_set_twiddles), and the monomial table that depends on them
+    b.tw = a.tw;
+    if ((r = copy_across(dst, b.d_tw, dd, a.d_tw, sd, (size_t)4 * M * cb))) return r;
+    if ((r = copy_across(dst, b.d_monomial, dd, a.d_monomial, sd, (size_t)2 * N * M * cb))) return r;
+    if ((r = copy_across(dst, b.d_brk, dd, a.d_brk, sd, (size_t)np * a.brk_party_cplx * cb))) return r;
+    if ((r = copy_across(dst, b.d_ksk, dd, a.d_ksk, sd, (size_t)np * a.ksk_party_words * 4))) return r;
+    if (mkt::is_mk(p.scheme)) {
+        if ((r = copy_across(dst, b.d_pub, dd, a.d_pub, sd, (size_t)np * p.l_uni * M * cb * src->split))) return r;
+        if ((r = copy_across(dst, b.d_crs, dd, a.d_crs, sd, (size_t)p.l_uni * M * cb * src->split))) return r;
+    }
+    if (mkt::is_kms(p.scheme)) {
+        if ((r = copy_across(dst, b.d_rlk_d, dd, a.d_rlk_d, sd, (size_t)np * p.l_uni * M * cb * src->split))) return r;
+        if ((r = copy_across(dst, b.d_rlk_f, dd, a.d_rlk_f, sd, (size_t)np * p.l_uni * 2 * M * cb * src->split))) return r;
+    }
+    b.brk_loaded = a.brk_loaded; b.ksk_loaded = a.ksk_loaded; b.rlk_loaded = a.rlk_loaded; b.pub_loaded = a.pub_loaded; b.crs_loaded = a.crs_loaded;
+    dst->tune = src->tune;
+    return MKT_OK;
+}
+int mkt_internal_device_of(const mkt_ctx *c) { return c ? c->device : -1; }
+size_t mkt_internal_lwe_len(const mkt_ctx *c) { return c ? (size_t)c->sh.lwe_len : 0; }
+size_t mkt_internal_acc_bytes(const mkt_ctx *c) { return c ? (size_t)(1 + c->sh.kacc) * poly_bytes(c) : 0; }
+
 int mkt_set_stream(mkt_ctx *c, void *hip_stream) { if (!c) return MKT_ERR_ARG; c->stream = (hipStream_t)hip_stream; return MKT_OK; }
+
+int mkt_get_stream(mkt_ctx *c, void **hip_stream) { if (!c || !hip_stream) return MKT_ERR_ARG; *hip_stream = (void *)c->stream; return MKT_OK; }
+
+// kernel-selection switches (parity tests force every kernel variant through this; A/B tools may seed them from the
+// MKT_ROT_* / MKT_CCS_* environment, which is read once at mkt_ctx_create)
+int mkt_set_option(mkt_ctx *c, const char *name, int value) {
+    if (!c || !name) return fail(c, MKT_ERR_ARG, "null argument");
+    const std::string k(name);
+    Tune &t = c->tune;
+    if (k == "rot_variant") t.rot_variant = value;
+    else if (k == "rot_stagger") t.rot_stagger = value;
+    else if (k == "rot_split") t.rot_split = value;
+    else if (k == "rot_wide") t.rot_wide = value;
+    else if (k == "rot_blkg") t.rot_blkg = value;
+    else if (k == "ccs_stagger") t.ccs_stagger = value;
+    else if (k == "ccs_pipe") t.ccs_pipe = value;
+    else return fail(c, MKT_ERR_ARG, "mkt_set_option: unknown option '" + k + "'");
+    return MKT_OK;
+}
+
+const char *mkt_last_kernel_name(const mkt_ctx *c) { return c ? c->last_rot_kernel : ""; }
 
 int mkt_synchronize(mkt_ctx *c) {
     if (!c) return MKT_ERR_ARG;
@@ -714,23 +822,61 @@ int mkt_get_ksk(mkt_ctx *c, int party, uint32_t *out_host) {
 
 // ---- batched hot path ----
 
-int mkt_gate_batch(mkt_ctx *c, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem) {
-    if (!c || !x || !y || !out || !mem_ok(mem) || op < MKT_NAND || op > MKT_NOR) return fail(c, MKT_ERR_ARG, "bad argument");
+// the gate entry points share one body: `op` for the whole batch or per-gate `ops`; operands in batch order (x, y: [B][len]) or
+// picked by row index from a pool (x = y = pool, [pool_rows][len])
+static int gate_impl(mkt_ctx *c, int op, const uint8_t *ops, const uint32_t *x, const uint32_t *y, size_t rows_xy, const uint32_t *ix, const uint32_t *iy,
+                     uint32_t *out, size_t B, int mem) {
     MKT_EXACT_GATE(c);
     int r;
     if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
     DevGuard dg(c->device);
     Timer whole(c, 0);
     const size_t len = (size_t)c->sh.lwe_len;
-    Staged sx{c}, sy{c}, so{c};
-    if ((r = sx.in(x, B * len * 4, mem, true)) || (r = sy.in(y, B * len * 4, mem, true)) || (r = so.in(out, B * len * 4, mem, false))) return r;
+    const bool pool = ix != nullptr;
+    Staged sx{c}, sy{c}, so{c}, sops{c}, six{c}, siy{c};
+    if ((r = sx.in(x, rows_xy * len * 4, mem, true))) return r;
+    if (pool) sy.dev = sx.dev; else if ((r = sy.in(y, rows_xy * len * 4, mem, true))) return r;
+    if ((r = so.in(out, B * len * 4, mem, false))) return r;
+    if (ops && (r = sops.in(ops, B, mem, true))) return r;
+    if (pool && ((r = six.in(ix, B * 4, mem, true)) || (r = siy.in(iy, B * 4, mem, true)))) return r;
     for (size_t off = 0; off < B; off += CHUNK_GATES) {
         const size_t nb = std::min(CHUNK_GATES, B - off);
         if ((r = ensure_workspace(c, nb))) return r;
-        HIPCHK(c, mktd::launch_gate_linear(op, (const uint32_t *)sx.dev + off * len, (const uint32_t *)sy.dev + off * len, c->ws_lin, (int)len, nb, c->stream));
+        const size_t xoff = pool ? 0 : off * len;
+        HIPCHK(c, mktd::launch_gate_linear(op, ops ? (const uint8_t *)sops.dev + off : nullptr, (const uint32_t *)sx.dev + xoff, (const uint32_t *)sy.dev + xoff,
+                                           pool ? (const uint32_t *)six.dev + off : nullptr, pool ? (const uint32_t *)siy.dev + off : nullptr, c->ws_lin, (int)len, nb, c->stream));
         if ((r = bootstrap_chunk(c, c->ws_lin, (uint32_t *)so.dev + off * len, nb))) return r;
     }
     return so.out(out);
+}
+
+int mkt_gate_batch(mkt_ctx *c, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem) {
+    if (!c || !x || !y || !out || !mem_ok(mem) || op < MKT_NAND || op > MKT_NOR) return fail(c, MKT_ERR_ARG, "bad argument");
+    return gate_impl(c, op, nullptr, x, y, B, nullptr, nullptr, out, B, mem);
+}
+
+// a different gate per ciphertext pair -- the shape of the reference's own tests (test/KMS.jl:29-34 draws a random gate per step;
+// gate.jl:1-53) -- in ONE launch sequence: ops[j] = MKT_NAND .. MKT_NOR, optionally | MKT_OP_NOT_X / MKT_OP_NOT_Y
+static bool ops_valid_host(const uint8_t *ops, size_t B) {
+    for (size_t j = 0; j < B; j++) if ((ops[j] & 7) > MKT_NOR || (ops[j] & ~31u)) return false;
+    return true;
+}
+int mkt_gate_batch_ops(mkt_ctx *c, const uint8_t *ops, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem) {
+    if (!c || !ops || !x || !y || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (mem == MKT_MEM_HOST && !ops_valid_host(ops, B)) return fail(c, MKT_ERR_ARG, "mkt_gate_batch_ops: unknown gate code");
+    return gate_impl(c, 0, ops, x, y, B, nullptr, nullptr, out, B, mem);
+}
+
+// one circuit level: gate j reads pool[ix[j]] and pool[iy[j]] (rows of [pool_rows][k*n+1]) and writes out[j]; `out` may be a
+// later region of the same pool as long as no gate of THIS call reads a row this call writes
+int mkt_gate_batch_gather(mkt_ctx *c, const uint8_t *ops, const uint32_t *pool, size_t pool_rows, const uint32_t *ix, const uint32_t *iy,
+                          uint32_t *out, size_t B, int mem) {
+    if (!c || !ops || !pool || !ix || !iy || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (mem == MKT_MEM_HOST) {
+        if (!ops_valid_host(ops, B)) return fail(c, MKT_ERR_ARG, "mkt_gate_batch_gather: unknown gate code");
+        for (size_t j = 0; j < B; j++) if (ix[j] >= pool_rows || iy[j] >= pool_rows) return fail(c, MKT_ERR_ARG, "mkt_gate_batch_gather: operand index outside the pool");
+    }
+    return gate_impl(c, 0, ops, pool, pool, pool_rows, ix, iy, out, B, mem);
 }
 
 int mkt_not_batch(mkt_ctx *c, uint32_t *x, size_t B, int mem) {

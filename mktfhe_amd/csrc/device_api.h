@@ -10,6 +10,14 @@ struct cplx;
 
 struct TwPtrs { const cplx *psi, *psiinv, *roots, *rootsinv; };
 
+// Launcher-level A/B switches (grid shapes of the transform and key-switch kernels): process-wide, read from the
+// environment on FIRST USE only -- the call path never calls getenv (context.cpp).  0 = the built-in default.
+struct LaunchTuning { int fft_grid, fft_nb, fft_igrid, ks_g, ks_blocks, ks_waves; };
+const LaunchTuning &launch_tuning();
+// base name of the blind-rotation kernel the calling thread launched last (set by every rotation launcher; read by
+// mkt_last_kernel_name so that bench.py's roofline names the kernel that actually ran)
+extern thread_local const char *last_rot_kernel;
+
 // Blind rotation with an RLWE accumulator of length 1 (b, a): CGGI/LMSS with k = 1 and every row of
 // KMS / KMS_block phase 1.  One workgroup per rotation.
 struct RotArgs {
@@ -113,7 +121,8 @@ hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx 
 hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, int to_device, int order, hipStream_t s);
 hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void *p, size_t B, hipStream_t s);
 hipError_t launch_decompose(int W, const void *p, void *digits, int N, int l, int logB, size_t B, hipStream_t s);
-hipError_t launch_gate_linear(int op, const uint32_t *x, const uint32_t *y, uint32_t *out, int len, size_t B, hipStream_t s);
+// ops / ix / iy may be NULL: one op for the batch / operands in batch order (kernels.hip gate_linear_kernel)
+hipError_t launch_gate_linear(int op, const uint8_t *ops, const uint32_t *x, const uint32_t *y, const uint32_t *ix, const uint32_t *iy, uint32_t *out, int len, size_t B, hipStream_t s);
 hipError_t launch_negate(uint32_t *x, size_t words, hipStream_t s);
 hipError_t launch_modswitch(const uint32_t *lwe, uint32_t *atilde, uint32_t *btilde, int len, int logN, size_t B, hipStream_t s);
 hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int logN, int kacc, void *acc, size_t B, hipStream_t s);

@@ -183,13 +183,20 @@ __global__ void reorder_kernel(const cplx *__restrict__ in, cplx *__restrict__ o
 // ------------------------------------------------------------------------------------------------
 // gate.jl:1-58, bootstrapping.jl:8-23: linear part, mod-switch, test vector
 // ------------------------------------------------------------------------------------------------
-__global__ void gate_linear_kernel(int op, const uint32_t *__restrict__ x, const uint32_t *__restrict__ y,
-                                   uint32_t *__restrict__ out, int len, size_t total) {
+// `ops` (optional): one code per gate -- bits 0-2 the gate, bit 3 / bit 4 = the x / y input is negated first (NOT!, gate.jl:55-58,
+// folded into the linear part: -x is what NOT! leaves in memory); `ix` / `iy` (optional): row of the x / y operand in a
+// ciphertext pool (a circuit level reads its operands where the earlier levels left them)
+__global__ void gate_linear_kernel(int op_all, const uint8_t *__restrict__ ops, const uint32_t *__restrict__ x, const uint32_t *__restrict__ y,
+                                   const uint32_t *__restrict__ ix, const uint32_t *__restrict__ iy, uint32_t *__restrict__ out, int len, size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const bool isb = (int)(i % len) == len - 1;
-        const uint32_t a = x[i], b = y[i];
+        const size_t g = i / len; const int c = (int)(i % len);
+        const bool isb = c == len - 1;
+        const int code = ops ? ops[g] : op_all;
+        uint32_t a = x[(ix ? (size_t)ix[g] : g) * len + c], b = y[(iy ? (size_t)iy[g] : g) * len + c];
+        if (code & 8) a = 0u - a;
+        if (code & 16) b = 0u - b;
         uint32_t r;
-        switch (op) {
+        switch (code & 7) {
         case 0:  r = (isb ? (1u << 29) : 0u) - a - b; break;              // NAND gate.jl:1-8
         case 1:  r = (isb ? (7u << 29) : 0u) + a + b; break;              // AND  :10-17
         case 2:  r = (isb ? (1u << 29) : 0u) + a + b; break;              // OR   :19-26
@@ -1116,9 +1123,8 @@ hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx 
     if (B == 0) return hipSuccess;
     // swept on MI355X (tools/fft_sweep.py): with nontemporal streams many short-lived workgroups (8-16 polynomials each
     // at a 4 GiB batch) beat few long-lived ones, as a flat copy beats a grid-stride one on this part (tools/membench2.hip)
-    int gmax = 32768, nbt = 1;
-    if (const char *e = getenv("MKT_FFT_GRID")) { if (atoi(e) > 0) gmax = atoi(e); }
-    if (const char *e = getenv("MKT_FFT_NB")) nbt = atoi(e);
+    const LaunchTuning &lt = launch_tuning();
+    const int gmax = lt.fft_grid > 0 ? lt.fft_grid : 32768, nbt = lt.fft_nb;
     MKT_DISPATCH_LOGM(logM, {
         if (nbt == 2 && LM <= 10) {
             if (W == 64) return launch_fwd_one<LM, uint64_t, 2>(tw, p, t, B, dev_order, gmax, s);
@@ -1140,8 +1146,7 @@ hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, in
 
 hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void *p, size_t B, hipStream_t s) {
     if (B == 0) return hipSuccess;
-    size_t gmax = 32768;
-    if (const char *e = getenv("MKT_FFT_IGRID")) { if (atoi(e) > 0) gmax = (size_t)atoi(e); }
+    const size_t gmax = launch_tuning().fft_igrid > 0 ? (size_t)launch_tuning().fft_igrid : 32768;
     const int grid = (int)(B < gmax ? B : gmax);
     MKT_DISPATCH_LOGM(logM, {
         using P = Plan<LM, LOGR>;
@@ -1166,10 +1171,10 @@ hipError_t launch_decompose(int W, const void *p, void *digits, int N, int l, in
     return hipGetLastError();
 }
 
-hipError_t launch_gate_linear(int op, const uint32_t *x, const uint32_t *y, uint32_t *out, int len, size_t B, hipStream_t s) {
+hipError_t launch_gate_linear(int op, const uint8_t *ops, const uint32_t *x, const uint32_t *y, const uint32_t *ix, const uint32_t *iy, uint32_t *out, int len, size_t B, hipStream_t s) {
     const size_t total = B * (size_t)len;
     if (!total) return hipSuccess;
-    hipLaunchKernelGGL(gate_linear_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, op, x, y, out, len, total);
+    hipLaunchKernelGGL(gate_linear_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, op, ops, x, y, ix, iy, out, len, total);
     return hipGetLastError();
 }
 
@@ -1202,6 +1207,7 @@ static hipError_t launch_rot_lt(const RotArgs &a, size_t nrot, hipStream_t s) {
     const size_t lds_bytes = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
     hipError_t e = set_lds(blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT, BT>, lds_bytes);
     if (e != hipSuccess) return e;
+    last_rot_kernel = "blindrotate_k1_kernel";
     if (a.split == 0 || a.split >= nrot) {
         hipLaunchKernelGGL((blindrotate_k1_kernel<LM, WORD, LB, LR, NB, LT, BT>), dim3((unsigned)nrot), dim3(P::NT), lds_bytes, s, a);
         return hipGetLastError();
@@ -1347,6 +1353,7 @@ static hipError_t launch_kr_one(const RotArgs &a, size_t nrot, hipStream_t s) {
     constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
     hipError_t e = set_lds(blindrotate_kr_kernel<LM, WORD, KR, BLK, BL>, LB);
     if (e != hipSuccess) return e;
+    last_rot_kernel = "blindrotate_kr_kernel";
     hipLaunchKernelGGL((blindrotate_kr_kernel<LM, WORD, KR, BLK, BL>), dim3((unsigned)nrot), dim3(P::NT), LB, s, a);
     return hipGetLastError();
 }
@@ -1402,6 +1409,7 @@ static hipError_t launch_ccs_one(const CcsArgs &a, size_t B, hipStream_t s) {
     using P = Plan<LM, LOGR, 1>;
     constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
     hipError_t e = set_lds(ccs_blindrotate_kernel<LM, WORD, LT, BT>, LB); if (e != hipSuccess) return e;
+    last_rot_kernel = "ccs_blindrotate_kernel";
     hipLaunchKernelGGL((ccs_blindrotate_kernel<LM, WORD, LT, BT>), dim3((unsigned)B), dim3(P::NT), LB, s, a);
     return hipGetLastError();
 }
@@ -1430,8 +1438,9 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     // the batch leaves few slabs (and one wave per staged table, below): Blockparam 4096 gates 2.12 -> 1.32 ms, 16 384 gates 8.49 -> 4.94 ms, KMS2partyblock 1024 gates
     // 2.73 -> 2.35 ms, neutral at 1024 LMSS gates; the unbalanced variant is fastest at 1024 at every batch size (tools/ks_blocks_sweep*.sh)
     if (a.balanced) target_blocks = a.mk ? 4096 : 8192;
-    if (const char *e = getenv("MKT_KS_G")) G = atoi(e);
-    if (const char *e = getenv("MKT_KS_BLOCKS")) target_blocks = atoi(e);
+    const LaunchTuning &lt = launch_tuning();
+    if (lt.ks_g > 0) G = lt.ks_g;
+    if (lt.ks_blocks > 0) target_blocks = lt.ks_blocks;
     const int ngroups = (int)((B + G - 1) / G);
     const int parties = a.mk ? a.kacc : 1;
     // enough workgroups to fill the chip (~8 per CU), slabs of at least 8 coefficients
@@ -1440,11 +1449,10 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     if (slabs > a.N / 8) slabs = a.N / 8;
     const int jslab = (a.N + slabs - 1) / slabs;
     slabs = (a.N + jslab - 1) / jslab;
-    int waves = 4;
-    if (const char *e = getenv("MKT_KS_WAVES")) waves = atoi(e);
+    int waves = lt.ks_waves > 0 ? lt.ks_waves : 4;
     if (waves != 2 && waves != 4) waves = 1;
     if (G != 32) waves = 1;
-    if (a.balanced && !getenv("MKT_KS_WAVES")) waves = 1;   // balanced digits: every wave stages its own table (KMS2partyblock 2.7 ms alone vs 4.0 ms shared; Blockparam 16 384 gates 4.98 -> 4.11 ms, RLWE length 2 19.3 -> 14.9 ms)
+    if (a.balanced && lt.ks_waves <= 0) waves = 1;   // balanced digits: every wave stages its own table (KMS2partyblock 2.7 ms alone vs 4.0 ms shared; Blockparam 16 384 gates 4.98 -> 4.11 ms, RLWE length 2 19.3 -> 14.9 ms)
     const int gblocks = (ngroups + waves - 1) / waves;
     if (waves > 1) {   // same number of waves in flight as the single-wave launch
         slabs = (target_blocks + ngroups * parties - 1) / (ngroups * parties);
@@ -1629,6 +1637,7 @@ static hipError_t launch_wide_one(const RotArgs &a, size_t nrot, hipStream_t s) 
     const size_t lds_bytes = (size_t)(1 + 2 * LT) * P::M * sizeof(cplx);
     hipError_t e = set_lds(blindrotate_wide_kernel<LM, WORD, LR, LT>, lds_bytes);
     if (e != hipSuccess) return e;
+    last_rot_kernel = "blindrotate_wide_kernel";
     hipLaunchKernelGGL((blindrotate_wide_kernel<LM, WORD, LR, LT>), dim3((unsigned)nrot), dim3(threads), lds_bytes, s, a);
     return hipGetLastError();
 }

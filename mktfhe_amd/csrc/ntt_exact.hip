@@ -795,7 +795,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
 // sequence as ccs_blindrotate_kernel -- per input polynomial q: decompose, l forward transforms, u = sum dig_j d[j],
 // v = -/+ sum dig_j (crs | b_{q-1})[j], inverse of v, decompose v, l forward transforms, w into tacc.b and tacc.a[idx]; then
 // every polynomial times the monomial, inverse, add.  All sums are integers mod P, so the order in which the reference's
-// Float64 sums must be formed plays no role here.  True coefficients stay below 2 (np + 2) l N 2^(logB-1) 2^32 < P / 2
+// Float64 sums must be formed plays no role here.  True coefficients stay below 2 (np + 2) l N 2^(logB-1) 2^31 < P / 2 (centered words: context.cpp exact_gate_ok)
 // (host check).  The accumulator lives in the caller's buffer, the u of the earlier parties' polynomials in a scratch area.
 // ------------------------------------------------------------------------------------------------
 struct ExactCcsArgs {
@@ -965,6 +965,7 @@ hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_
                                     int pre_switched, int n, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
     if (blk_len != 1 && blk_len != 3) return hipErrorInvalidValue;
+    last_rot_kernel = "exact_blindrotate_kernel";
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
     MKT_NTT_DISPATCH(logN, {
         const size_t lds = lds_bytes<LN>(2);
@@ -993,6 +994,7 @@ hipError_t launch_ntt_fwd_split(int logN, const uint64_t *tab, const void *p, ui
 
 hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
+    last_rot_kernel = "exact_kms_phase1_kernel";
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
     MKT_NTT_DISPATCH(logN, {
         const size_t lds = lds_bytes<LN>(2);
@@ -1018,6 +1020,7 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
 
 hipError_t launch_exact_ccs(int logN, const uint64_t *tab, const ExactCcsHostArgs &h, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
+    last_rot_kernel = "exact_ccs_kernel";
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
     ExactCcsArgs a;
     a.lwe = h.lwe; a.lwe_stride = h.lwe_stride; a.pre_switched = h.pre_switched; a.n = h.n; a.k = h.k; a.l = h.l; a.logB = h.logB;

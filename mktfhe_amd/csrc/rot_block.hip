@@ -346,6 +346,7 @@ static hipError_t launch_blk_lt(const RotArgs &a, size_t nslots, hipStream_t s) 
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     hipError_t e = set_lds(blindrotate_blk_kernel<LM, WORD, LB, G, LT, BT, NP>, lds_bytes);
     if (e != hipSuccess) return e;
+    last_rot_kernel = "blindrotate_blk_kernel";
     const size_t wg_per_slot = (a.ngates + G - 1) / G;
     hipLaunchKernelGGL((blindrotate_blk_kernel<LM, WORD, LB, G, LT, BT, NP>), dim3((unsigned)(wg_per_slot * nslots)), dim3(G * P::NT), lds_bytes, s, a, (int)wg_per_slot);
     return hipGetLastError();

@@ -220,7 +220,8 @@ class Scheme:
 
     def close(self):
         if getattr(self, "h", None):
-            _lib.lib().mkt_ctx_destroy(self.h)
+            if getattr(self, "_owned", True):        # a borrowed view (MultiScheme.shard) never destroys the context
+                _lib.lib().mkt_ctx_destroy(self.h)
             self.h = None
 
     __del__ = close
@@ -295,6 +296,21 @@ class Scheme:
     def synchronize(self):
         self._ck(_lib.lib().mkt_synchronize(self.h))
 
+    def get_stream(self):
+        """the hipStream_t handle (int) this context enqueues on right now (a fork: its own non-blocking stream)"""
+        st = C.c_void_p()
+        self._ck(_lib.lib().mkt_get_stream(self.h, C.byref(st)))
+        return st.value or 0
+
+    def set_option(self, name, value):
+        """kernel-selection switch (mkt_set_option): "rot_wide", "rot_blkg", "ccs_pipe", ... -- results never depend on them;
+        the parity tests force every kernel variant through this"""
+        self._ck(_lib.lib().mkt_set_option(self.h, name.encode(), int(value)))
+
+    def last_kernel_name(self):
+        """base name of the blind-rotation kernel the last batch call launched"""
+        return (_lib.lib().mkt_last_kernel_name(self.h) or b"").decode()
+
     # -- tables (tests)
     def twiddles(self, which):
         out = np.empty(self.params.N // 2, dtype=np.complex128)
@@ -334,6 +350,42 @@ class Scheme:
         if tuple(kx.shape) != tuple(ky.shape) or kx.shape[-1] != self.params.lwe_len:
             raise ValueError("ciphertext shape mismatch")       # reference: @assert length checks
         self._ck(_lib.lib().mkt_gate_batch(self.h, op, px, py, po, self._batch(kx), mem))
+        return ko
+
+    def gate_ops(self, ops, x, y, out=None):
+        """a different gate per ciphertext pair (mkt_gate_batch_ops; the reference's tests draw a random gate per step,
+        test/KMS.jl:29-34): ops[j] in 0..5 (NAND..NOR), optionally | OP_NOT_X / OP_NOT_Y (that input negated first, NOT!);
+        a uint8 array living where x and y live"""
+        px, mem, kx = _arg(x, np.uint32, scheme=self)
+        py, mem2, ky = _arg(y, np.uint32, scheme=self)
+        po_, mem4, kops = _arg(ops, np.uint8, scheme=self)
+        if not (mem == mem2 == mem4):
+            raise ValueError("ops, x and y must all be host arrays or all be GPU tensors")
+        if out is None:
+            out = kx.new_empty(kx.shape) if mem == MEM_DEVICE else np.empty_like(kx)
+        po, mem3, ko = _arg(out, np.uint32, writable=True, scheme=self)
+        if mem3 != mem:
+            raise ValueError("out must live where the inputs live")
+        B = self._batch(kx)
+        if tuple(kx.shape) != tuple(ky.shape) or kx.shape[-1] != self.params.lwe_len or int(np.prod(kops.shape)) != B:
+            raise ValueError("ciphertext / ops shape mismatch")
+        self._ck(_lib.lib().mkt_gate_batch_ops(self.h, po_, px, py, po, B, mem))
+        return ko
+
+    def gate_gather(self, ops, pool, ix, iy, out):
+        """one circuit level (mkt_gate_batch_gather): gate j = ops[j](pool[ix[j]], pool[iy[j]]) -> out[j]; pool (rows, k*n+1),
+        ix / iy uint32 (int32 tensors) row indices; out may be a later region of the pool"""
+        pp, mem, kp = _arg(pool, np.uint32, scheme=self)
+        pops, m1, kops = _arg(ops, np.uint8, scheme=self)
+        pix, m2, kix = _arg(ix, np.uint32, scheme=self)
+        piy, m3, kiy = _arg(iy, np.uint32, scheme=self)
+        po, m4, ko = _arg(out, np.uint32, writable=True, scheme=self)
+        if not (mem == m1 == m2 == m3 == m4):
+            raise ValueError("all arguments must live in the same memory")
+        B = int(np.prod(kops.shape))
+        if kp.shape[-1] != self.params.lwe_len or int(np.prod(kix.shape)) != B or int(np.prod(kiy.shape)) != B or self._batch(ko) != B:
+            raise ValueError("shape mismatch")
+        self._ck(_lib.lib().mkt_gate_batch_gather(self.h, pops, pp, self._batch(kp), pix, piy, po, B, mem))
         return ko
 
     def bootstrapping_(self, ctxt):
@@ -423,6 +475,160 @@ class Scheme:
         out = np.empty(a.shape[:-1] + (l, self.params.N), dtype=self.params.ring_dtype)
         self._ck(_lib.lib().mkt_decompose_batch(self.h, _np_ptr(a), _np_ptr(out), l, logB, B, MEM_HOST))
         return out
+
+
+OP_NOT_X, OP_NOT_Y = 8, 16      # mktfhe.h MKT_OP_NOT_X / _Y: per-gate code bits of gate_ops / gate_gather
+
+
+class MultiScheme:
+    """ONE scheme object over several MI355X (mkt_multi_*): the reference's caller is one process whose threads
+    share one read-only scheme (README.md:38-44, bootstrapping.jl:38-45); here the batch is cut into contiguous shards, one per
+    entry of `devices` (a device named twice = two logical shards over that device's one key set), keys uploaded once and
+    replicated device-to-device, every shard writing its slice of the caller's one output array.  No collective.  Same batch
+    methods as Scheme; arrays are host numpy arrays or GPU tensors on ANY of the devices."""
+
+    def __init__(self, params: Params, devices, arith=ARITH_F64REF, private_keys=False):
+        """private_keys: shards that share a device each get their own replicated key copy (MKT_MULTI_PRIVATE_KEYS: the
+        device-to-device replication path, testable on one GPU) instead of sharing that device's one key set"""
+        self.params, self.devices, self.arith = params, list(devices), arith
+        h = C.c_void_p()
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        code = _lib.lib().mkt_multi_create(C.byref(params.c()), arith, arr, len(self.devices), 1 if private_keys else 0, C.byref(h))
+        if code < 0:
+            raise MktError(code, (_lib.lib().mkt_multi_last_error(None) or b"").decode())
+        self.h = h
+        self._sealed = False
+
+    def _ck(self, code):
+        if code < 0:
+            raise MktError(code, (_lib.lib().mkt_multi_last_error(self.h) or b"").decode())
+        return code
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().mkt_multi_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def nshards(self):
+        return len(self.devices)
+
+    def shard_range(self, B, shard):
+        lo, hi = C.c_size_t(), C.c_size_t()
+        self._ck(_lib.lib().mkt_multi_shard_range(self.h, B, shard, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def shard(self, i):
+        """borrowed Scheme view of shard i's context (timing, kernel names); valid while this object lives"""
+        s = object.__new__(Scheme)
+        s.params, s.device, s.arith, s._user_stream = self.params, self.devices[i], self.arith, True
+        s.h = C.c_void_p(_lib.lib().mkt_multi_ctx(self.h, i))
+        s._owned = False
+        return s
+
+    # -- keys: once, on the first device; replicate() copies them to the others
+    def load_party(self, party, keys: "PartyKeys" = None, *, brk=None, ksk=None, rlk_d=None, rlk_f=None, pubkey=None, fmt=FMT_INT_COEFF):
+        L, p = _lib.lib(), self.params
+        if keys is not None:
+            brk, ksk, rlk_d, rlk_f, pubkey = keys.brk, keys.ksk, keys.rlk_d, keys.rlk_f, keys.pubkey
+        kd = np.complex128 if fmt == FMT_F64_FFT else p.ring_dtype
+        if brk is not None:
+            self._ck(L.mkt_multi_load_brk(self.h, party, _np_ptr(np.ascontiguousarray(brk, dtype=kd)), fmt))
+        if ksk is not None:
+            self._ck(L.mkt_multi_load_ksk(self.h, party, _np_ptr(np.ascontiguousarray(ksk, dtype=np.uint32))))
+        if rlk_d is not None:
+            self._ck(L.mkt_multi_load_rlk(self.h, party, _np_ptr(np.ascontiguousarray(rlk_d, dtype=kd)),
+                                          _np_ptr(np.ascontiguousarray(rlk_f, dtype=kd)), fmt))
+        if pubkey is not None:
+            self._ck(L.mkt_multi_load_pubkey(self.h, party, _np_ptr(np.ascontiguousarray(pubkey, dtype=kd)), fmt))
+
+    def keygen_device(self, party, keys: "PartyKeys"):
+        crs_p = _np_ptr(keys._crs) if (self.params.scheme == CCS and keys._crs is not None) else None
+        self._ck(_lib.lib().mkt_multi_keygen_device(self.h, party, keys.h, crs_p))
+        self.load_party(party, rlk_d=keys.rlk_d, rlk_f=keys.rlk_f, pubkey=keys.pubkey)
+
+    def load_crs(self, a, fmt=FMT_INT_COEFF):
+        kd = np.complex128 if fmt == FMT_F64_FFT else self.params.ring_dtype
+        self._ck(_lib.lib().mkt_multi_load_crs(self.h, _np_ptr(np.ascontiguousarray(a, dtype=kd)), fmt))
+
+    def replicate(self):
+        self._ck(_lib.lib().mkt_multi_replicate(self.h))
+        self._sealed = True
+
+    def set_option(self, name, value):
+        self._ck(_lib.lib().mkt_multi_set_option(self.h, name.encode(), int(value)))
+
+    # -- hot path (no stream following: calls are synchronous, inputs are settled by the library)
+    @staticmethod
+    def _batch(x):
+        return int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+
+    def gate(self, op, x, y, out=None):
+        px, mem, kx = _arg(x, np.uint32)
+        py, mem2, ky = _arg(y, np.uint32)
+        if mem != mem2:
+            raise ValueError("x and y must both be host arrays or both be GPU tensors")
+        if out is None:
+            out = kx.new_empty(kx.shape) if mem == MEM_DEVICE else np.empty_like(kx)
+        po, mem3, ko = _arg(out, np.uint32, writable=True)
+        if mem3 != mem or tuple(kx.shape) != tuple(ky.shape) or kx.shape[-1] != self.params.lwe_len:
+            raise ValueError("ciphertext shape / memory mismatch")
+        self._ck(_lib.lib().mkt_multi_gate_batch(self.h, op, px, py, po, self._batch(kx), mem))
+        return ko
+
+    def gate_ops(self, ops, x, y, out=None):
+        px, mem, kx = _arg(x, np.uint32)
+        py, mem2, ky = _arg(y, np.uint32)
+        pops, mem4, kops = _arg(ops, np.uint8)
+        if out is None:
+            out = kx.new_empty(kx.shape) if mem == MEM_DEVICE else np.empty_like(kx)
+        po, mem3, ko = _arg(out, np.uint32, writable=True)
+        if not (mem == mem2 == mem3 == mem4) or tuple(kx.shape) != tuple(ky.shape) or kx.shape[-1] != self.params.lwe_len:
+            raise ValueError("ciphertext shape / memory mismatch")
+        self._ck(_lib.lib().mkt_multi_gate_batch_ops(self.h, pops, px, py, po, self._batch(kx), mem))
+        return ko
+
+    def bootstrapping_(self, ctxt):
+        p, mem, k = _arg(ctxt, np.uint32, writable=True)
+        self._ck(_lib.lib().mkt_multi_bootstrap_batch(self.h, p, self._batch(k), mem))
+        return k
+
+    def not_(self, ctxt):
+        p, mem, k = _arg(ctxt, np.uint32, writable=True)
+        self._ck(_lib.lib().mkt_multi_not_batch(self.h, p, self._batch(k), mem))
+        return k
+
+    def blindrotate_(self, atilde, acc):
+        pa, mem, ka = _arg(atilde, np.uint32)
+        pc, mem2, kc = _arg(acc, self.params.ring_dtype, writable=True)
+        if mem != mem2:
+            raise ValueError("atilde and acc must live in the same memory")
+        self._ck(_lib.lib().mkt_multi_blindrotate_batch(self.h, pa, pc, self._batch(ka), mem))
+        return kc
+
+    def keyswitch(self, acc):
+        a = np.ascontiguousarray(acc, dtype=self.params.ring_dtype)
+        B = int(np.prod(a.shape[:-2])) if a.ndim > 2 else 1
+        out = np.empty(a.shape[:-2] + (self.params.lwe_len,), dtype=np.uint32)
+        self._ck(_lib.lib().mkt_multi_keyswitch_batch(self.h, _np_ptr(a), _np_ptr(out), B, MEM_HOST))
+        return out
+
+
+def setup_multi(params: Params, devices, keys=None, a=None, arith=ARITH_F64REF, private_keys=False):
+    """setup (scheme.jl:151 / :190 / :244 / :292 / :343) for a MultiScheme: evaluation keys uploaded (or, for keys made with
+    secrets_only=True, generated) once on devices[0], pre-transformed there and replicated to the other devices"""
+    sch = MultiScheme(params, devices, arith=arith, private_keys=private_keys)
+    if params.multikey:
+        sch.load_crs(a)
+        klist = list(keys)
+    else:
+        klist = [keys if isinstance(keys, PartyKeys) else keys[0]]
+    for i, kk in enumerate(klist):
+        (sch.keygen_device if kk.secrets_only else sch.load_party)(i, kk)
+    sch.replicate()
+    return sch
 
 
 def setup(params: Params, keys=None, a=None, device=0, deterministic_seed=None, arith=ARITH_F64REF):

@@ -1,0 +1,259 @@
+"""GPU tests of the round-4 boundary additions, through the C ABI against the CPU oracle, bit for bit:
+
+* mkt_gate_batch_ops  -- a different gate (and optional input NOTs) per ciphertext pair, the shape of the reference's own
+  tests (test/KMS.jl:29-34 draws a random gate per step; gate.jl:1-58);
+* mkt_gate_batch_gather -- one circuit level per call, operands picked from a ciphertext pool;
+* mkt_multi_* -- ONE evaluator over several shards, one caller process: keys uploaded once and replicated,
+  contiguous balanced slices, every shard writing its slice of the caller's one output array.  The GPU box has one
+  device, so the shards are LOGICAL shards of device 0: forked contexts over one key set (the default), or -- with
+  private_keys=True -- one replicated key copy per shard, which runs the device-to-device replication path.
+"""
+import numpy as np
+import pytest
+
+from helpers import GATE_FUNCS, O, encrypt_bits, gpu_scheme, keygen, mk, oracle_scheme
+
+pytestmark = pytest.mark.gpu
+
+SMALL = [
+    mk.CGGIparam.scaled(n=20, N=256),
+    mk.Blockparam.scaled(n=30, N=256, blk_d=10),
+    mk.KMS2party.scaled(n=16, N=256),
+    mk.KMS2partyblock.scaled(n=24, N=256, blk_d=8),
+    mk.CCS2party.scaled(n=12, N=256),
+    mk.KMS4party.scaled(n=8, N=256),
+]
+
+
+def _neg(c):
+    return (0 - c.astype(np.int64)).astype(np.uint32)
+
+
+def oracle_gate_ops(so, ops, x, y):
+    """the reference semantics of one coded gate: NOT! (gate.jl:55-58) on the flagged inputs, then the gate (gate.jl:1-53)"""
+    out = np.empty_like(x)
+    for j in range(len(ops)):
+        a = _neg(x[j]) if ops[j] & mk.OP_NOT_X else x[j]
+        b = _neg(y[j]) if ops[j] & mk.OP_NOT_Y else y[j]
+        out[j] = so.gate(int(ops[j] & 7), a, b)
+    return out
+
+
+def plain_gate_ops(ops, bx, by):
+    out = np.empty(len(ops), dtype=bool)
+    for j, o in enumerate(ops):
+        a = ~bx[j] if o & mk.OP_NOT_X else bx[j]
+        b = ~by[j] if o & mk.OP_NOT_Y else by[j]
+        out[j] = GATE_FUNCS[int(o & 7)](a, b)
+    return out
+
+
+@pytest.mark.parametrize("p", SMALL, ids=lambda p: f"{p.name}-n{p.n}-N{p.N}")
+def test_mixed_gate_batch_matches_the_oracle(require_gpu, p):
+    """a random gate per ciphertext pair in ONE call == the oracle gate by gate, host and device memory; the counterpart of
+    the reference's test loop (test/KMS.jl:29-34: `rand(1:6)` picks the gate of every step)"""
+    import torch
+    crs, keys = keygen(p, 41)
+    so, sg = oracle_scheme(p, crs, keys), gpu_scheme(p, crs, keys)
+    B = 13
+    rng = np.random.default_rng(42)
+    bits = rng.integers(0, 2, 2 * B).astype(bool)
+    c = encrypt_bits(p, keys, bits, seed=4200)
+    x, y = c[:B], c[B:][::-1].copy()            # cross-party pairs
+    bx, by = bits[:B], bits[B:][::-1]
+    ops = rng.integers(0, 6, B).astype(np.uint8)
+    ops[:6] = np.arange(6)                       # every gate at least once
+    ops[1::3] |= mk.OP_NOT_X
+    ops[2::4] |= mk.OP_NOT_Y
+    want = oracle_gate_ops(so, ops, x, y)
+    got_h = sg.gate_ops(ops, x, y)
+    assert np.array_equal(got_h, want)
+    td = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()   # noqa: E731
+    got_d = sg.gate_ops(td(ops), td(x), td(y))
+    torch.cuda.synchronize()
+    assert np.array_equal(got_d.cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(mk.lwe_decrypt(got_h, keys if p.multikey else keys[0], p), plain_gate_ops(ops, bx, by))
+    # one op for the whole batch through the coded entry point == mkt_gate_batch
+    for op in (0, 3):
+        assert np.array_equal(sg.gate_ops(np.full(B, op, np.uint8), x, y), sg.gate(op, x, y))
+    with pytest.raises(mk.MktError):
+        sg.gate_ops(np.full(B, 6, np.uint8), x, y)          # not a gate
+    sg.close()
+
+
+@pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=20, N=256), mk.KMS2party.scaled(n=16, N=256)], ids=lambda p: p.name)
+def test_gather_level_matches_the_oracle(require_gpu, p):
+    """mkt_gate_batch_gather: operands by row index from a pool, output into a later region of the SAME pool (device memory)
+    and into a separate array (host memory)"""
+    import torch
+    crs, keys = keygen(p, 43)
+    so, sg = oracle_scheme(p, crs, keys), gpu_scheme(p, crs, keys)
+    rng = np.random.default_rng(44)
+    P, B = 9, 11
+    bits = rng.integers(0, 2, P).astype(bool)
+    pool = encrypt_bits(p, keys, bits, seed=4400)
+    ix = rng.integers(0, P, B).astype(np.uint32)
+    iy = rng.integers(0, P, B).astype(np.uint32)
+    ops = (rng.integers(0, 6, B) | (rng.integers(0, 2, B) << 3) | (rng.integers(0, 2, B) << 4)).astype(np.uint8)
+    want = oracle_gate_ops(so, ops, pool[ix], pool[iy])
+    out_h = np.empty((B, p.lwe_len), dtype=np.uint32)
+    sg.gate_gather(ops, pool, ix, iy, out_h)
+    assert np.array_equal(out_h, want)
+    big = torch.zeros((P + B, p.lwe_len), dtype=torch.int32, device="cuda")
+    big[:P] = torch.from_numpy(pool.view(np.int32)).cuda()
+    sg.gate_gather(torch.from_numpy(ops).cuda(), big, torch.from_numpy(ix.view(np.int32)).cuda(), torch.from_numpy(iy.view(np.int32)).cuda(), big[P:])
+    torch.cuda.synchronize()
+    assert np.array_equal(big[P:].cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(big[:P].cpu().numpy().view(np.uint32), pool)          # the operand rows are untouched
+    with pytest.raises(mk.MktError):
+        sg.gate_gather(ops, pool, ix + P, iy, out_h)                              # index outside the pool
+    sg.close()
+
+
+def test_circuit_level_is_one_call_whatever_the_gate_mix(require_gpu):
+    """circuit.evaluate_on issues ONE engine call per level (adder: XOR + AND + OR mixed in a level), the ciphertext words equal
+    the per-(level, op) evaluation through the oracle backend"""
+    from mktfhe_amd import circuit as CI
+    p = mk.KMS2party.scaled(n=16, N=256)
+    crs, keys = keygen(p, 45)
+    so, sg = oracle_scheme(p, crs, keys), gpu_scheme(p, crs, keys)
+    circ = CI.ripple_adder(3)
+    B = 5
+    rng = np.random.default_rng(46)
+    bits = rng.integers(0, 2, (6, B)).astype(bool)
+    inputs = [np.stack([mk.lwe_ith_encrypt(int(bits[i, j]), (i + j) % 2, keys[(i + j) % 2], p, deterministic_seed=4600 + 10 * i + j) for j in range(B)]) for i in range(6)]
+    calls = []
+    orig = sg.gate_gather
+    sg.gate_gather = lambda *a: (calls.append(len(a[0])), orig(*a))[1]
+    outs = CI.evaluate_on(circ, inputs, sg)
+    depth, sched = circ.levels()
+    assert len(calls) == len(sched) == max(depth)                # one call per level ...
+    assert sum(calls) == B * sum(len(v) for lv in sched.values() for v in lv.values())   # ... covering every gate
+    ref = CI.evaluate(circ, inputs, lambda op, x, y: so.gate_batch(op, x, y, threads=8), _neg)
+    for o, r in zip(outs, ref):
+        assert np.array_equal(o, r)
+    a = sum(bits[i].astype(int) << i for i in range(3)); b = sum(bits[3 + i].astype(int) << i for i in range(3))
+    assert np.array_equal(sum(mk.lwe_decrypt(o, keys, p).astype(int) << i for i, o in enumerate(outs)), a + b)
+    # a circuit whose OUTPUT is a NOT and whose gates read NOTs of NOTs
+    c2 = CI.Circuit(); u, v = c2.input(), c2.input()
+    c2.output(c2.NOT(c2.XOR(c2.NOT(c2.NOT(u)), c2.NOT(v))))
+    (o2,) = CI.evaluate_on(c2, inputs[:2], sg)
+    (r2,) = CI.evaluate(c2, inputs[:2], lambda op, x, y: so.gate_batch(op, x, y, threads=8), _neg)
+    assert np.array_equal(o2, r2)
+    sg.close()
+
+
+# ---------------------------------------------------------------- the multi-shard evaluator
+MULTI_SETS = [
+    (mk.KMS2party.scaled(n=16, N=256), mk.ARITH_F64REF),
+    (mk.CGGIparam.scaled(n=20, N=256), mk.ARITH_F64REF),
+    (mk.CCS2party.scaled(n=12, N=256), mk.ARITH_F64REF),
+    (mk.Blockparam.scaled(n=30, N=256, blk_d=10), mk.ARITH_F64REF),
+    (mk.KMS2party.scaled(n=8, N=256), mk.ARITH_EXACT),
+    (mk.CGGIparam.scaled(n=12, N=256), mk.ARITH_EXACT),
+]
+
+
+def multi_scheme(p, crs, keys, devices, arith, private_keys=False):
+    return mk.setup_multi(p, devices, keys=keys if p.multikey else keys[0], a=crs, arith=arith, private_keys=private_keys)
+
+
+@pytest.mark.parametrize("private", [False, True], ids=["shared-keys", "replicated-keys"])
+@pytest.mark.parametrize("nshards", [2, 3])
+@pytest.mark.parametrize("p,arith", MULTI_SETS, ids=lambda v: v.name if hasattr(v, "name") else ("exact" if v else "f64ref"))
+def test_multi_shard_evaluator_equals_the_single_context(require_gpu, p, arith, nshards, private):
+    """N logical shards of device 0 behind ONE mkt_multi handle: every batch entry point gives, word for word, what one
+    context gives on the whole batch (and, in F64REF, what the oracle gives), for ragged splits (7 = 3+2+2, 2 over 3 shards
+    leaves one shard empty, 1), in host and in device memory, with the keys shared per device or replicated per shard."""
+    import torch
+    crs, keys = keygen(p, 51)
+    single = gpu_scheme(p, crs, keys, arith=arith)
+    multi = multi_scheme(p, crs, keys, [0] * nshards, arith, private)
+    so = oracle_scheme(p, crs, keys) if arith == mk.ARITH_F64REF else None
+    assert multi.nshards == nshards and multi.shard_range(7, 0) == (0, 7 // nshards + 1)
+    rng = np.random.default_rng(52)
+    td = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()   # noqa: E731
+    for B in (7, 2, 1):
+        bits = rng.integers(0, 2, 2 * B).astype(bool)
+        c = encrypt_bits(p, keys, bits, seed=5200 + B)
+        x, y = c[:B], c[B:]
+        for op in (0, 3):
+            want = single.gate(op, x, y)
+            assert np.array_equal(multi.gate(op, x, y), want), (B, op, "host")
+            got = multi.gate(op, td(x), td(y))
+            assert np.array_equal(got.cpu().numpy().view(np.uint32), want), (B, op, "device")
+            if so is not None:
+                assert np.array_equal(want, np.stack([so.gate(op, x[j], y[j]) for j in range(B)]))
+            assert np.array_equal(mk.lwe_decrypt(want, keys if p.multikey else keys[0], p), GATE_FUNCS[op](bits[:B], bits[B:]))
+        ops = (rng.integers(0, 6, B) | (rng.integers(0, 2, B) << 3)).astype(np.uint8)
+        assert np.array_equal(multi.gate_ops(ops, x, y), single.gate_ops(ops, x, y))
+        assert np.array_equal(multi.gate_ops(td(ops), td(x), td(y)).cpu().numpy().view(np.uint32), single.gate_ops(ops, x, y))
+        # bootstrapping! in place, NOT!, blindrotate! / keyswitch! (the operators the north star names)
+        lin = np.stack([O.gate_linear(0, x[j], y[j]) for j in range(B)])
+        assert np.array_equal(multi.bootstrapping_(lin.copy()), single.bootstrapping_(lin.copy()))
+        assert np.array_equal(multi.not_(x.copy()), single.not_(x.copy()))
+        at, bt = single.modswitch(lin)
+        W = p.W
+        acc0 = np.zeros((B, 1 + p.k, p.N), dtype=p.ring_dtype)
+        for j in range(B):      # bootstrapping.jl:11-23
+            e = 1 << (W - 3)
+            tb = int(bt[j])
+            lo, hi = (e, (1 << W) - e) if tb <= p.N else ((1 << W) - e, e)
+            tb = tb if tb <= p.N else tb - p.N
+            acc0[j, 0, :tb] = lo; acc0[j, 0, tb:] = hi
+        acc_s = single.blindrotate_(at, acc0.copy())
+        acc_m = multi.blindrotate_(at, acc0.copy())
+        assert np.array_equal(acc_m, acc_s)
+        assert np.array_equal(multi.keyswitch(acc_m), single.keyswitch(acc_s))
+    multi.close(); single.close()
+
+
+def test_multi_shard_evaluator_full_size_and_errors(require_gpu):
+    """the headline shape (BASELINE configs[1]) on three logical shards == one context == the oracle sample; keys are
+    immutable once replicated; calls before mkt_multi_replicate are refused"""
+    p = mk.KMS2party_N1024_l2
+    crs, keys = keygen(p, 53)
+    single = gpu_scheme(p, crs, keys)
+    multi = mk.MultiScheme(p, [0, 0, 0])
+    B = 10
+    bits = np.random.default_rng(54).integers(0, 2, 2 * B).astype(bool)
+    c = encrypt_bits(p, keys, bits, seed=5400)
+    with pytest.raises(mk.MktError, match="mkt_multi_replicate"):
+        multi.gate(0, c[:B], c[B:])
+    multi.load_crs(crs)
+    for i, kk in enumerate(keys):
+        multi.load_party(i, kk)
+    multi.replicate()
+    with pytest.raises(mk.MktError, match="immutable"):
+        multi.load_crs(crs)
+    want = single.gate(0, c[:B], c[B:])
+    assert np.array_equal(multi.gate(0, c[:B], c[B:]), want)
+    so = oracle_scheme(p, crs, keys)
+    assert np.array_equal(want[:3], so.gate_batch(0, c[:3], c[B:B + 3], threads=3))
+    # per-shard timing and kernel names through the borrowed contexts
+    sh = multi.shard(1)
+    sh.enable_timing(True)
+    multi.gate(0, c[:B], c[B:])
+    ms, n = sh.kernel_ms(1)
+    assert n == 1 and ms > 0 and sh.last_kernel_name().startswith("blindrotate_")
+    with pytest.raises(mk.MktError):
+        mk.MultiScheme(p, [0, 99])                               # no such device
+    multi.close(); single.close()
+
+
+def test_last_kernel_name_follows_the_dispatch(require_gpu):
+    """mkt_last_kernel_name: bench.py's roofline names the kernel that actually ran"""
+    p = mk.Blockparam.scaled(n=24, N=1024, blk_d=8)
+    crs, keys = keygen(p, 55)
+    sg = gpu_scheme(p, crs, keys)
+    c = encrypt_bits(p, keys, np.zeros(10, dtype=bool), seed=5500)
+    assert sg.last_kernel_name() == ""
+    sg.set_option("rot_blkg", 1); sg.set_option("rot_wide", 1)
+    sg.gate(0, c[:5], c[5:])
+    assert sg.last_kernel_name() == "blindrotate_k1_kernel"
+    sg.set_option("rot_blkg", 4)
+    sg.gate(0, c[:5], c[5:])
+    assert sg.last_kernel_name() == "blindrotate_blk_kernel"
+    with pytest.raises(mk.MktError, match="unknown option"):
+        sg.set_option("no_such_switch", 1)
+    sg.close()

@@ -330,7 +330,7 @@ def test_errors(require_gpu):
         s.gate(0, x, x)
     with pytest.raises(ValueError):       # wrong length (reference: @assert)
         s.gate(0, x[:, :-1], x[:, :-1])
-    # EXACT: a gadget whose product sums would not fit the two-prime modulus (P / 2 = 2^60.9), or an RLWE length it has no kernel
+    # EXACT: a gadget whose product sums would not fit the two-prime modulus (P / 2 = 2^58.9998), or an RLWE length it has no kernel
     # for, is refused instead of computing something else
     for pk in (mk.KMS2party.scaled(n=8, N=2048, l_gsw=2, logB_gsw=20), mk.CGGIparam.scaled(n=8, N=256, k=2)):
         ex = mk.Scheme(pk, arith=mk.ARITH_EXACT)
@@ -808,7 +808,7 @@ def test_latency_variant_of_the_rotation_is_bit_identical(require_gpu, p, monkey
     acc_o = np.stack([so.blindrotate(at[j], acc0[j]) for j in range(B)])
     res = {}
     for mode in ("1", "2"):
-        monkeypatch.setenv("MKT_ROT_WIDE", mode)
+        sg.set_option("rot_wide", int(mode))      # mkt_set_option: the environment is only read at context creation
         acc_g = sg.blindrotate_(at, acc0.astype(p.ring_dtype).copy())
         assert np.array_equal(acc_g.astype(np.uint64), acc_o), f"blindrotate, MKT_ROT_WIDE={mode}"
         lev = sg.kms_phase1(at) if p.scheme == mk.KMS else None

@@ -258,7 +258,8 @@ def test_every_shipped_set_fits_the_exact_modulus():
         elif p.scheme == mk.CCS:
             b = 2.0 * (p.k + 2.0) * p.l_uni * 2.0**(p.logB_uni - 1) * n31
         else:
-            b = (2.0 * p.blk_len if p.scheme == mk.LMSS else 1.0) * 2.0 * p.l_gsw * 2.0**(p.logB_gsw - 1) * n31
+            # CGGI too carries the doubling: the kernel multiplies the product sum by X^a - 1 in the transform domain before its one lift
+            b = 2.0 * (p.blk_len if p.scheme == mk.LMSS else 1.0) * 2.0 * p.l_gsw * 2.0**(p.logB_gsw - 1) * n31
         worst[name] = b
         assert b < half_P, (name, np.log2(b))
     assert len(worst) >= 19 and abs(np.log2(worst["KMS2party_N1024_l2"]) - 58.0) < 1e-9
@@ -437,7 +438,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/mktfhe.h but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert _lib.lib().mkt_abi_version() == 2
+    assert _lib.lib().mkt_abi_version() == 3
 
 
 def test_no_cpu_fallback_and_argument_errors():
@@ -515,6 +516,48 @@ def test_circuit_levelisation_with_oracle_backend():
     o3 = CI.evaluate(c3, inputs[:3], gate_fn, lambda v: (0 - v.astype(np.int64)).astype(np.uint32))
     assert np.array_equal(mk.lwe_decrypt(o3[0], keys[0], p), np.where(bits[0], bits[1], bits[2]))
     assert calls == [(1, 2 * B), (2, B)]
+
+
+def test_circuit_plan_one_call_per_level_with_oracle_backend():
+    """circuit.Plan / evaluate_on (one mkt_gate_batch_gather per LEVEL, NOTs folded into per-gate op codes) driven by a stand-in
+    scheme whose gate_gather is the ORACLE: same ciphertext words as the per-(level, op) evaluator, on a circuit that mixes
+    gate kinds in a level, chains NOTs and ends in a NOT"""
+    from mktfhe_amd import circuit as CI
+    p = mk.CGGIparam.scaled(n=16, N=128)
+    crs, keys = keygen(p, 73)
+    so = oracle_scheme(p, crs, keys)
+    neg = lambda x: (0 - x.astype(np.int64)).astype(np.uint32)   # noqa: E731
+
+    class OracleAsScheme:
+        calls = []
+        def gate_gather(self, ops, pool, ix, iy, out):
+            self.calls.append(len(ops))
+            for j in range(len(ops)):
+                a = neg(pool[ix[j]]) if ops[j] & 8 else pool[ix[j]]
+                b = neg(pool[iy[j]]) if ops[j] & 16 else pool[iy[j]]
+                out[j] = so.gate(int(ops[j] & 7), a, b)
+            return out
+        def not_(self, x):
+            x[...] = neg(x)
+            return x
+
+    B = 3
+    rng = np.random.default_rng(74)
+    circ = CI.ripple_adder(2)
+    c2 = CI.Circuit(); u, v, w = c2.input(), c2.input(), c2.input()
+    c2.output(c2.NOT(c2.XOR(c2.NOT(c2.NOT(u)), c2.NOT(v)))); c2.output(c2.MUX(u, v, w))
+    for cc in (circ, c2):
+        bits = rng.integers(0, 2, (cc.n_inputs, B)).astype(bool)
+        inputs = [np.stack([mk.lwe_encrypt(int(bits[i, j]), keys[0], p, deterministic_seed=7400 + 10 * i + j) for j in range(B)]) for i in range(cc.n_inputs)]
+        fake = OracleAsScheme(); fake.calls = []
+        plan = CI.Plan(cc, B)
+        outs = CI.evaluate_on(cc, inputs, fake, plan)
+        depth, sched = cc.levels()
+        assert len(fake.calls) == max(depth) and sum(fake.calls) == plan.gates
+        ref = CI.evaluate(cc, inputs, lambda op, x, y: so.gate_batch(op, x, y, threads=4), neg)
+        for o, r, wv in zip(outs, ref, cc.plain(bits)):
+            assert np.array_equal(o, r)
+            assert np.array_equal(mk.lwe_decrypt(o, keys[0], p), wv)
 
 
 def test_lds_staging_swizzle_is_conflict_free_in_the_bank_model():
