@@ -19,6 +19,15 @@ them, relays rank 0's JSON line and exits non-zero if any rank failed.  Under to
 Gates shard across ranks with no data-path collective (keys replicated per GPU); RCCL carries the timing barrier,
 the max-over-ranks of the step time and the `ranks_seen` census only.
 
+--launcher inproc: ONE process drives all N GPUs through the library's multi-device evaluator (mkt_multi_*: keys uploaded
+once and replicated device to device, the batch cut into N contiguous shards, one host thread per GPU, no collective, no
+torch.distributed) -- the shape of a Julia caller of the ccall shim, which is one process.  The default launcher stays one
+process per GPU under torch.distributed (what the driver's census expects).
+
+--workload adder8 --instances I: circuit throughput -- I independent 8-bit ripple-carry adders evaluated level by level with
+one engine call per level (mkt_gate_batch_gather: mixed gate kinds, operands gathered from a ciphertext pool in HBM), beside
+the flat NAND rate of the same parameter set measured in the same run.
+
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline           -- the kernel that costs the time, blindrotate_k1_kernel (93 % of a step): bound = f64 VALU issue
                         WITHOUT FMA (the reference's arithmetic rounds after every multiply and every add), achieved =
@@ -55,6 +64,7 @@ WORKLOADS = {
     "ccs2party": ("CCS2party", "CCS2party k=2, N=1024 (src/tfhe/params.jl:15-21)"),
     "ccs8party": ("CCS8party", "CCS8party k=8, N=1024 (src/tfhe/params.jl:31-37)"),
     "ccs8_n2048": ("CCS8party_N2048", "CCS k=8, N=2048 (BASELINE.json configs[3], synthetic shape)"),
+    "adder8": ("KMS2party_N1024_l2", "8-bit ripple-carry adder circuits on the BASELINE configs[1] parameter set (KMS k=2, N=1024, l_gsw=2), one engine call per circuit level"),
 }
 
 # Parameter sets whose own output noise leaves less than 6 sigma of decryption margin, with the per-gate failure probability
@@ -231,7 +241,8 @@ def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, w
     p2_ms, _ = sch.kernel_ms(4)
     sch.enable_timing(False)
     mine = elapsed
-    elapsed = D.max_over_ranks(elapsed, device=red_dev)
+    if world > 1:                                   # world == 1 also marks a leg only rank 0 runs: no collective there
+        elapsed = D.max_over_ranks(elapsed, device=red_dev)
     per_rank = [1e3 * mine / max(steps, 1)]
     if world > 1:
         t = torch.zeros(world, dtype=torch.float64, device=red_dev)
@@ -252,14 +263,15 @@ def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, w
                 decrypt_errors_all=errs_all, decrypt_checked_all=checked_all, per_rank_ms=per_rank)
 
 
-def rot_roofline(mk, p, B, t, workload):
-    """the roofline object of the dominant kernel of this workload (plain / KMS schemes: blindrotate_k1_kernel)"""
+def rot_roofline(mk, p, B, t, workload, kern=None):
+    """the roofline object of the dominant kernel of this workload; `kern` = the name the engine reports for the kernel it
+    actually launched (mkt_last_kernel_name), so the line and the rocprof trace name the same kernel"""
     flop_step, rows = blindrotate_flop(mk, p, B)              # one step = ceil(B / 8192) launches (the engine's workspace chunk)
     launches_per_step = max(1, -(-B // 8192))
     flop = flop_step / launches_per_step
     avg_ms = t["rot_ms"] / max(t["rot_n"], 1)
     achieved = flop / (avg_ms * 1e-3) / 1e12
-    kern = "ccs_blindrotate_kernel" if p.scheme == mk.CCS else ("blindrotate_kr_kernel" if (not p.multikey and p.k > 1) else "blindrotate_k1_kernel")
+    kern = kern or ("ccs_blindrotate_kernel" if p.scheme == mk.CCS else ("blindrotate_kr_kernel" if (not p.multikey and p.k > 1) else "blindrotate_k1_kernel"))
     r = {"bound": "f64-valu-nofma", "kernel": kern, "achieved": achieved, "peak": PEAK_F64_NOFMA_TFLOPS,
          "unit": "TFLOP/s", "frac": achieved / PEAK_F64_NOFMA_TFLOPS, "traffic": None,
          "algorithmic_flop_per_launch": flop, "rotations_per_launch": rows * B / launches_per_step, "cmux_per_rotation": p.n // max(p.blk_len, 1),
@@ -280,66 +292,240 @@ def rot_roofline(mk, p, B, t, workload):
 
 
 def transform_roofline(mk, torch, local, dev):
-    """BASELINE.json metric 2: batched forward (fft.jl:57-63) and inverse (fft.jl:74-81) transforms streamed HBM ->
-    HBM, 64-bit ring, N = 1024 and 2048, >= 4 GiB per launch (>> 256 MiB Infinity Cache); algorithmic bytes 16 N each"""
+    """BASELINE.json metric 2: batched forward (fft.jl:57-63) and inverse (fft.jl:74-81) transforms streamed HBM -> HBM at
+    N = 1024 and 2048, >= 4 GiB per launch (>> 256 MiB Infinity Cache), on both rings: algorithmic bytes per transform
+    N (W/8 + 8) -- 16 N on the 64-bit ring (KMS), 12 N on the 32-bit ring (CGGI / LMSS / CCS: BASELINE.md 4)"""
     out = []
-    for N in (1024, 2048):
-        p = mk.KMS2party.scaled(n=8, N=N)
-        s = mk.Scheme(p, device=local)
-        nb = (4 << 30) // (16 * N)
-        polys = torch.randint(-2**31, 2**31 - 1, (nb, 2 * N), dtype=torch.int32, device=dev).view(torch.int64)
-        tr = torch.empty((nb, N // 2), dtype=torch.complex128, device=dev)
-        back = torch.empty((nb, N), dtype=torch.int64, device=dev)
-        for direction in ("forward", "inverse"):
-            fn = (lambda: s.transform_fwd(polys, out=tr)) if direction == "forward" else (lambda: s.transform_inv(tr, out=back))
-            for _ in range(3):                     # warm-up (first touches of a fresh working set run slower)
-                fn()
-            torch.cuda.synchronize()
-            s.enable_timing(True)
-            for _ in range(10):
-                fn()
-            ms, cnt = s.kernel_ms(3)
-            s.enable_timing(False)
-            achieved = nb * 16 * N / (ms / cnt * 1e-3) / 1e9
-            kern = "transform_fwd_kernel" if direction == "forward" else "transform_inv_kernel"
-            e = {"bound": "hbm", "kernel": kern, "direction": direction, "N": N, "ring_bits": 64, "achieved": achieved, "peak": 8000.0,
-                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": nb * 16 * N,
-                 "bytes_per_transform": 16 * N, "transforms_per_launch": nb, "avg_launch_ms": ms / cnt}
-            prof = profiled_counters(f"mktd::{kern}<{int(np.log2(N)) - 1}", "kms2_n1024")
-            if prof:
-                c, src, _ = prof
-                e["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-                e["traffic_source"] = src
-            out.append(e)
-        s.close()
-        # the same buffers through the exact integer transform (MKT_ARITH_EXACT: two-prime NTT, N residue pairs = 8 N bytes)
-        sx = mk.Scheme(p, device=local, arith=mk.ARITH_EXACT)
-        for direction in ("forward", "inverse"):
-            fn = (lambda: sx.transform_fwd(polys, out=tr)) if direction == "forward" else (lambda: sx.transform_inv(tr, out=back))
-            for _ in range(2):
-                fn()
-            torch.cuda.synchronize()
-            sx.enable_timing(True)
-            for _ in range(5):
-                fn()
-            ms, cnt = sx.kernel_ms(3)
-            sx.enable_timing(False)
-            achieved = nb * 16 * N / (ms / cnt * 1e-3) / 1e9
-            kern = "ntt_fwd_kernel" if direction == "forward" else "ntt_inv_kernel"
-            e = {"bound": "hbm", "kernel": kern, "arith": "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)",
-                 "direction": direction, "N": N, "ring_bits": 64, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                 "traffic": None, "algorithmic_bytes_per_launch": nb * 16 * N, "bytes_per_transform": 16 * N, "transforms_per_launch": nb,
-                 "avg_launch_ms": ms / cnt, "bound_note": "integer issue, not HBM: VALU ~0.95 busy per SIMD at a 1.6-1.8 GHz clock (profiles/r03_ntt_pmc.txt)"}
-            prof = profiled_counters(f"mktd::{kern}<{int(np.log2(N))}", "kms2_n1024")
-            if prof:
-                c, src, _ = prof
-                e["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-                e["traffic_source"] = src
-            out.append(e)
-        sx.close()
-        del polys, tr, back
-        torch.cuda.empty_cache()
+    for W in (64, 32):
+        for N in (1024, 2048):
+            wb = W // 8
+            per = N * (wb + 8)
+            p = (mk.KMS2party if W == 64 else mk.CGGIparam).scaled(n=8, N=N)
+            nb = (4 << 30) // per
+            if W == 64:
+                polys = torch.randint(-2**31, 2**31 - 1, (nb, 2 * N), dtype=torch.int32, device=dev).view(torch.int64)
+            else:
+                polys = torch.randint(-2**31, 2**31 - 1, (nb, N), dtype=torch.int32, device=dev)
+            tr = torch.empty((nb, N // 2), dtype=torch.complex128, device=dev)
+            back = torch.empty_like(polys)
+            for arith, reps, warm in ((mk.ARITH_F64REF, 10, 3), (mk.ARITH_EXACT, 5, 2)):
+                if arith == mk.ARITH_EXACT and W == 32 and N == 2048:
+                    continue                                   # the integer legs are reported at three shapes; keeps the default run short
+                s = mk.Scheme(p, device=local, arith=arith)
+                for direction in ("forward", "inverse"):
+                    fn = (lambda: s.transform_fwd(polys, out=tr)) if direction == "forward" else (lambda: s.transform_inv(tr, out=back))
+                    for _ in range(warm):                      # warm-up (first touches of a fresh working set run slower)
+                        fn()
+                    torch.cuda.synchronize()
+                    s.enable_timing(True)
+                    for _ in range(reps):
+                        fn()
+                    ms, cnt = s.kernel_ms(3)
+                    s.enable_timing(False)
+                    achieved = nb * per / (ms / cnt * 1e-3) / 1e9
+                    if arith == mk.ARITH_F64REF:
+                        kern = "transform_fwd_kernel" if direction == "forward" else "transform_inv_kernel"
+                        prefix = f"mktd::{kern}<{int(np.log2(N)) - 1}, unsigned {'long' if W == 64 else 'int'}"
+                        e = {"bound": "hbm", "kernel": kern}
+                    else:
+                        kern = "ntt_fwd_kernel" if direction == "forward" else "ntt_inv_kernel"
+                        prefix = f"mktd::{kern}<{int(np.log2(N))}, unsigned {'long' if W == 64 else 'int'}"
+                        e = {"bound": "hbm", "kernel": kern, "arith": "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)",
+                             "bound_note": "integer issue, not HBM: VALU ~0.95 busy per SIMD (profiles/r03_ntt_pmc.txt)"}
+                    e.update({"direction": direction, "N": N, "ring_bits": W, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                              "traffic": None, "algorithmic_bytes_per_launch": nb * per, "bytes_per_transform": per, "transforms_per_launch": nb, "avg_launch_ms": ms / cnt})
+                    prof = profiled_counters(prefix, "kms2_n1024")      # the headline workload's PMC passes include these legs
+                    if prof:
+                        c, src, _ = prof
+                        e["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                        e["traffic_source"] = src
+                    out.append(e)
+                s.close()
+            del polys, tr, back
+            torch.cuda.empty_cache()
     return out
+
+
+def cpu_baseline(p, crs, keys, allc, B, res, args, check_bits):
+    """the C oracle ("port": F64REF restatement of the reference CPU path) timed on this box's host cores on a bounded sample of
+    the same workload -- one gate per thread over all the cores this process may use, and one thread alone --
+    compiled for these cores (-O3 -march=native, contraction off: same bits, checked against the GPU result)"""
+    from oracle import oracle as ORA
+    flags = ORA.use_native_build()
+    from helpers import oracle_scheme
+    so = oracle_scheme(p, crs, keys)
+    cores = effective_cpus()                   # host threads this process may actually run on (cgroup quota aware)
+    npilot = min(cores, B)                     # pilot round (one gate per thread) sizes the sample to ~10 s of CPU work
+    t0 = time.perf_counter()
+    so.gate_batch(0, allc[:npilot], allc[B:B + npilot], threads=npilot)
+    pilot = time.perf_counter() - t0
+    sample = args.cpu_sample or cores * max(1, min(int(10.0 / max(pilot, 1e-3)), 64))
+    sample = min(B, sample)
+    cores = min(cores, sample)
+    xs, ys = allc[:sample], allc[B:B + sample]
+    t0 = time.perf_counter()
+    ref = so.gate_batch(0, xs, ys, threads=cores)
+    dt = time.perf_counter() - t0
+    n1 = max(1, min(sample, int(3.0 / max(pilot, 1e-3))))          # ~3 s on one thread
+    t0 = time.perf_counter()
+    so.gate_batch(0, xs[:n1], ys[:n1], threads=1)
+    dt1 = time.perf_counter() - t0
+    out = {"value": sample / dt, "unit": "gates/s", "cores": cores, "kind": "port",
+           "sample": f"{sample} NAND gates of the same workload, C oracle (F64REF restatement of the reference CPU path), {cores} threads (the host's CPU quota), one gate per thread",
+           "seconds": dt, "one_thread": {"value": n1 / dt1, "unit": "gates/s", "cores": 1, "sample": f"{n1} gates", "seconds": dt1},
+           "build": flags}
+    bitexact = bool(np.array_equal(ref, res[:sample])) if check_bits else None
+    return out, bitexact
+
+
+def exact_rot_roofline(mk, p, B, t, kern, workload):
+    """integer-issue roofline of the EXACT (two-prime NTT) blind-rotation kernels: VALU instructions the arithmetic itself
+    needs per launch (ntt_exact.hip; DESIGN.md 2: a two-residue butterfly is 14 instructions forward / 16 inverse, a lazy
+    Montgomery multiply-accumulate over both residues 12, conversion / lift per coefficient as counted below) against the rate
+    at which one MI355X issues 32-bit integer multiply-class instructions (tools/valu_probe.hip: v_mul_lo_u32, v_mul_hi_u32,
+    v_mad_u64_u32 at 4.4 cycles per wave64 instruction per SIMD = 16 lanes/clk, like a v_add_f64; plain 32-bit ALU ops at
+    2.5).  Model: 60 % of the instruction stream is multiply-class (quarter rate), 40 % full rate -> a mean of 3.6 cycles per
+    wave instruction; peak = 256 CU x 4 SIMD x 64 lanes / 3.6 cycles x 2.4 GHz."""
+    N = p.N
+    lg = int(np.log2(N))
+    bf_fwd, bf_inv, mac = 14, 16, 12
+    fwd = (N // 2) * lg * bf_fwd + 6 * N          # butterflies + input conversion of N coefficients (both residues)
+    inv = (N // 2) * lg * bf_inv + 14 * N         # butterflies + CRT lift, sign and reduction mod 2^W per coefficient
+    rows = (1 + (p.k - 1) * p.l_lev) if p.scheme in (mk.KMS, mk.KMS_BLOCK) else 1
+    l = max(p.l_gsw, 1)
+    LB = max(p.blk_len, 1)
+    if p.scheme == mk.CCS:
+        lu = p.l_uni
+        per_poly = 2 * lu * fwd + 2 * inv + 4 * lu * mac * N + 8 * N
+        instr = sum((idx + 2) * per_poly for idx in range(p.k)) * p.n * B
+        rows = 1
+    elif p.W == 64:      # split tables: 2l forward, (low, high) x (b, a) = 4 inverses, 2 x 2 x 2l MACs per key bit
+        per_blk = 2 * l * fwd * (LB if LB > 1 else 1) + 4 * inv + LB * (8 * l * mac * N) + 16 * N
+        instr = per_blk * (p.n // LB) * rows * B
+    else:                # 32-bit ring: 2l forward, 2 inverses, 2 x 2l MACs per key bit, monomial product in the transform domain
+        per_blk = 2 * l * fwd + 2 * inv + LB * (4 * l * mac * N + 2 * mac * N) + 8 * N
+        instr = per_blk * (p.n // LB) * rows * B
+    launches_per_step = max(1, -(-B // 8192))
+    avg_ms = t["rot_ms"] / max(t["rot_n"], 1)
+    peak = 256 * 4 * 64 / 3.6 * 2.4e9 / 1e12           # T lane-instructions / s
+    ach = instr / launches_per_step / (avg_ms * 1e-3) / 1e12
+    r = {"bound": "int32-valu-issue", "kernel": kern, "achieved": ach, "peak": peak, "unit": "T lane-instr/s", "frac": ach / peak, "traffic": None,
+         "algorithmic_instr_per_launch": instr / launches_per_step, "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
+         "peak_note": "256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 3.6 cycles per wave instruction (60 % multiply-class at 4.4, 40 % at 2.5: tools/valu_probe.hip)"}
+    prof = profiled_counters("mktd::" + kern, workload + "_exact", want=("FETCH_SIZE", "WRITE_SIZE"))
+    if prof:
+        c, src, _ = prof
+        r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        r["traffic_source"] = src
+        if "GRBM_GUI_ACTIVE" in c:
+            ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["ms:GRBM_GUI_ACTIVE"] * 1e-3) / 1e9
+            r["sustained_clock_ghz"] = ghz
+            r["frac_at_sustained_clock"] = ach / (peak * ghz / 2.4)
+        if "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c:
+            r["valu_active_per_wave_cycle"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
+    return r
+
+
+def run_circuit(mk, torch, p, keys, sch, args, dev, flat_rate):
+    """--workload adder8: I independent 8-bit ripple-carry adders, ciphertexts resident in HBM, one mkt_gate_batch_gather per
+    level (mixed XOR / AND / OR, NOT-free here).  A step = one evaluation of all I circuits."""
+    from mktfhe_amd import circuit as CI
+    circ = CI.ripple_adder(8)
+    inst = args.instances
+    plan = CI.Plan(circ, inst)
+    rng = np.random.default_rng(7)
+    bits = rng.integers(0, 2, (circ.n_inputs, inst)).astype(bool)
+    # inputs: a few distinct fresh encryptions per (wire, bit, party), replicated over the instances (the work does not depend on
+    # the ciphertext values; all parties appear so that no mask block is empty after the first level)
+    enc = {(i, v): mk.lwe_ith_encrypt(v, i % p.nparty, keys[i % p.nparty], p, deterministic_seed=9000 + 2 * i + v) for i in range(circ.n_inputs) for v in (0, 1)}
+    inputs = [torch.from_numpy(np.stack([enc[(i, int(bits[i, j]))] for j in range(inst)]).view(np.int32)).to(dev) for i in range(circ.n_inputs)]
+    for _ in range(args.warmup):
+        outs = CI.evaluate_on(circ, inputs, sch, plan)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = CI.evaluate_on(circ, inputs, sch, plan)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    want = circ.plain(bits)
+    ok = 0
+    for o, w in zip(outs, want):
+        ok += int(np.count_nonzero(mk.lwe_decrypt(o.cpu().numpy().view(np.uint32), keys if p.multikey else keys[0], p) == w))
+    checked = len(want) * inst
+    gates = plan.gates * args.steps
+    return {"circuit": "8-bit ripple-carry adder", "gates_per_instance": plan.gates // inst, "levels": len(plan.levels), "instances": inst,
+            "level_widths": [n * inst for _, n, _, _, _ in plan.levels], "engine_calls_per_evaluation": len(plan.levels),
+            "value": gates / dt, "unit": "gates/s", "ms_per_evaluation": 1e3 * dt / args.steps,
+            "flat_nand_gates_per_s": flat_rate, "vs_flat": gates / dt / flat_rate if flat_rate else None,
+            "output_bits_correct": ok, "output_bits_checked": checked}
+
+
+def main_inproc(args):
+    """--launcher inproc: one process, N GPUs through the library's multi-device evaluator (no torch.distributed)"""
+    import torch
+    import mktfhe_amd as mk
+    n = args.gpus
+    share = os.environ.get("MKT_BENCH_SHARE_GPU") == "1" or torch.cuda.device_count() < n
+    devices = [0] * n if share else list(range(n))
+    pname, desc = WORKLOADS[args.workload]
+    p = getattr(mk, pname)
+    total = args.batch if args.scaling == "strong" else n * args.batch
+    arith = mk.ARITH_EXACT if args.arith == "exact" else mk.ARITH_F64REF
+    need_host_keys = not args.no_cpu_baseline
+    if p.multikey:
+        crs = mk.CRS(p, 1)
+        keys = [mk.party_keygen(crs, p, party=i, secrets_only=not need_host_keys, deterministic_seed=1) for i in range(p.k)]
+    else:
+        crs, keys = None, [mk.PartyKeys(p, secrets_only=not need_host_keys, deterministic_seed=1)]
+    sch = mk.setup_multi(p, devices, keys=keys if p.multikey else keys[0], a=crs, arith=arith)
+    torch.cuda.set_device(devices[0])
+    dev = torch.device("cuda", devices[0])
+    bits, x, y = make_inputs(mk, torch, p, keys, sch, total, 0, dev, args.inputs)     # the folds run through the multi evaluator too
+    torch.cuda.synchronize()
+    out = torch.empty_like(x)
+    for _ in range(args.warmup):
+        sch.gate(0, x, y, out=out)
+    shards = [sch.shard(i) for i in range(n)]
+    for sh in shards:
+        sh.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sch.gate(0, x, y, out=out)                   # synchronous: returns when every shard is done
+    elapsed = time.perf_counter() - t0
+    per_shard, rot, ks, p2, rot_n = [], 0.0, 0.0, 0.0, 0
+    for sh in shards:
+        w, _ = sh.kernel_ms(0)
+        per_shard.append(w / max(args.steps, 1))
+    r0, rot_n = shards[0].kernel_ms(1); k0, _ = shards[0].kernel_ms(2); q0, _ = shards[0].kernel_ms(4)
+    kern = shards[0].last_kernel_name()
+    for sh in shards:
+        sh.enable_timing(False)
+    res = out.cpu().numpy().view(np.uint32)
+    want = ~(bits[:total] & bits[total:])
+    errs = int(np.count_nonzero(mk.lwe_decrypt(res, keys if p.multikey else keys[0], p) != want))
+    lo, hi = sch.shard_range(total, 0)
+    t = {"rot_ms": r0, "rot_n": rot_n}
+    line = {
+        "metric": "NAND gate-bootstraps/sec", "value": total * args.steps / elapsed, "unit": "gates/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f64" if args.arith == "f64ref" else "u32x2-residue", "data": "synthetic",
+        "config": {"workload": desc, "params": pname, "parties": p.k, "N": p.N, "n": p.n, "ring_bits": p.W, "l_gsw": p.l_gsw,
+                   "batch_per_gpu": hi - lo, "batch_total": total, "op": "NAND", "inputs": args.inputs,
+                   "arith": "F64REF" if args.arith == "f64ref" else "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)",
+                   "sharding": "gates across GPUs, keys replicated device to device (hipMemcpyPeer), one process, one host thread per GPU",
+                   "launcher": "inproc (mkt_multi_*)", "devices": devices,
+                   "io": f"inputs and outputs are ONE array each on device {devices[0]}; the other shards' slices travel by peer copy inside the timed region"},
+        "ranks_seen": n, "per_rank_ms_per_step": per_shard,
+        "decrypt_ok": errs <= allowed_wrong(pname, total), "decrypt_errors": errs, "decrypt_checked": total,
+        "decrypt_failure_rate_measured": errs / max(total, 1), "decrypt_failure_rate_predicted": NOISY_SETS.get(pname, 0.0),
+        "kernels_ms_per_step": {"shard": 0, "blindrotate": r0 / max(args.steps, 1), "kms_phase2": q0 / max(args.steps, 1), "keyswitch": k0 / max(args.steps, 1)},
+    }
+    line["roofline"] = rot_roofline(mk, p, hi - lo, t, args.workload, kern) if args.arith == "f64ref" else exact_rot_roofline(mk, p, hi - lo, t, kern, args.workload)
+    if not args.no_cpu_baseline:
+        allc = np.concatenate([x.cpu().numpy(), y.cpu().numpy()]).view(np.uint32)
+        line["cpu_baseline"], line["oracle_bitexact"] = cpu_baseline(p, crs, keys, allc, total, res, args, args.arith == "f64ref")
+    print(json.dumps(line), flush=True)
+    sch.close()
 
 
 def main():
@@ -350,6 +536,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--workload", default="kms2_n1024", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch gates per GPU; strong: --batch gates in total, sharded over the ranks")
+    ap.add_argument("--launcher", default="ranks", choices=["ranks", "inproc"], help="ranks: one process per GPU under torch.distributed (default); inproc: one process, all GPUs through mkt_multi_*")
+    ap.add_argument("--instances", type=int, default=1024, help="--workload adder8: independent circuit instances")
     ap.add_argument("--arith", default="f64ref", choices=["f64ref", "exact"], help="f64ref: the reference's Float64 transforms, bit-identical to it (default); exact: integer NTT over two 30-bit primes (MKT_ARITH_EXACT: all five schemes)")
     ap.add_argument("--inputs", default="mixed", choices=["mixed", "fresh"], help="mixed: every ciphertext involves all k parties (default); fresh: single-party first-level encryptions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -358,6 +546,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="gates in the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
 
+    if args.launcher == "inproc":
+        return main_inproc(args)                   # one process; nothing is spawned or exec'ed
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])       # never returns; nothing has touched the GPU in this process
 
@@ -392,7 +582,7 @@ def main():
         B = hi - lo
         if B == 0:
             raise SystemExit(f"rank {rank}: empty shard (batch {args.batch} over {world} ranks)")
-    need_host_keys = rank == 0 and world == 1 and not args.no_cpu_baseline
+    need_host_keys = rank == 0 and not args.no_cpu_baseline
     arith = mk.ARITH_EXACT if args.arith == "exact" else mk.ARITH_F64REF
     crs, keys, sch = make_scheme(mk, p, local, need_host_keys, arith)
     bits, x, y = make_inputs(mk, torch, p, keys, sch, B, rank, dev, args.inputs)
@@ -400,6 +590,7 @@ def main():
     allc = np.concatenate([x.cpu().numpy(), y.cpu().numpy()]).view(np.uint32)
     t = time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, args.steps, args.warmup, world, red_dev)
     res = t["res"]
+    kern = sch.last_kernel_name()
 
     line = None
     if rank == 0:
@@ -408,9 +599,10 @@ def main():
         line = {
             "metric": "NAND gate-bootstraps/sec", "value": gates / t["elapsed"], "unit": "gates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t["elapsed"] / args.steps,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64" if args.arith == "f64ref" else "u32x2-residue", "data": "synthetic",
             "config": {"workload": desc, "params": pname, "parties": p.k, "N": p.N, "n": p.n, "ring_bits": p.W,
-                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": "NAND", "inputs": args.inputs, "arith": "F64REF" if args.arith == "f64ref" else "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)", "sharding": "gates across GPUs, keys replicated"},
+                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": "NAND", "inputs": args.inputs, "arith": "F64REF" if args.arith == "f64ref" else "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)", "sharding": "gates across GPUs, keys replicated",
+                       "launcher": "ranks (one process per GPU, torch.distributed)"},
             "ranks_seen": ranks_seen, "per_rank_ms_per_step": t["per_rank_ms"],
             # Wrong decryptions are the parameter set's own output noise (profiles/r03_noise_theory_vs_measured.md: predicted
             # from the schemes' variance formulas, measured on this engine; the oracle produces the identical words --
@@ -423,7 +615,11 @@ def main():
             "kernels_ms_per_step": {"blindrotate": t["rot_ms"] / max(args.steps, 1), "kms_phase2": t["p2_ms"] / max(args.steps, 1),
                                     "keyswitch": t["ks_ms"] / max(args.steps, 1)},
         }
-        line["roofline"] = rot_roofline(mk, p, B, t, args.workload)
+        line["roofline"] = rot_roofline(mk, p, B, t, args.workload, kern) if args.arith == "f64ref" else exact_rot_roofline(mk, p, B, t, kern, args.workload)
+
+    # ---- circuit throughput (--workload adder8): rank 0, N = 1 ----
+    if rank == 0 and world == 1 and args.workload == "adder8":
+        line["circuit"] = run_circuit(mk, torch, p, keys, sch, args, dev, line["value"])
 
     # ---- secondary leg: the reference's own 2-party set, same measurement, short ----
     if not args.no_secondary and args.workload == "kms2_n1024":
@@ -437,52 +633,35 @@ def main():
                    "steps": st2, "ms_per_step": 1e3 * t2["elapsed"] / st2, "batch_per_gpu": B,
                    "decrypt_errors": t2["decrypt_errors"], "decrypt_checked": B,
                    "kernels_ms_per_step": {"blindrotate": t2["rot_ms"] / st2, "kms_phase2": t2["p2_ms"] / st2, "keyswitch": t2["ks_ms"] / st2}}
-            rr = rot_roofline(mk, p2, B, t2, "kms2party")
-            sec["roofline"] = {k: rr[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
+            rr = rot_roofline(mk, p2, B, t2, "kms2party", sch2.last_kernel_name())
+            sec["roofline"] = {k: rr[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "traffic")}
             line["secondary"] = sec
         sch2.close()
         del x2, y2
         torch.cuda.empty_cache()
 
-    # ---- the same workload in the integer-NTT arithmetic the north star names (MKT_ARITH_EXACT), short; N = 1 only ----
-    if rank == 0 and world == 1 and not args.no_secondary and args.arith == "f64ref" and args.workload == "kms2_n1024":
+    # ---- the same workload in the integer-NTT arithmetic the north star names (MKT_ARITH_EXACT), short; rank 0 only ----
+    if rank == 0 and not args.no_secondary and args.arith == "f64ref" and args.workload == "kms2_n1024":
         crsx, keysx, schx = make_scheme(mk, p, local, False, mk.ARITH_EXACT)
         bitsx, xx, yx = make_inputs(mk, torch, p, keysx, schx, B, rank, dev, args.inputs)
         stx = max(2, args.steps // 2)
-        tx = time_gates(mk, torch, dist, D, schx, p, keysx, xx, yx, bitsx, B, stx, 1, world, red_dev)
-        line["exact_mode"] = {"arith": "EXACT (two-prime integer NTT, exact products; DESIGN.md section 2)", "value": B * stx / tx["elapsed"], "unit": "gates/s", "steps": stx,
+        tx = time_gates(mk, torch, None, D, schx, p, keysx, xx, yx, bitsx, B, stx, 1, 1, red_dev)
+        line["exact_mode"] = {"arith": "EXACT (two-prime integer NTT, exact products; DESIGN.md section 2)", "dtype": "u32x2-residue", "value": B * stx / tx["elapsed"], "unit": "gates/s", "steps": stx,
                               "ms_per_step": 1e3 * tx["elapsed"] / stx, "batch_per_gpu": B, "decrypt_errors": tx["decrypt_errors"], "decrypt_checked": B,
                               "kernels_ms_per_step": {"blindrotate": tx["rot_ms"] / stx, "keyswitch": tx["ks_ms"] / stx},
+                              "roofline": exact_rot_roofline(mk, p, B, tx, schx.last_kernel_name(), args.workload),
                               "note": "valid ciphertexts, bitwise unrelated to the Float64 reference's (not the parity mode); word-identical to a big-integer restatement (tests/ref_exact.py)"}
         schx.close()
         del xx, yx
         torch.cuda.empty_cache()
 
-    # ---- transform roofline legs (BASELINE.json metric 2) ----
-    if rank == 0 and world == 1 and not args.no_roofline:
+    # ---- transform roofline legs (BASELINE.json metric 2): rank 0, at every world size ----
+    if rank == 0 and not args.no_roofline:
         line["roofline_transform"] = transform_roofline(mk, torch, local, dev)
 
-    # ---- CPU baseline leg (oracle, "port"): rank 0 at N = 1 only ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from helpers import oracle_scheme
-        so = oracle_scheme(p, crs, keys)
-        cores = effective_cpus()                   # host threads this process may actually run on (cgroup quota aware)
-        # pilot round (one gate per thread) sizes the sample to ~10 s of CPU work, capped at the batch
-        npilot = min(cores, B)
-        t0 = time.perf_counter()
-        so.gate_batch(0, allc[:npilot], allc[B:B + npilot], threads=npilot)
-        pilot = time.perf_counter() - t0
-        sample = args.cpu_sample or cores * max(1, min(int(10.0 / max(pilot, 1e-3)), 64))
-        sample = min(B, sample)
-        cores = min(cores, sample)
-        xs, ys = allc[:sample], allc[B:B + sample]
-        t0 = time.perf_counter()
-        ref = so.gate_batch(0, xs, ys, threads=cores)
-        dt = time.perf_counter() - t0
-        line["cpu_baseline"] = {"value": sample / dt, "unit": "gates/s", "cores": cores, "kind": "port",
-                                "sample": f"{sample} NAND gates of the same workload, C oracle (F64REF restatement of the reference CPU path), {cores} threads (the host's CPU quota), one gate per thread",
-                                "seconds": dt}
-        line["oracle_bitexact"] = bool(np.array_equal(ref, res[:sample])) if args.arith == "f64ref" else None   # EXACT words differ from the Float64 reference by construction (checked against big-integer arithmetic in tests)
+    # ---- CPU baseline leg (oracle, "port"): rank 0, at every world size (the other ranks wait at the final barrier) ----
+    if rank == 0 and not args.no_cpu_baseline:
+        line["cpu_baseline"], line["oracle_bitexact"] = cpu_baseline(p, crs, keys, allc, B, res, args, args.arith == "f64ref")   # EXACT words differ from the Float64 reference by construction (checked against big-integer arithmetic in tests)
 
     if rank == 0:
         print(json.dumps(line), flush=True)

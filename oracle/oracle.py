@@ -31,10 +31,33 @@ def build(force=False):
     return so
 
 
+_NATIVE = None
+
+
+def use_native_build():
+    """bench.py's cpu_baseline leg: compile the oracle for THIS host's cores (-O3 -march=native; still -ffp-contract=off, no
+    fast-math: the same IEEE operation sequence, so the same bits) into a temporary directory and load that instead of the
+    portable in-tree build, which has to run on whatever CPU the GPU box has.  Must be called before the first oracle call;
+    returns the flags actually used (the portable build's if the native compile fails)."""
+    global _NATIVE
+    if _LIB is not None:
+        return "already loaded"
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="mkt_oracle_"), "libmkt_oracle_native.so")
+    flags = ["-O3", "-march=native", "-std=gnu11", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
+    try:
+        subprocess.check_call(["gcc"] + flags + ["-shared", "-o", out, os.path.join(_HERE, "mkt_oracle.c"), "-lquadmath", "-lpthread", "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _NATIVE = out
+        return " ".join(flags)
+    except (OSError, subprocess.CalledProcessError):
+        return "-O3 -ffp-contract=off -fno-fast-math (portable in-tree build; native compile failed)"
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        L = C.CDLL(_NATIVE or build())
         vp, i32, u32, u64, dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_double
         L.ora_ffter_create.restype = vp; L.ora_ffter_create.argtypes = [i32, i32]
         L.ora_ffter_destroy.argtypes = [vp]

@@ -44,7 +44,9 @@ def test_ccs_sets_without_margin_are_predicted_to_fail():
 
 def test_kms_linear_noise_model_matches_the_engine():
     """KMS: the phase-1 error recursion and the phase-2 error identity simulated on random digits, keys and rounding errors
-    (the Float64 product error measured against exact integer products) -- heavy-tailed per gate, so a loose band"""
-    br, ks = T.kms(mk.KMS2party_N1024_l2, trials=6, seed=3)
+    (the Float64 product error measured against exact integer products).  The per-key spread is heavy-tailed (a single key
+    set moves the prediction by +-25 %), so the model averages 40 key sets: three seeds gave 0.93 / 1.09 / 1.15 of the measured
+    sigma at the headline shape; the band 0.8-1.3 is what a misread key row or relinearisation step (x sqrt 2 and up) cannot meet"""
+    br, ks = T.kms(mk.KMS2party_N1024_l2, trials=40, seed=3)
     ratio = measured()["KMS2party_N1024_l2"] / math.sqrt(br + ks)
-    assert 0.6 < ratio < 2.2, ratio
+    assert 0.8 < ratio < 1.3, ratio
