@@ -435,9 +435,10 @@ def run_circuit(mk, torch, p, keys, sch, args, dev, flat_rate):
     plan = CI.Plan(circ, inst)
     rng = np.random.default_rng(7)
     bits = rng.integers(0, 2, (circ.n_inputs, inst)).astype(bool)
-    # inputs: a few distinct fresh encryptions per (wire, bit, party), replicated over the instances (the work does not depend on
-    # the ciphertext values; all parties appear so that no mask block is empty after the first level)
-    enc = {(i, v): mk.lwe_ith_encrypt(v, i % p.nparty, keys[i % p.nparty], p, deterministic_seed=9000 + 2 * i + v) for i in range(circ.n_inputs) for v in (0, 1)}
+    # inputs: one fresh encryption per (wire, bit), replicated over the instances (the work does not depend on the values)
+    # operand a under party 0, operand b under party 1 (mod k): already the first level's gates span parties, as every later one does
+    party = lambda i: (i // 8) % p.nparty                                     # noqa: E731  (ripple_adder: inputs 0-7 = a, 8-15 = b)
+    enc = {(i, v): mk.lwe_ith_encrypt(v, party(i), keys[party(i)], p, deterministic_seed=9000 + 2 * i + v) for i in range(circ.n_inputs) for v in (0, 1)}
     inputs = [torch.from_numpy(np.stack([enc[(i, int(bits[i, j]))] for j in range(inst)]).view(np.int32)).to(dev) for i in range(circ.n_inputs)]
     for _ in range(args.warmup):
         outs = CI.evaluate_on(circ, inputs, sch, plan)

@@ -36,11 +36,13 @@ struct Tune {
     int rot_blkg = 0;       // block schemes: rotations per workgroup, 0 automatic
     int ccs_stagger = 0;
     int ccs_pipe = -1;      // two-group CCS kernel: -1 automatic (below one chip-fill), 0 never, 1 always
+    int rot_map = 0;        // workgroup id -> (ciphertext, slot) mapping of the k = 1 rotation kernels (kernel_common.h rot_decode)
+    int exact_wide = 1;     // EXACT KMS phase 1 at l_gsw = 2: wide (64-bit) digit-product accumulation
     void from_env() {
         rot_variant = env_int("MKT_ROT_VARIANT", rot_variant); rot_stagger = env_int("MKT_ROT_STAGGER", rot_stagger);
         rot_split = env_int("MKT_ROT_SPLIT", rot_split); rot_wide = env_int("MKT_ROT_WIDE", rot_wide);
         rot_blkg = env_int("MKT_ROT_BLKG", rot_blkg); ccs_stagger = env_int("MKT_CCS_STAGGER", ccs_stagger);
-        ccs_pipe = env_int("MKT_CCS_PIPE", ccs_pipe);
+        ccs_pipe = env_int("MKT_CCS_PIPE", ccs_pipe); exact_wide = env_int("MKT_EXACT_WIDE", exact_wide); rot_map = env_int("MKT_ROT_MAP", rot_map);
     }
 };
 }  // namespace
@@ -259,7 +261,7 @@ mktd::RotArgs rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
     a.rows_per_gate = c->ks->rtot; a.slot_party = c->ks->d_slot_party; a.slot_row = c->ks->d_slot_row;
     a.logB_lev = p.logB_lev; a.dev_order = c->dev_order;
     a.variant = c->tune.rot_variant; a.stagger = c->tune.rot_stagger; a.split = (unsigned)c->tune.rot_split;
-    a.wide = c->tune.rot_wide; a.blk_group = c->tune.rot_blkg;
+    a.wide = c->tune.rot_wide; a.blk_group = c->tune.rot_blkg; a.map_mode = c->tune.rot_map;
     return a;
 }
 
@@ -304,7 +306,7 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         q.slot_party = c->ks->d_slot_party; q.slot_row = c->ks->d_slot_row; q.levkey = reinterpret_cast<uint64_t *>(lev);
         q.rlk_d = reinterpret_cast<const uint64_t *>(c->ks->d_rlk_d); q.rlk_f = reinterpret_cast<const uint64_t *>(c->ks->d_rlk_f);
         q.pub_b = reinterpret_cast<const uint64_t *>(c->ks->d_pub); q.crs = reinterpret_cast<const uint64_t *>(c->ks->d_crs);
-        q.lin_for_tv = lin_for_tv; q.acc = reinterpret_cast<uint64_t *>(acc); q.scratch = reinterpret_cast<uint64_t *>(scratch); q.phase1_only = 0;
+        q.lin_for_tv = lin_for_tv; q.acc = reinterpret_cast<uint64_t *>(acc); q.scratch = reinterpret_cast<uint64_t *>(scratch); q.phase1_only = 0; q.wide = c->tune.exact_wide;
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_exact_kms(c->logN, c->d_ntt, q, B, c->stream));
         return MKT_OK;
@@ -634,6 +636,8 @@ int mkt_set_option(mkt_ctx *c, const char *name, int value) {
     else if (k == "rot_blkg") t.rot_blkg = value;
     else if (k == "ccs_stagger") t.ccs_stagger = value;
     else if (k == "ccs_pipe") t.ccs_pipe = value;
+    else if (k == "exact_wide") t.exact_wide = value;
+    else if (k == "rot_map") t.rot_map = value;
     else return fail(c, MKT_ERR_ARG, "mkt_set_option: unknown option '" + k + "'");
     return MKT_OK;
 }
@@ -955,7 +959,7 @@ int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, siz
         q.brk = reinterpret_cast<const uint64_t *>(c->ks->d_brk); q.brk_party_stride = c->ks->brk_party_cplx * 2 /* in 8-byte residue pairs */; q.mono = reinterpret_cast<const uint64_t *>(c->ks->d_monomial);
         q.lwe = (const uint32_t *)sa.dev; q.lwe_stride = (int)alen; q.pre_switched = 1; q.n = p.n; q.k = p.k; q.l_gsw = p.l_gsw; q.logB_gsw = p.logB_gsw;
         q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni; q.rtot = c->ks->rtot; q.lwe_len = c->sh.lwe_len; q.blk_len = p.scheme == MKT_KMS_BLOCK ? p.blk_len : 1;
-        q.slot_party = c->ks->d_slot_party; q.slot_row = c->ks->d_slot_row; q.levkey = (uint64_t *)sl.dev; q.phase1_only = 1;
+        q.slot_party = c->ks->d_slot_party; q.slot_row = c->ks->d_slot_row; q.levkey = (uint64_t *)sl.dev; q.phase1_only = 1; q.wide = c->tune.exact_wide;
         { Timer tm(c, 1); HIPCHK(c, mktd::launch_exact_kms(c->logN, c->d_ntt, q, B, c->stream)); }
         return sl.out(levkey);
     }

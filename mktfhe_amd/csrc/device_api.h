@@ -48,6 +48,7 @@ struct RotArgs {
     unsigned block0;          // first workgroup index of this launch (a rotation batch may be issued as several launches)
     unsigned split;           // workgroups per launch (0 = the whole batch in one launch)
     int dev_order;            // device point order of the resident tables (fft_device.h dev_pos)
+    int map_mode;             // workgroup id -> (ciphertext, slot): 0 slot-major, 1 rows of one (ciphertext, party) eight ids apart (kernel_common.h rot_decode)
     int blk_group;            // block schemes: rotations per workgroup -- 0 automatic, 1 one (blindrotate_k1_kernel<LB>), 2 / 4 (rot_block.hip)
 };
 
@@ -157,6 +158,7 @@ struct ExactKmsArgs {
     const uint32_t *lin_for_tv;                     // bootstrapping.jl:11-23 from the linear combination, or NULL (acc holds the test vector)
     uint64_t *acc, *scratch;                        // [B][1+k][N] ; [B][4(k+1)][N]
     int phase1_only;
+    int wide;                                       // phase 1, l_gsw = 2: the digit products of an accumulator gathered in 64 bits, one reduction (speed only)
 };
 hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a, size_t B, hipStream_t s);
 // CCS blind rotation with exact products (32-bit ring); tables as residue pairs, natural order, Montgomery form

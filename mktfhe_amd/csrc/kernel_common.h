@@ -53,6 +53,32 @@ __device__ __forceinline__ void inverse_to_words(cplx (&z)[1 << LOGR], WORD (&w)
     }
 }
 
+// Workgroup index -> (ciphertext, rotation slot) of a rotation launch.
+// map_mode 0: slot-major -- all ciphertexts' rotations of one slot are adjacent, so the workgroups resident at any time stream
+//   the SAME party's key rows through L2.
+// map_mode 1: party-major, and inside a party's region the R rows of one (ciphertext, party) sit EIGHT workgroup ids apart
+//   (chunks of 8 ciphertexts x R rows: id = chunk * 8R + row * 8 + ciphertext % 8).  Workgroup ids are dealt round-robin over
+//   the 8 XCDs, so the rows of one ciphertext -- which share the mask words, hence the monomial row and the key rows of every
+//   step (bootstrapping.jl:400-406) -- run on the same XCD at the same time and meet in its L2.
+__device__ __forceinline__ void rot_decode(const RotArgs &a, unsigned bid, size_t &gate, int &slot) {
+    if (a.map_mode == 0) { gate = bid % (size_t)a.ngates; slot = (int)(bid / (size_t)a.ngates); return; }
+    size_t base = 0;
+    int s0 = 0;
+    for (;;) {
+        const int pty = a.slot_party[s0];
+        int R = 1;
+        while (s0 + R < a.rows_per_gate && a.slot_party[s0 + R] == pty) R++;
+        const size_t sz = (size_t)a.ngates * R;
+        if (bid < base + sz || s0 + R >= a.rows_per_gate) {
+            const size_t idx = bid - base, chunk = idx / (8 * (size_t)R), j = idx % (8 * (size_t)R);
+            const size_t left = a.ngates - 8 * chunk, g8 = left < 8 ? left : 8;
+            gate = 8 * chunk + j % g8; slot = s0 + (int)(j / g8);
+            return;
+        }
+        base += sz; s0 += R;
+    }
+}
+
 // Key rows, monomial rows and the twist tables are read through buffer descriptors: SGPR base + 32-bit per-lane
 // offset + SGPR row offset, so a load costs no address arithmetic on the VALU (flat loads needed a 64-bit add each:
 // ~100 of the ~2000 VALU instructions of a CMux).

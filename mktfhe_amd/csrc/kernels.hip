@@ -280,8 +280,8 @@ void blindrotate_k1_kernel(const RotArgs a) {
     __syncthreads();
     // workgroups are dealt slot-major (all ciphertexts' rotations of one party/row are adjacent), so the workgroups
     // resident at any time stream the SAME party's key rows through L2; results are stored ciphertext-major
-    const size_t gate = bid % (size_t)a.ngates;
-    const int slot = (int)(bid / (size_t)a.ngates);
+    size_t gate; int slot;
+    rot_decode(a, bid, gate, slot);
     const size_t rot = gate * (size_t)a.rows_per_gate + slot;
     const int party = __builtin_amdgcn_readfirstlane(a.slot_party[slot]), row = __builtin_amdgcn_readfirstlane(a.slot_row[slot]);
     const uint32_t *at_src = a.lwe + gate * (size_t)a.lwe_stride + (size_t)party * a.n;
@@ -1515,8 +1515,8 @@ __global__ __launch_bounds__((2 * LT * Plan<LOGM, LR>::NT)) void blindrotate_wid
     for (int i = tid; i < M; i += G * NT) psi_l[i] = a.tw.psi[i];
     __syncthreads();
     const unsigned bid = blockIdx.x + a.block0;
-    const size_t gate = bid % (size_t)a.ngates;
-    const int slot = (int)(bid / (size_t)a.ngates);
+    size_t gate; int slot;
+    rot_decode(a, bid, gate, slot);
     const size_t rot = gate * (size_t)a.rows_per_gate + slot;
     const int party = __builtin_amdgcn_readfirstlane(a.slot_party[slot]), row = __builtin_amdgcn_readfirstlane(a.slot_row[slot]);
     const uint32_t *at_src = a.lwe + gate * (size_t)a.lwe_stride + (size_t)party * a.n;

@@ -25,6 +25,8 @@
 #include <stdint.h>
 
 #include "device_api.h"
+#include <type_traits>
+
 #include "fft_device.h"
 
 namespace mktd {
@@ -90,6 +92,19 @@ __device__ __forceinline__ Pt pt_msub(Pt acc, Pt x, Pt y) { Pt r; r.a = msub_laz
 __device__ __forceinline__ Pt pt_add_lazy(Pt x, Pt y) { Pt r; r.a = add_lazy<P1>(x.a, y.a); r.b = add_lazy<P2>(x.b, y.b); return r; }
 __device__ __forceinline__ Pt pt_mac(Pt acc, Pt x, Pt y) { Pt r; r.a = mac_lazy<P1, PI1>(acc.a, x.a, y.a); r.b = mac_lazy<P2, PI2>(acc.b, x.b, y.b); return r; }
 __device__ __forceinline__ Pt pt_canon4(Pt x) { Pt r; r.a = canon4<P1>(x.a); r.b = canon4<P2>(x.b); return r; }
+// WIDE lazy accumulation: the products x_j y_j of a sum over the gadget digits gathered in a 64-bit accumulator (ONE v_mad_u64_u32 per
+// term and residue) and reduced ONCE: sum_j x_j y_j 2^-32 mod P -- the value the chain of mac_lazy gives, for 1 + 4 / T
+// multiply-class instructions per term instead of 3 (6 in all).  Room: x < 2P (wide_x), y < P < 2^30: a term is below 2^61, the
+// Montgomery correction m P below 2^62, so T <= 4 terms stay below 2^64; x < P (wide_x_canon) admits T <= 12.
+struct Wide { uint64_t a, b; };
+__device__ __forceinline__ Pt wide_x(Pt x) { Pt r; r.a = umin32(x.a, x.a - 2u * P1); r.b = umin32(x.b, x.b - 2u * P2); return r; }     // lazy forward value [0, 4P) -> [0, 2P)
+__device__ __forceinline__ void wide_mac(Wide &acc, Pt x, Pt y) { acc.a += (uint64_t)x.a * y.a; acc.b += (uint64_t)x.b * y.b; }
+template <uint32_t P, uint32_t PINV> __device__ __forceinline__ uint32_t wide_reduce1(uint64_t z) {
+    const uint32_t m = (uint32_t)z * (0u - PINV);
+    const uint32_t s = (uint32_t)((z + (uint64_t)m * P) >> 32);      // < 2^32: (T 2^61 + 2^62) / 2^32 <= 3 * 2^30 for T <= 4; x < P: (12 P^2 + 2^32 P) / 2^32 < 4P
+    return umin32(s, s - 2u * P);                                     // [0, 2P): fine as the input of ntt_inverse and as the x of another product
+}
+__device__ __forceinline__ Pt wide_reduce(Wide w) { Pt r; r.a = wide_reduce1<P1, PI1>(w.a); r.b = wide_reduce1<P2, PI2>(w.b); return r; }
 // Lazy butterflies (D. Harvey, "Faster arithmetic for number-theoretic transforms", 2014), 4P < 2^32.
 // forward (Cooley-Tukey): x, y in [0, 4P) -> x + w y, x - w y in [0, 4P); FIRST: x < 2P already (a transform's first stage).
 // The forward table holds the NEGATED twiddle (2^32 - w, with the companion of w): q P - y w is then one multiply-add
@@ -528,7 +543,7 @@ __device__ __forceinline__ void lift_pair(Pt (&lo)[8], Pt (&hi)[8], uint64_t (&w
 
 // KMS phase 1 (bootstrapping.jl:389-443) with exact products: one workgroup per RLEV row rotation, accumulator (b, a) in
 // registers (slot e = coefficient e*NT + t); output: the row's two polynomials as split residue tables for phase 2
-template <int LOGN, bool BLK>
+template <int LOGN, bool BLK, bool WIDE = false>   // WIDE: l_gsw = 2, the digit products of an accumulator gathered in 64 bits (its own instantiation: its own register allocation)
 __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(2, 2))) void exact_kms_phase1_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
                                                                               const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe, int lwe_stride,
                                                                               int pre_switched, int n, int l, int logB, int blk_len, size_t ngates, int rows_per_gate,
@@ -579,6 +594,54 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
             const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
             if (at == 0) continue;
             Pt tacc[2][2][8];
+            // l = 2 (the headline gadget): the 2l = 4 digit transforms are all kept, and every accumulator gathers its four products
+            // WIDE (one multiply-add per term, one reduction per accumulator) right before its inverse transforms
+            if constexpr (WIDE) {
+                Pt zz[4][8];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) zz[g][e] = res_small(gd.digit(gd.prep(g >= 2 ? acc[1][e] : acc[0][e]), g & 1));   // :415-425 decompto!
+                    ntt_forward<LOGN>(zz[g], tw[0], lds, t);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) zz[g][e] = wide_x(zz[g][e]);
+                }
+                const uint64_t *rowb = brk + ((size_t)i * 4 * 4) * N + 8 * t;     // [digit g][poly][half][N]
+                auto output_poly = [&](auto ppc) {                               // written out twice: a rolled loop would index acc[pp] at run time (-> scratch)
+                    constexpr int pp = decltype(ppc)::value;
+                    Pt th[2][8];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        Wide wa[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) { wa[e].a = 0; wa[e].b = 0; }
+                        __builtin_amdgcn_sched_barrier(0);                     // the key rows of this accumulator are requested here, not above the transforms before (registers)
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+#pragma unroll
+                            for (int e = 0; e < 8; e++) wide_mac(wa[e], zz[g][e], unpack(rowb[(size_t)(g * 4 + pp * 2 + h) * N + e]));   // :427-432: the same sum  (plain global loads: through a buffer descriptor 13 instead of 36 spilled registers, and 8 % SLOWER)
+#pragma unroll
+                        for (int e = 0; e < 8; e++) th[h][e] = wide_reduce(wa[e]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    uint64_t w[8];
+                    lift_pair<LOGN>(th[0], th[1], w, tw[1], k, lds, t);
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {                                  // :435-437: (X^at S)[i] = +-S[i - at mod N]
+                        const uint32_t src = (uint32_t)(e * NT + t - (int)at) & (2u * N - 1u);
+                        const uint64_t v = lds[src & (N - 1)];
+                        acc[pp][e] += (src >= (uint32_t)N ? (uint64_t)0 - v : v) - w[e];
+                    }
+                };
+                output_poly(std::integral_constant<int, 0>{});
+                output_poly(std::integral_constant<int, 1>{});
+                continue;
+            }
+            if constexpr (!WIDE) {
 #pragma unroll
             for (int pp = 0; pp < 2; pp++)
 #pragma unroll
@@ -599,6 +662,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                             for (int e = 0; e < 8; e++) tacc[pp][h][e] = pt_mac(tacc[pp][h][e], z[e], unpack(rowp[(size_t)(pp * 2 + h) * N + e]));   // :427-432 / :639-646, exactly
                 }
+            }
             if (BLK) {
                 const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
 #pragma unroll
@@ -1004,9 +1068,15 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
             hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, true>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
                                a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, a.blk_len, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
         } else {
-            e = ntt_set_lds(exact_kms_phase1_kernel<LN, false>, lds); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, false>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
-                               a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, 1, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+            if (a.wide && a.l_gsw == 2) {
+                e = ntt_set_lds(exact_kms_phase1_kernel<LN, false, true>, lds); if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, false, true>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
+                                   a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, 1, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+            } else {
+                e = ntt_set_lds(exact_kms_phase1_kernel<LN, false>, lds); if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, false>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
+                                   a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, 1, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+            }
         }
         if (a.phase1_only) return hipGetLastError();
         ExactPhase2Args q;

@@ -1,0 +1,98 @@
+"""Fixed-seed slices of the builder-side soak / fuzz tools (tools/fuzz_shapes.py, tools/fuzz_exact.py, tools/soak.py), run under
+the driver's `-m gpu` pass, and the MKT_ARITH_EXACT gate paths at FULL key length.
+
+* fuzz_shapes: random small shapes of every rotation kernel that has more than one implementation, each forced grouping,
+  ragged batches, every stage and gate against the oracle;
+* fuzz_exact: random shapes and gadgets through the EXACT gate paths against the big-integer restatement; gadgets beyond
+  the two-prime modulus must be refused, never evaluated;
+* soak: repeated full batches must reproduce their first result word for word (an intermittent LDS race would not);
+* full-n EXACT: the parity tests of the EXACT paths run at n = 3 .. 12 key bits; here ONE gate per scheme kind runs the whole
+  blind rotation (n = 560 .. 687) against tests/ref_exact.py, whose products are the oracle's C schoolbook
+  (ora_negacyclic_schoolbook) -- an error that needs hundreds of CMux steps to surface (a lazy-residue range that drifts, an
+  accumulator that leaves [-P/2, P/2)) shows here and nowhere else.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import GATE_FUNCS, ROOT, encrypt_bits, gpu_scheme, keygen, mk, oracle_scheme
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_fuzz_shapes_slice(require_gpu):
+    import fuzz_shapes
+    log = []
+    assert fuzz_shapes.run(rounds=4, seed=77, log=log.append) == 0, "\n".join(log)
+    assert len(log) == 12
+
+
+def test_fuzz_exact_slice(require_gpu):
+    import fuzz_exact
+    log = []
+    bad, refused = fuzz_exact.run(rounds=10, seed=94, log=log.append)       # seed 94: all five scheme kinds and two gadgets beyond the modulus
+    assert bad == 0, "\n".join(log)
+    assert refused >= 1, "the slice must include a gadget beyond the modulus\n" + "\n".join(log)
+
+
+@pytest.mark.parametrize("p,arith", [(mk.CGGIparam, 0), (mk.KMS2party_N1024_l2, 0), (mk.Blockparam, 0), (mk.CCS2party, 0), (mk.KMS2party_N1024_l2, 1), (mk.CGGIparam, 1)],
+                         ids=lambda v: v.name if hasattr(v, "name") else ("exact" if v else "f64ref"))
+def test_soak_slice_repeated_batches_are_deterministic(require_gpu, p, arith):
+    """tools/soak.py at 6 repetitions: two dense gate levels over a chip-filling batch and over 64 gates (latency variant,
+    ragged groups) reproduce the first result word for word"""
+    import torch
+    crs, keys = keygen(p, 3)
+    sg = gpu_scheme(p, crs, keys, arith=arith)
+    for B in (1024 if p.scheme != mk.CCS else 256, 64):
+        bits = np.random.default_rng(4).integers(0, 2, 2 * B + 1).astype(bool)
+        c = np.empty((2 * B + 1, p.lwe_len), dtype=np.uint32)
+        nd = 16                                              # a few distinct fresh encryptions, repeated: the work does not depend on the values
+        enc = encrypt_bits(p, keys, bits[:nd], seed=40)
+        for j in range(2 * B + 1):
+            c[j] = enc[j % nd]
+        x = torch.from_numpy(c[:B].view(np.int32)).cuda(); y = torch.from_numpy(c[B + 1:].view(np.int32)).cuda()
+        ref = mk.NAND(x, y, sg).clone()
+        ref2 = mk.NAND(ref, mk.NAND(y, x, sg), sg).clone()
+        for _ in range(6):
+            o = mk.NAND(x, y, sg)
+            assert torch.equal(o, ref)
+            assert torch.equal(mk.NAND(o, mk.NAND(y, x, sg), sg), ref2)
+    sg.close()
+
+
+FULL_N = [mk.CGGIparam, mk.Blockparam, mk.KMS2party_N1024_l2, mk.KMS2partyblock.scaled(N=1024), mk.CCS2party.scaled(n=140)]
+
+
+@pytest.mark.parametrize("p", FULL_N, ids=lambda p: f"{p.name}-n{p.n}-N{p.N}")
+def test_exact_gate_at_full_key_length(require_gpu, p):
+    """one NAND per scheme kind through the EXACT path with the whole key (CCS: 140 of its 560 bits per party -- its restatement
+    is 10x the products) == the exact-arithmetic restatement, word for word, and it decrypts"""
+    import ref_exact as RX
+    crs, keys = keygen(p, 77)
+    so = oracle_scheme(p, crs, keys)
+    sx = gpu_scheme(p, crs, keys, arith=mk.ARITH_EXACT)
+    bits = np.array([1, 1], dtype=bool)
+    if p.multikey:           # inputs that involve every party: party 0's bit + (enc 1 + enc 0) of the others
+        def allp(j):
+            ct = mk.lwe_ith_encrypt(int(bits[j]), 0, keys[0], p, deterministic_seed=7700 + 100 * j).astype(np.uint32)
+            for i in range(1, p.k):
+                for m in (0, 1):
+                    ct = ct + mk.lwe_ith_encrypt(m, i, keys[i], p, deterministic_seed=7700 + 100 * j + 2 * i + m).astype(np.uint32)
+            return ct
+        x, y = allp(0)[None], allp(1)[None]
+    else:
+        c = encrypt_bits(p, keys, bits, seed=7700)
+        x, y = c[:1], c[1:]
+    out = sx.gate(0, x, y)
+    if p.scheme in (mk.KMS, mk.KMS_BLOCK):
+        want = RX.kms_gate(p, so, keys, crs, 0, x[0], y[0])
+    elif p.scheme == mk.CCS:
+        want = RX.ccs_gate(p, so, keys, crs, 0, x[0], y[0])
+    else:
+        want = RX.gate(p, so, keys[0].brk, 0, x[0], y[0])
+    assert np.array_equal(out[0], want)
+    assert np.array_equal(mk.lwe_decrypt(out, keys if p.multikey else keys[0], p), GATE_FUNCS[0](bits[:1], bits[1:]))
+    sx.close()
