@@ -458,6 +458,15 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
 #pragma unroll
             for (int e = 0; e < 8; e++) tp[e] = gd.prep(c ? acc[1][e] : acc[0][e]);      // :50-51 / :131-132 decompto!
             for (int j = 0; j < l; j++) {
+                // the rows of the block's first key bit are requested ahead of the digit's transform (at use, each was one exposed L2
+                // round trip per digit); a block's other key bits load theirs at use -- 96 accumulator registers leave no room
+                uint64_t kr0[2][8];
+                {
+                    const uint64_t *row0 = brk + (((size_t)(blk * LB) * 2 * l + (size_t)(c * l + j)) * 2) * N + 8 * t;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { kr0[0][e] = row0[e]; kr0[1][e] = row0[N + e]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 Pt z[8];
 #pragma unroll
                 for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(tp[e], j));
@@ -468,8 +477,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
                     const uint64_t *row = brk + (((size_t)(blk * LB + q) * 2 * l + (size_t)(c * l + j)) * 2) * N + 8 * t;
 #pragma unroll
                     for (int e = 0; e < 8; e++) {                        // :63-68 / :146-154, exactly
-                        tacc[q][0][e] = pt_mac(tacc[q][0][e], z[e], unpack(row[e]));
-                        tacc[q][1][e] = pt_mac(tacc[q][1][e], z[e], unpack(row[N + e]));
+                        tacc[q][0][e] = pt_mac(tacc[q][0][e], z[e], unpack(q == 0 ? kr0[0][e] : row[e]));
+                        tacc[q][1][e] = pt_mac(tacc[q][1][e], z[e], unpack(q == 0 ? kr0[1][e] : row[N + e]));
                     }
                 }
             }
@@ -650,17 +659,38 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
                     for (int e = 0; e < 8; e++) { tacc[pp][h][e].a = 0; tacc[pp][h][e].b = 0; }
             for (int c = 0; c < 2; c++)
                 for (int j = 0; j < l; j++) {
+                    // the digit's four key rows are REQUESTED here and consumed after its transform: left to the compiler they were loaded
+                    // at use, four rows x one exposed L2 round trip each per digit (16 per CMux at two waves per SIMD)
+                    const uint64_t *rowp = brk + (((size_t)i * 2 * l + (size_t)(c * l + j)) * 4) * N + 8 * t;   // [poly][half][N]
+                    // (all four rows ahead: 108 spilled registers.  Two ahead, the other two requested right after the transform, under the
+                    // first two rows' multiply-adds.  KMS_block keeps loading at use: its second accumulator set leaves no room.)
+                    constexpr bool PF = !BLK;
+                    uint64_t kr[2][8], ks[2][8];
+                    if constexpr (PF) {
+#pragma unroll
+                        for (int ph = 0; ph < 2; ph++)
+#pragma unroll
+                            for (int e = 0; e < 8; e++) kr[ph][e] = rowp[(size_t)ph * N + e];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     Pt z[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(gd.prep(c ? acc[1][e] : acc[0][e]), j));   // :415-425 / :625-633 decompto! (the rounding offset re-applied per digit: two instructions, sixteen registers less)
                     ntt_forward<LOGN>(z, tw[0], lds, t);
-                    const uint64_t *rowp = brk + (((size_t)i * 2 * l + (size_t)(c * l + j)) * 4) * N + 8 * t;   // [poly][half][N]
+                    if constexpr (PF) {
+#pragma unroll
+                        for (int ph = 0; ph < 2; ph++)
+#pragma unroll
+                            for (int e = 0; e < 8; e++) ks[ph][e] = rowp[(size_t)(2 + ph) * N + e];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int pp = 0; pp < 2; pp++)
 #pragma unroll
                         for (int h = 0; h < 2; h++)
 #pragma unroll
-                            for (int e = 0; e < 8; e++) tacc[pp][h][e] = pt_mac(tacc[pp][h][e], z[e], unpack(rowp[(size_t)(pp * 2 + h) * N + e]));   // :427-432 / :639-646, exactly
+                            for (int e = 0; e < 8; e++)                                // :427-432 / :639-646, exactly
+                                tacc[pp][h][e] = pt_mac(tacc[pp][h][e], z[e], unpack(PF ? (pp == 0 ? kr[h][e] : ks[h][e]) : rowp[(size_t)(pp * 2 + h) * N + e]));
                 }
             }
             if (BLK) {

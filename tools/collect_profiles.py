@@ -11,7 +11,7 @@ for f in glob.glob(f"{src}/bench_*.json"):
         open(f"{dst}/{tag}_{os.path.basename(f)}", "w").write("".join(lines))
 for f in glob.glob(f"{src}/trace_{wl}/*/*kernel_stats.csv"):
     shutil.copy(f, f"{dst}/{tag}_bench_{wl}_kernel_stats.csv")
-dirs = sorted(glob.glob(f"{src}/pmc_{wl}_*"))
+dirs = sorted(d for d in glob.glob(f"{src}/pmc_{wl}_*") if os.path.basename(d)[len(f"pmc_{wl}_"):] in ("fetch", "write", "clk", "sq1", "sq2"))   # exactly this name's passes (kms2_n1024 must not swallow kms2_n1024_exact)
 if dirs:
     with open(f"{dst}/{tag}_bench_{wl}_pmc.txt", "w") as out:
         out.write(f"# rocprofv3 --kernel-trace --pmc <counters> (separate passes), python3 bench.py --steps 2 --warmup 0 --workload {wl} --no-cpu-baseline --no-secondary\n")

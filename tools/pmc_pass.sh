@@ -1,0 +1,20 @@
+# usage (GPU box, repo root): bash tools/pmc_pass.sh <tag> <workload> <name> [full] [-- extra bench.py args]
+# rocprofv3 passes of ONE bench.py command (--steps 2 --warmup 0, no CPU baseline / secondary legs), each counter group in its own
+# run as MI355X_MICROARCH.md prescribes (--pmc only with --kernel-trace): FETCH_SIZE, WRITE_SIZE, clock + hit rates; `full` adds
+# the kernel-trace --stats run and the two SQ groups.  Output: gpurun_out/<tag>/{trace,pmc}_<name>_*; tools/collect_profiles.py
+# <tag> <name> turns them into profiles/<tag>_bench_<name>_{kernel_stats.csv,pmc.txt}.
+TAG=$1; WL=$2; NAME=$3; shift 3
+FULL=0; if [ "$1" = full ]; then FULL=1; shift; fi
+if [ "$1" = -- ]; then shift; fi
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
+ARGS="--workload $WL --no-cpu-baseline --no-secondary --no-roofline $*"
+run() { timeout 400 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/pmc_${NAME}_$1 -- python3 $R/bench.py --steps 2 --warmup 0 $ARGS > /dev/null 2>&1; }
+run fetch "FETCH_SIZE"
+run write "WRITE_SIZE"
+run clk "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU"
+if [ $FULL = 1 ]; then
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$NAME -- python3 $R/bench.py --steps 5 --warmup 1 $ARGS > $O/trace_$NAME.log 2>&1
+  run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"
+  run sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES"
+fi
+ls $O | grep "_${NAME}_" | tr '\n' ' '; echo
