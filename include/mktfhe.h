@@ -176,6 +176,11 @@ int mkt_gate_batch_ops(mkt_ctx *ctx, const uint8_t *ops, const uint32_t *x, cons
  * later region of the same pool provided no gate of this call reads a row this call writes */
 int mkt_gate_batch_gather(mkt_ctx *ctx, const uint8_t *ops, const uint32_t *pool, size_t pool_rows, const uint32_t *ix,
                           const uint32_t *iy, uint32_t *out, size_t B, int mem);
+/* MUX(s, a, b) = s ? a : b -- named by the north star; the reference has no MUX gate (gate.jl:1-57).  Two blind rotations and one
+ * key switch, built from the reference's own operators as CGGI16 builds it:
+ *   acc = blindrotate!(AND-linear(s, a)) + blindrotate!(AND-linear(NOT! s, b)), + 1/8 at X^0 of acc.b;  out = keyswitch!(acc)
+ * (a composite OR(AND(s, a), AND(NOT s, b)) of the reference's gates takes three full bootstraps).  s, a, b, out: [B][k*n+1] */
+int mkt_mux_batch(mkt_ctx *ctx, const uint32_t *s, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t B, int mem);
 /* gate.jl:55-58 NOT!: in-place negation, no bootstrap */
 int mkt_not_batch(mkt_ctx *ctx, uint32_t *x, size_t B, int mem);
 /* bootstrapping.jl:4-27 bootstrapping!: in place on [B][k*n+1] */
@@ -237,6 +242,7 @@ int mkt_multi_replicate(mkt_multi *m);
 int mkt_multi_set_option(mkt_multi *m, const char *name, int value);
 int mkt_multi_gate_batch(mkt_multi *m, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem);
 int mkt_multi_gate_batch_ops(mkt_multi *m, const uint8_t *ops, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem);
+int mkt_multi_mux_batch(mkt_multi *m, const uint32_t *s, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t B, int mem);
 int mkt_multi_bootstrap_batch(mkt_multi *m, uint32_t *lwe, size_t B, int mem);
 int mkt_multi_not_batch(mkt_multi *m, uint32_t *x, size_t B, int mem);
 int mkt_multi_blindrotate_batch(mkt_multi *m, const uint32_t *atilde, void *acc, size_t B, int mem);

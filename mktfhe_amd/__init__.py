@@ -8,7 +8,7 @@ from .params import *  # noqa: F401,F403
 from .params import Params  # noqa: F401
 from .scheme import (  # noqa: F401
     CRS, PartyKeys, Scheme, MultiScheme, party_keygen, setup, setup_multi, OP_NOT_X, OP_NOT_Y, lwe_encrypt, lwe_ith_encrypt, lwe_decrypt,
-    bootstrapping_, blindrotate_, keyswitch, NAND, AND, OR, XOR, XNOR, NOR, NOT_, MUX,
+    bootstrapping_, blindrotate_, keyswitch, NAND, AND, OR, XOR, XNOR, NOR, NOT_, MUX, MUX_composite,
     MEM_DEVICE, MEM_HOST, FMT_INT_COEFF, FMT_F64_FFT, ARITH_F64REF, ARITH_EXACT,
 )
 from ._lib import MktError, LIB_PATH  # noqa: F401

@@ -52,6 +52,7 @@ SYMBOLS = {
     "mkt_gate_batch": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _i]),
     "mkt_gate_batch_ops": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
     "mkt_gate_batch_gather": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _i]),
+    "mkt_mux_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
     "mkt_not_batch": (_i, [_vp, _vp, _sz, _i]),
     "mkt_bootstrap_batch": (_i, [_vp, _vp, _sz, _i]),
     "mkt_modswitch_batch": (_i, [_vp, _vp, _vp, _vp, _sz, _i]),
@@ -80,6 +81,7 @@ SYMBOLS = {
     "mkt_multi_set_option": (_i, [_vp, C.c_char_p, _i]),
     "mkt_multi_gate_batch": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _i]),
     "mkt_multi_gate_batch_ops": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "mkt_multi_mux_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
     "mkt_multi_bootstrap_batch": (_i, [_vp, _vp, _sz, _i]),
     "mkt_multi_not_batch": (_i, [_vp, _vp, _sz, _i]),
     "mkt_multi_blindrotate_batch": (_i, [_vp, _vp, _vp, _sz, _i]),

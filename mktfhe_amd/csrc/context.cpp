@@ -357,16 +357,20 @@ int do_keyswitch(mkt_ctx *c, const void *acc, uint32_t *out, size_t B) {
     return MKT_OK;
 }
 
-// bootstrapping!(lin) -> out for a device-resident chunk
-int bootstrap_chunk(mkt_ctx *c, const uint32_t *lin, uint32_t *out, size_t B) {
+// bootstrapping.jl:8-24 (mod-switch, test vector, blindrotate!) for a device-resident chunk of linear combinations: ws_acc <- accumulators
+int rotate_chunk(mkt_ctx *c, const uint32_t *lin, size_t B) {
     const mkt_params &p = c->p;
-    int r;
     if (!mkt::is_kms(p.scheme)) {
         HIPCHK(c, mktd::launch_testvector(p.W, lin, c->sh.lwe_len, c->logN, c->sh.kacc, c->ws_acc, B, c->stream));
-        if ((r = do_blindrotate(c, lin, c->sh.lwe_len, 0, nullptr, c->ws_acc, c->ws_lev, c->ws_scratch, B))) return r;
-    } else {
-        if ((r = do_blindrotate(c, lin, c->sh.lwe_len, 0, lin, c->ws_acc, c->ws_lev, c->ws_scratch, B))) return r;
+        return do_blindrotate(c, lin, c->sh.lwe_len, 0, nullptr, c->ws_acc, c->ws_lev, c->ws_scratch, B);
     }
+    return do_blindrotate(c, lin, c->sh.lwe_len, 0, lin, c->ws_acc, c->ws_lev, c->ws_scratch, B);
+}
+
+// bootstrapping!(lin) -> out for a device-resident chunk
+int bootstrap_chunk(mkt_ctx *c, const uint32_t *lin, uint32_t *out, size_t B) {
+    int r;
+    if ((r = rotate_chunk(c, lin, B))) return r;
     return do_keyswitch(c, c->ws_acc, out, B);
 }
 
@@ -881,6 +885,35 @@ int mkt_gate_batch_gather(mkt_ctx *c, const uint8_t *ops, const uint32_t *pool, 
         for (size_t j = 0; j < B; j++) if (ix[j] >= pool_rows || iy[j] >= pool_rows) return fail(c, MKT_ERR_ARG, "mkt_gate_batch_gather: operand index outside the pool");
     }
     return gate_impl(c, 0, ops, pool, pool, pool_rows, ix, iy, out, B, mem);
+}
+
+// MUX(s, a, b) = s ? a : b with TWO blind rotations and ONE key switch (the reference has no MUX gate, gate.jl:1-57; this is the
+// CGGI16 construction written with the reference's own operators):
+//   acc = blindrotate!(AND-linear(s, a)) + blindrotate!(AND-linear(NOT! s, b)), + 1/8 at X^0 of acc.b;  out = keyswitch!(acc)
+// Each rotation leaves +-1/8 and at most one of the two ANDs holds, so the sum + 1/8 is +-1/8 again.  A composite of the
+// reference's gates, OR(AND(s, a), AND(NOT s, b)), costs three full bootstraps.
+int mkt_mux_batch(mkt_ctx *c, const uint32_t *sel, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t B, int mem) {
+    if (!c || !sel || !a || !b || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    MKT_EXACT_GATE(c);
+    int r;
+    if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
+    DevGuard dg(c->device);
+    Timer whole(c, 0);
+    const size_t len = (size_t)c->sh.lwe_len, words = (size_t)(1 + c->sh.kacc) * c->p.N;
+    Staged ss{c}, sa{c}, sb{c}, so{c};
+    if ((r = ss.in(sel, B * len * 4, mem, true)) || (r = sa.in(a, B * len * 4, mem, true)) || (r = sb.in(b, B * len * 4, mem, true)) || (r = so.in(out, B * len * 4, mem, false))) return r;
+    constexpr size_t HALF = CHUNK_GATES / 2;                  // two rotations per gate share the workspace chunk
+    for (size_t off = 0; off < B; off += HALF) {
+        const size_t nb = std::min(HALF, B - off);
+        if ((r = ensure_workspace(c, 2 * nb))) return r;
+        const uint32_t *ps = (const uint32_t *)ss.dev + off * len;
+        HIPCHK(c, mktd::launch_gate_linear(MKT_AND, nullptr, ps, (const uint32_t *)sa.dev + off * len, nullptr, nullptr, c->ws_lin, (int)len, nb, c->stream));
+        HIPCHK(c, mktd::launch_gate_linear(MKT_AND | MKT_OP_NOT_X, nullptr, ps, (const uint32_t *)sb.dev + off * len, nullptr, nullptr, c->ws_lin + nb * len, (int)len, nb, c->stream));
+        if ((r = rotate_chunk(c, c->ws_lin, 2 * nb))) return r;
+        HIPCHK(c, mktd::launch_mux_combine(c->p.W, c->ws_acc, nb, words, c->stream));
+        if ((r = do_keyswitch(c, c->ws_acc, (uint32_t *)so.dev + off * len, nb))) return r;
+    }
+    return so.out(out);
 }
 
 int mkt_not_batch(mkt_ctx *c, uint32_t *x, size_t B, int mem) {

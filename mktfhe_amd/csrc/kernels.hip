@@ -208,6 +208,17 @@ __global__ void gate_linear_kernel(int op_all, const uint8_t *__restrict__ ops, 
     }
 }
 
+// native MUX: acc[j] += acc[B + j] (two blind-rotation outputs, polynomial by polynomial) and +1/8 at X^0 of the b polynomial
+template <typename WORD>
+__global__ void mux_combine_kernel(WORD *__restrict__ acc, size_t B, size_t words) {
+    const size_t total = B * words;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        WORD v = (WORD)(acc[i] + acc[total + i]);
+        if (i % words == 0) v = (WORD)(v + ((WORD)1 << (WordTraits<WORD>::W - 3)));
+        acc[i] = v;
+    }
+}
+
 __global__ void negate_kernel(uint32_t *x, size_t total) {   // gate.jl:55-58
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) x[i] = 0u - x[i];
 }
@@ -1175,6 +1186,13 @@ hipError_t launch_gate_linear(int op, const uint8_t *ops, const uint32_t *x, con
     const size_t total = B * (size_t)len;
     if (!total) return hipSuccess;
     hipLaunchKernelGGL(gate_linear_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, op, ops, x, y, ix, iy, out, len, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_mux_combine(int W, void *acc, size_t B, size_t words, hipStream_t s) {
+    if (!B) return hipSuccess;
+    if (W == 64) hipLaunchKernelGGL(mux_combine_kernel<uint64_t>, dim3(blocks_for(B * words, 256)), dim3(256), 0, s, (uint64_t *)acc, B, words);
+    else hipLaunchKernelGGL(mux_combine_kernel<uint32_t>, dim3(blocks_for(B * words, 256)), dim3(256), 0, s, (uint32_t *)acc, B, words);
     return hipGetLastError();
 }
 

@@ -240,6 +240,13 @@ int mkt_multi_gate_batch_ops(mkt_multi *m, const uint8_t *ops, const uint32_t *x
                         [&](mkt_ctx *c, void **a, size_t nb) { return mkt_gate_batch_ops(c, (const uint8_t *)a[0], (const uint32_t *)a[1], (const uint32_t *)a[2], (uint32_t *)a[3], nb, mem); });
 }
 
+int mkt_multi_mux_batch(mkt_multi *m, const uint32_t *sel, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t B, int mem) {
+    if (!m || !sel || !a || !b || !out) return mfail(m, MKT_ERR_ARG, "bad argument");
+    const size_t rb = mkt_internal_lwe_len(m->ctx[0]) * 4;
+    return sharded_call(m, B, mem, {{sel, rb, true, false}, {a, rb, true, false}, {b, rb, true, false}, {out, rb, false, true}},
+                        [&](mkt_ctx *c, void **p, size_t nb) { return mkt_mux_batch(c, (const uint32_t *)p[0], (const uint32_t *)p[1], (const uint32_t *)p[2], (uint32_t *)p[3], nb, mem); });
+}
+
 int mkt_multi_bootstrap_batch(mkt_multi *m, uint32_t *lwe, size_t B, int mem) {
     if (!m || !lwe) return mfail(m, MKT_ERR_ARG, "bad argument");
     const size_t rb = mkt_internal_lwe_len(m->ctx[0]) * 4;

@@ -388,6 +388,19 @@ class Scheme:
         self._ck(_lib.lib().mkt_gate_batch_gather(self.h, pops, pp, self._batch(kp), pix, piy, po, B, mem))
         return ko
 
+    def mux(self, s, a, b, out=None):
+        """MUX(s, a, b) = s ? a : b with two blind rotations and one key switch (mkt_mux_batch; the reference has no MUX gate)"""
+        ps, mem, ks = _arg(s, np.uint32, scheme=self)
+        pa, m1, ka = _arg(a, np.uint32, scheme=self)
+        pb, m2, kb = _arg(b, np.uint32, scheme=self)
+        if out is None:
+            out = ks.new_empty(ks.shape) if mem == MEM_DEVICE else np.empty_like(ks)
+        po, m3, ko = _arg(out, np.uint32, writable=True, scheme=self)
+        if not (mem == m1 == m2 == m3) or not (tuple(ks.shape) == tuple(ka.shape) == tuple(kb.shape)) or ks.shape[-1] != self.params.lwe_len:
+            raise ValueError("ciphertext shape / memory mismatch")
+        self._ck(_lib.lib().mkt_mux_batch(self.h, ps, pa, pb, po, self._batch(ks), mem))
+        return ko
+
     def bootstrapping_(self, ctxt):
         p, mem, k = _arg(ctxt, np.uint32, writable=True, scheme=self)
         if k.shape[-1] != self.params.lwe_len:
@@ -590,6 +603,18 @@ class MultiScheme:
         self._ck(_lib.lib().mkt_multi_gate_batch_ops(self.h, pops, px, py, po, self._batch(kx), mem))
         return ko
 
+    def mux(self, s, a, b, out=None):
+        ps, mem, ks = _arg(s, np.uint32)
+        pa, m1, ka = _arg(a, np.uint32)
+        pb, m2, kb = _arg(b, np.uint32)
+        if out is None:
+            out = ks.new_empty(ks.shape) if mem == MEM_DEVICE else np.empty_like(ks)
+        po, m3, ko = _arg(out, np.uint32, writable=True)
+        if not (mem == m1 == m2 == m3) or not (tuple(ks.shape) == tuple(ka.shape) == tuple(kb.shape)) or ks.shape[-1] != self.params.lwe_len:
+            raise ValueError("ciphertext shape / memory mismatch")
+        self._ck(_lib.lib().mkt_multi_mux_batch(self.h, ps, pa, pb, po, self._batch(ks), mem))
+        return ko
+
     def bootstrapping_(self, ctxt):
         p, mem, k = _arg(ctxt, np.uint32, writable=True)
         self._ck(_lib.lib().mkt_multi_bootstrap_batch(self.h, p, self._batch(k), mem))
@@ -690,9 +715,15 @@ def XNOR(c1, c2, scheme: Scheme, out=None):
     return scheme.gate(4, c1, c2, out)
 
 
-def MUX(s, c1, c2, scheme: Scheme):
-    """s ? c1 : c2 -- not a reference operator (gate.jl has none): the composite OR(AND(s, c1), AND(NOT s, c2)) of the
-    reference's gates, with the two ANDs evaluated as one batch"""
+def MUX(s, c1, c2, scheme: Scheme, out=None):
+    """s ? c1 : c2 -- not a reference operator (gate.jl has none; the north star names it): two blind rotations and one key
+    switch, blindrotate!(AND-linear(s, c1)) + blindrotate!(AND-linear(NOT s, c2)) + 1/8, then keyswitch! (mkt_mux_batch)"""
+    return scheme.mux(s, c1, c2, out)
+
+
+def MUX_composite(s, c1, c2, scheme: Scheme):
+    """the same function as the composite OR(AND(s, c1), AND(NOT s, c2)) of the reference's gates (three bootstraps), the two
+    ANDs evaluated as one batch"""
     ns = s.clone() if hasattr(s, "clone") else np.array(s, copy=True)
     NOT_(ns, scheme)
     if hasattr(s, "clone"):

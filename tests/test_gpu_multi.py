@@ -143,6 +143,81 @@ def test_circuit_level_is_one_call_whatever_the_gate_mix(require_gpu):
     sg.close()
 
 
+def oracle_mux(so, p, s, a, b):
+    """the native MUX restated WITHOUT composite gates, on the oracle's operators: two blindrotate! (bootstrapping.jl:8-24 on the
+    AND-linear parts, gate.jl:10-17 / NOT! :55-58), the accumulators added polynomial by polynomial, + 1/8 at X^0 of b, one keyswitch!"""
+    accs = []
+    for x, y in ((s, a), (_neg(s), b)):
+        lin = O.gate_linear(1, x, y)
+        at, bt = so.modswitch(lin)
+        accs.append(so.blindrotate(at, so.testvector(bt)).astype(np.uint64))
+    mask = np.uint64((1 << p.W) - 1)
+    acc = ((accs[0] + accs[1]) & mask).reshape(-1, p.N)              # [(b, a_0 ..)][N]
+    acc[0, 0] = (acc[0, 0] + (np.uint64(1) << np.uint64(p.W - 3))) & mask
+    return so.keyswitch(acc)
+
+
+MUX_SETS = [mk.CGGIparam.scaled(n=20, N=256), mk.Blockparam.scaled(n=30, N=256, blk_d=10), mk.KMS2party.scaled(n=16, N=256),
+            mk.KMS2partyblock.scaled(n=24, N=256, blk_d=8), mk.CCS2party.scaled(n=12, N=256), mk.KMS4party.scaled(n=8, N=256),
+            mk.CGGIparam.scaled(n=16, N=256, k=2)]
+
+
+@pytest.mark.parametrize("p", MUX_SETS, ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
+def test_native_mux_matches_its_oracle_restatement(require_gpu, p):
+    """mkt_mux_batch (two rotations + one key switch) == the same construction on the oracle's operators, word for word, for all
+    eight (s, a, b) combinations with the three operands under different parties; it decrypts to s ? a : b; the composite of the
+    reference's gates decrypts to the same bits; host and device memory; ragged batch"""
+    import torch
+    crs, keys = keygen(p, 61)
+    so, sg = oracle_scheme(p, crs, keys), gpu_scheme(p, crs, keys)
+    B = 11
+    combos = np.array([[(i >> 2) & 1, (i >> 1) & 1, i & 1] for i in range(B)], dtype=bool)      # every combination, then repeats
+    k = p.nparty
+    enc = lambda bit, party, seed: mk.lwe_ith_encrypt(int(bit), party % k, keys[party % k], p, deterministic_seed=seed)   # noqa: E731
+    s = np.stack([enc(combos[j, 0], j, 6100 + j) for j in range(B)])
+    a = np.stack([enc(combos[j, 1], j + 1, 6200 + j) for j in range(B)])
+    b = np.stack([enc(combos[j, 2], j + 2, 6300 + j) for j in range(B)])
+    want = np.stack([oracle_mux(so, p, s[j], a[j], b[j]) for j in range(B)])
+    got = mk.MUX(s, a, b, sg)
+    assert np.array_equal(got, want)
+    td = lambda v: torch.from_numpy(v.view(np.int32)).cuda()   # noqa: E731
+    got_d = mk.MUX(td(s), td(a), td(b), sg)
+    torch.cuda.synchronize()
+    assert np.array_equal(got_d.cpu().numpy().view(np.uint32), want)
+    kk = keys if p.multikey else keys[0]
+    plain = np.where(combos[:, 0], combos[:, 1], combos[:, 2])
+    assert np.array_equal(mk.lwe_decrypt(got, kk, p), plain)
+    assert np.array_equal(mk.lwe_decrypt(mk.MUX_composite(s, a, b, sg), kk, p), plain)
+    # a second level on the outputs (the output noise of the native MUX must leave room for another gate)
+    lvl2 = mk.NAND(got[:5], got[5:10], sg)
+    assert np.array_equal(mk.lwe_decrypt(lvl2, kk, p), ~(plain[:5] & plain[5:10]))
+    sg.close()
+
+
+def test_native_mux_full_size_exact_and_sharded(require_gpu):
+    """the headline shape: native MUX == its oracle restatement on a sample; the EXACT arithmetic and a three-shard evaluator
+    decrypt to s ? a : b as well (EXACT words differ from the Float64 ones by construction)"""
+    p = mk.KMS2party_N1024_l2
+    crs, keys = keygen(p, 62)
+    so = oracle_scheme(p, crs, keys)
+    B = 8
+    combos = np.array([[(i >> 2) & 1, (i >> 1) & 1, i & 1] for i in range(B)], dtype=bool)
+    s = np.stack([mk.lwe_ith_encrypt(int(combos[j, 0]), j % 2, keys[j % 2], p, deterministic_seed=6400 + j) for j in range(B)])
+    a = np.stack([mk.lwe_ith_encrypt(int(combos[j, 1]), (j + 1) % 2, keys[(j + 1) % 2], p, deterministic_seed=6500 + j) for j in range(B)])
+    b = np.stack([mk.lwe_ith_encrypt(int(combos[j, 2]), j % 2, keys[j % 2], p, deterministic_seed=6600 + j) for j in range(B)])
+    plain = np.where(combos[:, 0], combos[:, 1], combos[:, 2])
+    sg = gpu_scheme(p, crs, keys)
+    got = mk.MUX(s, a, b, sg)
+    assert np.array_equal(got[:2], np.stack([oracle_mux(so, p, s[j], a[j], b[j]) for j in range(2)]))
+    assert np.array_equal(mk.lwe_decrypt(got, keys, p), plain)
+    multi = multi_scheme(p, crs, keys, [0, 0, 0], mk.ARITH_F64REF)
+    assert np.array_equal(multi.mux(s, a, b), got)
+    multi.close(); sg.close()
+    sx = gpu_scheme(p, crs, keys, arith=mk.ARITH_EXACT)
+    assert np.array_equal(mk.lwe_decrypt(mk.MUX(s, a, b, sx), keys, p), plain)
+    sx.close()
+
+
 # ---------------------------------------------------------------- the multi-shard evaluator
 MULTI_SETS = [
     (mk.KMS2party.scaled(n=16, N=256), mk.ARITH_F64REF),

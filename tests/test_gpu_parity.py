@@ -466,7 +466,7 @@ def test_circuit_on_device(require_gpu):
         assert np.array_equal(og[:nb].cpu().numpy().view(np.uint32), oo)
     # MUX (composite of the reference's gates): selector under party 0, data under parties 1 / 0
     sel, d1, d0 = inputs[0], inputs[1], inputs[2]
-    m = mk.MUX(sel, d1, d0, sg)
+    m = mk.MUX_composite(sel, d1, d0, sg)
     assert np.array_equal(mk.lwe_decrypt(m.cpu().numpy().view(np.uint32), keys, p), np.where(bits[0], bits[1], bits[2]))
     cm = CI.Circuit(); s_, a_, b_ = cm.input(), cm.input(), cm.input(); cm.output(cm.MUX(s_, a_, b_))
     (mo,) = CI.evaluate_on(cm, [sel, d1, d0], sg)
