@@ -217,9 +217,11 @@ def make_inputs(mk, torch, p, keys, sch, B, rank, dev, kind):
     return bits, fct[:B].clone(), fct[B:].clone()
 
 
-def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, world, red_dev):
-    """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; max over ranks"""
+def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, world, red_dev, op="nand"):
+    """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; max over ranks.
+    op "mux": the native MUX(x, y, x) = x AND y (two blind rotations + one key switch per gate) instead of NAND"""
     out = torch.empty_like(x)
+    step = (lambda: mk.NAND(x, y, sch, out=out)) if op == "nand" else (lambda: mk.MUX(x, y, x, sch, out=out))
 
     def barrier():
         torch.cuda.synchronize()
@@ -228,12 +230,12 @@ def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, w
         torch.cuda.synchronize()
 
     for _ in range(warmup):
-        mk.NAND(x, y, sch, out=out)
+        step()
     barrier()
     sch.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        mk.NAND(x, y, sch, out=out)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     rot_ms, rot_n = sch.kernel_ms(1)
@@ -250,7 +252,7 @@ def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, w
         dist.all_reduce(t)
         per_rank = [float(v) for v in t.cpu()]
     res = out.cpu().numpy().view(np.uint32)
-    want = ~(bits[:B] & bits[B:])
+    want = ~(bits[:B] & bits[B:]) if op == "nand" else (bits[:B] & bits[B:])
     got = mk.lwe_decrypt(res, keys if p.multikey else keys[0], p)
     errs = int(np.count_nonzero(got != want))
     if world > 1:                                   # wrong decryptions of the whole job, not of rank 0's shard
@@ -539,6 +541,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch gates per GPU; strong: --batch gates in total, sharded over the ranks")
     ap.add_argument("--launcher", default="ranks", choices=["ranks", "inproc"], help="ranks: one process per GPU under torch.distributed (default); inproc: one process, all GPUs through mkt_multi_*")
     ap.add_argument("--instances", type=int, default=1024, help="--workload adder8: independent circuit instances")
+    ap.add_argument("--op", default="nand", choices=["nand", "mux"], help="nand (default: the metric); mux: the native MUX gate, two blind rotations + one key switch per gate (ranks launcher)")
     ap.add_argument("--arith", default="f64ref", choices=["f64ref", "exact"], help="f64ref: the reference's Float64 transforms, bit-identical to it (default); exact: integer NTT over two 30-bit primes (MKT_ARITH_EXACT: all five schemes)")
     ap.add_argument("--inputs", default="mixed", choices=["mixed", "fresh"], help="mixed: every ciphertext involves all k parties (default); fresh: single-party first-level encryptions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -589,7 +592,7 @@ def main():
     bits, x, y = make_inputs(mk, torch, p, keys, sch, B, rank, dev, args.inputs)
     torch.cuda.synchronize()
     allc = np.concatenate([x.cpu().numpy(), y.cpu().numpy()]).view(np.uint32)
-    t = time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, args.steps, args.warmup, world, red_dev)
+    t = time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, args.steps, args.warmup, world, red_dev, args.op)
     res = t["res"]
     kern = sch.last_kernel_name()
 
@@ -598,11 +601,11 @@ def main():
         total_batch = args.batch if args.scaling == "strong" else world * B
         gates = total_batch * args.steps
         line = {
-            "metric": "NAND gate-bootstraps/sec", "value": gates / t["elapsed"], "unit": "gates/s", "n_gpus": world,
+            "metric": "NAND gate-bootstraps/sec" if args.op == "nand" else "MUX gates/sec (native: two blind rotations + one key switch per gate)", "value": gates / t["elapsed"], "unit": "gates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t["elapsed"] / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64" if args.arith == "f64ref" else "u32x2-residue", "data": "synthetic",
             "config": {"workload": desc, "params": pname, "parties": p.k, "N": p.N, "n": p.n, "ring_bits": p.W,
-                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": "NAND", "inputs": args.inputs, "arith": "F64REF" if args.arith == "f64ref" else "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)", "sharding": "gates across GPUs, keys replicated",
+                       "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": args.op.upper(), "inputs": args.inputs, "arith": "F64REF" if args.arith == "f64ref" else "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)", "sharding": "gates across GPUs, keys replicated",
                        "launcher": "ranks (one process per GPU, torch.distributed)"},
             "ranks_seen": ranks_seen, "per_rank_ms_per_step": t["per_rank_ms"],
             # Wrong decryptions are the parameter set's own output noise (profiles/r03_noise_theory_vs_measured.md: predicted
@@ -616,7 +619,8 @@ def main():
             "kernels_ms_per_step": {"blindrotate": t["rot_ms"] / max(args.steps, 1), "kms_phase2": t["p2_ms"] / max(args.steps, 1),
                                     "keyswitch": t["ks_ms"] / max(args.steps, 1)},
         }
-        line["roofline"] = rot_roofline(mk, p, B, t, args.workload, kern) if args.arith == "f64ref" else exact_rot_roofline(mk, p, B, t, kern, args.workload)
+        nrot = B if args.op == "nand" else 2 * B            # a MUX gate is two blind rotations
+        line["roofline"] = rot_roofline(mk, p, nrot, t, args.workload, kern) if args.arith == "f64ref" else exact_rot_roofline(mk, p, nrot, t, kern, args.workload)
 
     # ---- circuit throughput (--workload adder8): rank 0, N = 1 ----
     if rank == 0 and world == 1 and args.workload == "adder8":
@@ -661,7 +665,7 @@ def main():
         line["roofline_transform"] = transform_roofline(mk, torch, local, dev)
 
     # ---- CPU baseline leg (oracle, "port"): rank 0, at every world size (the other ranks wait at the final barrier) ----
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and args.op == "nand":
         line["cpu_baseline"], line["oracle_bitexact"] = cpu_baseline(p, crs, keys, allc, B, res, args, args.arith == "f64ref")   # EXACT words differ from the Float64 reference by construction (checked against big-integer arithmetic in tests)
 
     if rank == 0:

@@ -224,7 +224,9 @@ int mkt_get_monomial(mkt_ctx *ctx, int e, double *out_host);
 typedef struct mkt_multi mkt_multi;
 /* flags: MKT_MULTI_PRIVATE_KEYS = shards that share a device do NOT share its key set: each gets its own replicated copy, as
  * shards on distinct devices do (exercises the device-to-device replication on a one-GPU box; costs one key copy per shard) */
-enum { MKT_MULTI_PRIVATE_KEYS = 1 };
+/* MKT_MULTI_STAGE_ALWAYS = device-resident arguments always travel through the shards' staging buffers (peer copies), as they do
+ * for a shard on another device than the array's (that path on a one-GPU box) */
+enum { MKT_MULTI_PRIVATE_KEYS = 1, MKT_MULTI_STAGE_ALWAYS = 2 };
 int mkt_multi_create(const mkt_params *params, int arith_mode, const int *devices, int nshards, int flags, mkt_multi **out);
 int mkt_multi_destroy(mkt_multi *m);
 const char *mkt_multi_last_error(const mkt_multi *m);  /* m may be NULL: last creation error */

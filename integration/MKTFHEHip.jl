@@ -56,13 +56,15 @@ function pack_ksk(ksk::Array{<:MKTFHE.LEV}, n::Int, f::Int)
     out
 end
 
-function create(p::MktParams, ffter, device)
-    ctx = Ref{Ptr{Cvoid}}()
-    check(ccall((:mkt_ctx_create, LIB), Cint, (Ref{MktParams}, Cint, Cint, Ref{Ptr{Cvoid}}), p, 0, device, ctx))
-    c = ctx[]                                               # install the caller's own tables verbatim (fft.jl:18-45)
+function install_tables(c, ffter)                          # the caller's own tables verbatim (fft.jl:18-45)
     check(ccall((:mkt_set_twiddles, LIB), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}),
                 c, ffter.Ψ, ffter.Ψinv, ffter.roots, ffter.rootsinv), c)
     c
+end
+function create(p::MktParams, ffter, device)
+    ctx = Ref{Ptr{Cvoid}}()
+    check(ccall((:mkt_ctx_create, LIB), Cint, (Ref{MktParams}, Cint, Cint, Ref{Ptr{Cvoid}}), p, 0, device, ctx))
+    install_tables(ctx[], ffter)
 end
 load_brk(c, i, v) = check(ccall((:mkt_load_brk, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{ComplexF64}, Cint), c, i, v, FFT_FORM), c)
 load_ksk(c, i, v) = check(ccall((:mkt_load_ksk, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{UInt32}), c, i, v), c)
@@ -75,43 +77,41 @@ end
 wbits(::Type{UInt32}) = 32
 wbits(::Type{UInt64}) = 64
 
+# parameter block and key upload per scheme type: params_of(s) -> (MktParams, ring word type, parties); upload!(c, s) fills context c
 # scheme.jl:107-116 -- single-key, RLWE length k
-function HipScheme(s::MKTFHE.CGGI{T}; device = 0) where T
-    p = MktParams(0, s.n, s.N, s.k, wbits(T), s.gswpar.l, s.gswpar.logB, 0, 0, 0, 0, s.kskpar.l, s.kskpar.logB, 0, 0)
-    c = create(p, s.ffter, device)
-    load_brk(c, 0, pack_rgsw(s.btk.brk)); load_ksk(c, 0, pack_ksk(s.btk.ksk, s.n, s.kskpar.l))
-    HipScheme{T}(c, s.k, s.n, s.N, 1)
-end
+params_of(s::MKTFHE.CGGI{T}) where T = (MktParams(0, s.n, s.N, s.k, wbits(T), s.gswpar.l, s.gswpar.logB, 0, 0, 0, 0, s.kskpar.l, s.kskpar.logB, 0, 0), T, 1)
 # scheme.jl:168-179 -- block-binary keys: n = d * ℓ
-function HipScheme(s::MKTFHE.LMSS{T}; device = 0) where T
-    p = MktParams(1, s.n, s.N, s.k, wbits(T), s.gswpar.l, s.gswpar.logB, 0, 0, 0, 0, s.kskpar.l, s.kskpar.logB, s.ℓ, s.d)
-    c = create(p, s.ffter, device)
+params_of(s::MKTFHE.LMSS{T}) where T = (MktParams(1, s.n, s.N, s.k, wbits(T), s.gswpar.l, s.gswpar.logB, 0, 0, 0, 0, s.kskpar.l, s.kskpar.logB, s.ℓ, s.d), T, 1)
+function upload!(c, s::Union{MKTFHE.CGGI, MKTFHE.LMSS})
     load_brk(c, 0, pack_rgsw(s.btk.brk)); load_ksk(c, 0, pack_ksk(s.btk.ksk, s.n, s.kskpar.l))
-    HipScheme{T}(c, s.k, s.n, s.N, 1)
 end
 # scheme.jl:209-219
-function HipScheme(s::MKTFHE.CCS{T}; device = 0) where T
-    p = MktParams(2, s.n, s.N, s.k, wbits(T), 0, 0, 0, 0, s.unipar.l, s.unipar.logB, s.kskpar.l, s.kskpar.logB, 0, 0)
-    c = create(p, s.ffter, device)
+params_of(s::MKTFHE.CCS{T}) where T = (MktParams(2, s.n, s.N, s.k, wbits(T), 0, 0, 0, 0, s.unipar.l, s.unipar.logB, s.kskpar.l, s.kskpar.logB, 0, 0), T, s.k)
+function upload!(c, s::MKTFHE.CCS)
     load_crs(c, pack_polys(s.a))
     for (i, b) in enumerate(s.btk)
         load_brk(c, i - 1, pack_unienc(b.brk)); load_ksk(c, i - 1, pack_ksk(b.ksk, s.n, s.kskpar.l)); load_pub(c, i - 1, pack_polys(b.b))
     end
-    HipScheme{T}(c, s.k, s.n, s.N, s.k)
 end
 # scheme.jl:256-265 and :301-312 (T = LWE word, R = ring word)
-function HipScheme(s::Union{MKTFHE.KMS{T, R}, MKTFHE.KMS_block{T, R}}; device = 0) where {T, R}
+function params_of(s::Union{MKTFHE.KMS{T, R}, MKTFHE.KMS_block{T, R}}) where {T, R}
     g, lv, u = s.btk[1].gswpar, s.btk[1].levpar, s.btk[1].unipar
     blk = s isa MKTFHE.KMS_block
-    p = MktParams(blk ? 4 : 3, s.n, s.N, s.k, wbits(R), g.l, g.logB, lv.l, lv.logB, u.l, u.logB, s.kskpar.l, s.kskpar.logB,
-                  blk ? s.ℓ : 0, blk ? s.d : 0)
-    c = create(p, s.ffter, device)
+    (MktParams(blk ? 4 : 3, s.n, s.N, s.k, wbits(R), g.l, g.logB, lv.l, lv.logB, u.l, u.logB, s.kskpar.l, s.kskpar.logB, blk ? s.ℓ : 0, blk ? s.d : 0), R, s.k)
+end
+function upload!(c, s::Union{MKTFHE.KMS, MKTFHE.KMS_block})
     load_crs(c, pack_polys(s.a))
     for (i, b) in enumerate(s.btk)
         load_brk(c, i - 1, pack_rgsw(b.brk)); load_ksk(c, i - 1, pack_ksk(b.ksk, s.n, s.kskpar.l))
         load_rlk(c, i - 1, b.rlk); load_pub(c, i - 1, pack_polys(b.b))
     end
-    HipScheme{R}(c, s.k, s.n, s.N, s.k)
+end
+const RefScheme = Union{MKTFHE.CGGI, MKTFHE.LMSS, MKTFHE.CCS, MKTFHE.KMS, MKTFHE.KMS_block}
+function HipScheme(s::RefScheme; device = 0)
+    p, R, np = params_of(s)
+    c = create(p, s.ffter, device)
+    upload!(c, s)
+    HipScheme{R}(c, s.k, s.n, s.N, np)
 end
 close!(s::HipScheme) = (ccall((:mkt_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), s.ctx); s.ctx = C_NULL; nothing)
 # a second handle over the same resident keys for another Julia thread (own stream / workspace): mkt_ctx_fork
@@ -172,4 +172,54 @@ for (op, name) in enumerate((:NAND, :AND, :OR, :XOR, :XNOR, :NOR))
     @eval MKTFHE.$name(c1::Vector{<:MKTFHE.LWE}, c2::Vector{<:MKTFHE.LWE}, s::HipScheme) = gate($(op - 1), c1, c2, s)
 end
 # NOT! (gate.jl:55-58) needs no scheme: the reference's own method applies unchanged.
+
+# a different gate per pair, ONE batch (mkt_gate_batch_ops) -- the shape of test/KMS.jl:29-34, which draws a gate per step:
+# ops[j] in 0:5 (NAND .. NOR), + 8 / + 16 to negate the first / second input first (NOT!)
+function gates(ops::Vector{<:Integer}, c1::Vector{<:MKTFHE.LWE}, c2::Vector{<:MKTFHE.LWE}, s::HipScheme)
+    x = reduce(hcat, flat.(c1)); y = reduce(hcat, flat.(c2)); out = similar(x)
+    check(ccall((:mkt_gate_batch_ops, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{UInt32}, Ptr{UInt32}, Ptr{UInt32}, Csize_t, Cint),
+                s.ctx, UInt8.(ops), x, y, out, length(c1), HOST), s.ctx)
+    [MKTFHE.LWE(out[end, j], out[1:end-1, j]) for j in 1:length(c1)]
+end
+# MUX(sel, a, b) = sel ? a : b -- the reference has no MUX gate; two blind rotations + one key switch (mkt_mux_batch)
+function MUX(sel::Vector{<:MKTFHE.LWE}, a::Vector{<:MKTFHE.LWE}, b::Vector{<:MKTFHE.LWE}, s::HipScheme)
+    xs = reduce(hcat, flat.(sel)); xa = reduce(hcat, flat.(a)); xb = reduce(hcat, flat.(b)); out = similar(xs)
+    check(ccall((:mkt_mux_batch, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt32}, Ptr{UInt32}, Ptr{UInt32}, Ptr{UInt32}, Csize_t, Cint),
+                s.ctx, xs, xa, xb, out, length(sel), HOST), s.ctx)
+    [MKTFHE.LWE(out[end, j], out[1:end-1, j]) for j in 1:length(sel)]
+end
+MUX(sel::MKTFHE.LWE, a::MKTFHE.LWE, b::MKTFHE.LWE, s::HipScheme) = MUX([sel], [a], [b], s)[1]
+
+# ---- one scheme over all the GPUs of the node, one Julia process (mkt_multi_*: keys uploaded once on devices[1], replicated
+#      device to device, the batch cut into contiguous shards, results written into the one output array; no collective) ----
+mutable struct HipMultiScheme{R<:Unsigned}
+    m::Ptr{Cvoid}
+    k::Int; n::Int; N::Int; nparty::Int
+end
+mcheck(rc, m=C_NULL) = rc < 0 ? error(unsafe_string(ccall((:mkt_multi_last_error, LIB), Cstring, (Ptr{Cvoid},), m))) : rc
+function HipMultiScheme(s::RefScheme; devices::Vector{<:Integer} = [0])
+    p, R, np = params_of(s)
+    h = Ref{Ptr{Cvoid}}()
+    mcheck(ccall((:mkt_multi_create, LIB), Cint, (Ref{MktParams}, Cint, Ptr{Cint}, Cint, Cint, Ref{Ptr{Cvoid}}), p, 0, Cint.(devices), length(devices), 0, h))
+    c0 = ccall((:mkt_multi_ctx, LIB), Ptr{Cvoid}, (Ptr{Cvoid}, Cint), h[], 0)    # the first device's context: tables and keys go there ...
+    install_tables(c0, s.ffter); upload!(c0, s)
+    mcheck(ccall((:mkt_multi_replicate, LIB), Cint, (Ptr{Cvoid},), h[]), h[])      # ... and are copied to the other devices (hipMemcpyPeer)
+    HipMultiScheme{R}(h[], s.k, s.n, s.N, np)
+end
+close!(s::HipMultiScheme) = (ccall((:mkt_multi_destroy, LIB), Cint, (Ptr{Cvoid},), s.m); s.m = C_NULL; nothing)
+function gate(op, c1::Vector{<:MKTFHE.LWE}, c2::Vector{<:MKTFHE.LWE}, s::HipMultiScheme)
+    x = reduce(hcat, flat.(c1)); y = reduce(hcat, flat.(c2)); out = similar(x)
+    mcheck(ccall((:mkt_multi_gate_batch, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{UInt32}, Ptr{UInt32}, Ptr{UInt32}, Csize_t, Cint),
+                 s.m, op, x, y, out, length(c1), HOST), s.m)
+    [MKTFHE.LWE(out[end, j], out[1:end-1, j]) for j in 1:length(c1)]
+end
+function MKTFHE.bootstrapping!(ctxts::Vector{MKTFHE.LWE{UInt32}}, s::HipMultiScheme)
+    v = reduce(hcat, flat.(ctxts))
+    mcheck(ccall((:mkt_multi_bootstrap_batch, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt32}, Csize_t, Cint), s.m, v, length(ctxts), HOST), s.m)
+    for (j, c) in enumerate(ctxts); unflat!(c, @view v[:, j]); end
+    ctxts
+end
+for (op, name) in enumerate((:NAND, :AND, :OR, :XOR, :XNOR, :NOR))
+    @eval MKTFHE.$name(c1::Vector{<:MKTFHE.LWE}, c2::Vector{<:MKTFHE.LWE}, s::HipMultiScheme) = gate($(op - 1), c1, c2, s)
+end
 end

@@ -31,8 +31,13 @@ struct mkt_multi {
     std::vector<int> devices;          // per shard
     std::vector<mkt_ctx *> ctx;        // per shard; ctx[i] is a root context for the first shard of a device, a fork otherwise
     std::vector<int> root_of;          // per shard: index of the first shard on the same device
+    bool stage_always = false;         // MKT_MULTI_STAGE_ALWAYS
     bool sealed = false;               // keys replicated, logical shards forked
     std::string err;
+    // staging buffers of the shards whose device is not the one a device-resident argument lives on: [shard][argument slot],
+    // grown on demand and kept (a hipMalloc / hipFree pair per call costs more than the peer copy of a ciphertext slice)
+    struct Stage { void *p = nullptr; size_t cap = 0; };
+    std::vector<std::vector<Stage>> stage;
 };
 
 namespace {
@@ -67,15 +72,21 @@ struct ShardArg {
     size_t bytes = 0;
     int dev = 0, remote_dev = 0;
     bool copy_back = false;
-    int prepare(const void *base, size_t row_bytes, size_t lo, size_t hi, int mem, int shard_dev, bool in, bool out) {
+    int prepare(const void *base, size_t row_bytes, size_t lo, size_t hi, int mem, int shard_dev, bool in, bool out, mkt_multi::Stage &pool, bool always) {
         dev = shard_dev;
         bytes = (hi - lo) * row_bytes;
         char *rows = (char *)const_cast<void *>(base) + lo * row_bytes;
         if (mem == MKT_MEM_HOST || !bytes) { use = rows; return 0; }
         const int owner = device_of_ptr(base);
-        if (owner < 0 || owner == shard_dev) { use = rows; return 0; }
+        if (owner < 0 || (owner == shard_dev && !always)) { use = rows; return 0; }
         remote = rows; remote_dev = owner; copy_back = out;
-        if (hipMalloc(&stage, bytes) != hipSuccess) return -1;
+        if (pool.cap < bytes) {
+            if (pool.p) (void)hipFree(pool.p);
+            pool.p = nullptr; pool.cap = 0;
+            if (hipMalloc(&pool.p, bytes) != hipSuccess) return -1;
+            pool.cap = bytes;
+        }
+        stage = pool.p;
         if (in && (hipMemcpyPeer(stage, dev, remote, remote_dev, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)) return -1;   // the shard's own stream is non-blocking: the copy must have landed before its kernels start
         use = stage;
         return 0;
@@ -83,8 +94,7 @@ struct ShardArg {
     int finish() {
         int rc = 0;
         if (stage && copy_back && (hipMemcpyPeer(remote, remote_dev, stage, dev, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)) rc = -1;
-        if (stage) (void)hipFree(stage);
-        stage = nullptr;
+        stage = nullptr;                       // the buffer stays with the shard (mkt_multi::stage)
         return rc;
     }
 };
@@ -131,8 +141,9 @@ int sharded_call(mkt_multi *m, size_t B, int mem, const std::vector<ArgSpec> &sp
         std::vector<ShardArg> args(specs.size());
         std::vector<void *> ptrs(specs.size());
         int rc = MKT_OK;
+        if (m->stage[s].size() < specs.size()) m->stage[s].resize(specs.size());     // this shard's thread only
         for (size_t i = 0; i < specs.size(); i++) {
-            if (args[i].prepare(specs[i].base, specs[i].row_bytes, lo, hi, mem, m->devices[s], specs[i].in, specs[i].out) != 0) { rc = MKT_ERR_HIP; why = "staging a remote device buffer failed"; }
+            if (args[i].prepare(specs[i].base, specs[i].row_bytes, lo, hi, mem, m->devices[s], specs[i].in, specs[i].out, m->stage[s][i], m->stage_always) != 0) { rc = MKT_ERR_HIP; why = "staging a remote device buffer failed"; }
             ptrs[i] = args[i].use;
         }
         if (rc == MKT_OK) {
@@ -152,13 +163,14 @@ extern "C" {
 const char *mkt_multi_last_error(const mkt_multi *m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
 
 int mkt_multi_create(const mkt_params *params, int arith_mode, const int *devices, int nshards, int flags, mkt_multi **out) {
-    if (!params || !devices || !out || nshards < 1 || nshards > 1024 || (flags & ~MKT_MULTI_PRIVATE_KEYS)) return mfail(nullptr, MKT_ERR_ARG, "bad argument");
+    if (!params || !devices || !out || nshards < 1 || nshards > 1024 || (flags & ~(MKT_MULTI_PRIVATE_KEYS | MKT_MULTI_STAGE_ALWAYS))) return mfail(nullptr, MKT_ERR_ARG, "bad argument");
     *out = nullptr;
     auto *m = new mkt_multi();
-    m->p = *params; m->arith = arith_mode;
+    m->p = *params; m->arith = arith_mode; m->stage_always = (flags & MKT_MULTI_STAGE_ALWAYS) != 0;
     m->devices.assign(devices, devices + nshards);
     m->ctx.assign((size_t)nshards, nullptr);
     m->root_of.assign((size_t)nshards, -1);
+    m->stage.assign((size_t)nshards, {});
     for (int s = 0; s < nshards; s++) {
         // MKT_MULTI_PRIVATE_KEYS: shards that share a device still get their own replicated key copy (the replication path on a one-GPU box)
         if (!(flags & MKT_MULTI_PRIVATE_KEYS)) for (int r = 0; r < s; r++) if (m->devices[r] == m->devices[s]) { m->root_of[s] = m->root_of[r]; break; }
@@ -173,6 +185,8 @@ int mkt_multi_create(const mkt_params *params, int arith_mode, const int *device
 
 int mkt_multi_destroy(mkt_multi *m) {
     if (!m) return MKT_OK;
+    for (size_t s = 0; s < m->stage.size(); s++)
+        for (auto &st : m->stage[s]) if (st.p) { int prev = -1; (void)hipGetDevice(&prev); (void)hipSetDevice(m->devices[s]); (void)hipFree(st.p); if (prev >= 0) (void)hipSetDevice(prev); }
     for (size_t s = m->ctx.size(); s-- > 0;) if (m->ctx[s]) (void)mkt_ctx_destroy(m->ctx[s]);   // forks first, roots last (either order is safe: the key set is reference counted)
     delete m;
     return MKT_OK;

@@ -153,7 +153,7 @@ def oracle_mux(so, p, s, a, b):
         accs.append(so.blindrotate(at, so.testvector(bt)).astype(np.uint64))
     mask = np.uint64((1 << p.W) - 1)
     acc = ((accs[0] + accs[1]) & mask).reshape(-1, p.N)              # [(b, a_0 ..)][N]
-    acc[0, 0] = (acc[0, 0] + (np.uint64(1) << np.uint64(p.W - 3))) & mask
+    acc[0, 0] = np.uint64((int(acc[0, 0]) + (1 << (p.W - 3))) & int(mask))
     return so.keyswitch(acc)
 
 
@@ -230,10 +230,11 @@ MULTI_SETS = [
 
 
 def multi_scheme(p, crs, keys, devices, arith, private_keys=False):
-    return mk.setup_multi(p, devices, keys=keys if p.multikey else keys[0], a=crs, arith=arith, private_keys=private_keys)
+    # replicated keys are tested together with the staged data path (device arrays through the shards' staging buffers)
+    return mk.setup_multi(p, devices, keys=keys if p.multikey else keys[0], a=crs, arith=arith, private_keys=private_keys, stage_always=private_keys)
 
 
-@pytest.mark.parametrize("private", [False, True], ids=["shared-keys", "replicated-keys"])
+@pytest.mark.parametrize("private", [False, True], ids=["shared-keys", "replicated-keys-staged-io"])
 @pytest.mark.parametrize("nshards", [2, 3])
 @pytest.mark.parametrize("p,arith", MULTI_SETS, ids=lambda v: v.name if hasattr(v, "name") else ("exact" if v else "f64ref"))
 def test_multi_shard_evaluator_equals_the_single_context(require_gpu, p, arith, nshards, private):

@@ -486,6 +486,13 @@ def test_c_example_through_the_abi(require_gpu, tmp_path):
                            "-o", exe, "-L" + lib, "-lmktfhe_hip", "-Wl,-rpath," + lib])
     out = subprocess.run([exe, "24", "256"], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+    # examples/multi_nand.c: the multi-shard evaluator (mkt_multi_*), per-gate ops and the native MUX from plain C; three
+    # logical shards of the one device, a ragged split of 13 gates
+    exe2 = str(tmp_path / "multi_nand")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "multi_nand.c"),
+                           "-o", exe2, "-L" + lib, "-lmktfhe_hip", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe2, "24", "256", "3", "1"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok") and "gates [5, 9)" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=24, N=256), mk.KMS2party.scaled(n=12, N=256), mk.Blockparam.scaled(n=30, N=256, blk_d=10),

@@ -439,6 +439,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/mktfhe.h but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     assert _lib.lib().mkt_abi_version() == 3
+    # the reference-side shim (unexecuted: no Julia in the image) may only ccall symbols the header declares
+    jl = open(os.path.join(ROOT, "integration", "MKTFHEHip.jl")).read()
+    called = set(re.findall(r"ccall\(\(:(mkt_[a-z0-9_]+)", jl))
+    assert called and called <= declared, called - declared
+    # ... and so may the C examples
+    for ex in ("kms_nand.c", "multi_nand.c"):
+        used = set(re.findall(r"\b(mkt_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "examples", ex)).read()))
+        assert used and used <= declared, (ex, used - declared)
 
 
 def test_no_cpu_fallback_and_argument_errors():
