@@ -219,9 +219,11 @@ def make_inputs(mk, torch, p, keys, sch, B, rank, dev, kind):
 
 def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, world, red_dev, op="nand"):
     """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; max over ranks.
-    op "mux": the native MUX(x, y, x) = x AND y (two blind rotations + one key switch per gate) instead of NAND"""
+    op "mux": the native MUX(x, y, z) with z = x rotated by one position in the batch (two blind rotations + one key switch per
+    gate; z must not be x itself: AND-linear(NOT x, x) has an all-zero mask and its rotation would be skipped)"""
     out = torch.empty_like(x)
-    step = (lambda: mk.NAND(x, y, sch, out=out)) if op == "nand" else (lambda: mk.MUX(x, y, x, sch, out=out))
+    z = torch.roll(x, 1, 0).contiguous() if op == "mux" else None
+    step = (lambda: mk.NAND(x, y, sch, out=out)) if op == "nand" else (lambda: mk.MUX(x, y, z, sch, out=out))
 
     def barrier():
         torch.cuda.synchronize()
@@ -252,7 +254,7 @@ def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, w
         dist.all_reduce(t)
         per_rank = [float(v) for v in t.cpu()]
     res = out.cpu().numpy().view(np.uint32)
-    want = ~(bits[:B] & bits[B:]) if op == "nand" else (bits[:B] & bits[B:])
+    want = ~(bits[:B] & bits[B:]) if op == "nand" else np.where(bits[:B], bits[B:], np.roll(bits[:B], 1))
     got = mk.lwe_decrypt(res, keys if p.multikey else keys[0], p)
     errs = int(np.count_nonzero(got != want))
     if world > 1:                                   # wrong decryptions of the whole job, not of rank 0's shard

@@ -36,7 +36,9 @@ struct Tune {
     int rot_blkg = 0;       // block schemes: rotations per workgroup, 0 automatic
     int ccs_stagger = 0;
     int ccs_pipe = -1;      // two-group CCS kernel: -1 automatic (below one chip-fill), 0 never, 1 always
-    int rot_map = 0;        // workgroup id -> (ciphertext, slot) mapping of the k = 1 rotation kernels (kernel_common.h rot_decode)
+    int rot_map = 1;        // workgroup id -> (ciphertext, slot) mapping of the k = 1 rotation kernels (kernel_common.h rot_decode): 1 = the RLEV rows of one
+                            // (ciphertext, party) on one XCD at one time -- 25 % less fabric traffic at KMS k = 2 (FETCH_SIZE 15.3 -> 11.4 GB per launch,
+                            // L2 misses -27 %), time -0.3 ... -2.5 % (profiles/r04j_bench_kms2_n1024_map{0,1}_pmc.txt)
     int exact_wide = 1;     // EXACT KMS phase 1 at l_gsw = 2: wide (64-bit) digit-product accumulation
     void from_env() {
         rot_variant = env_int("MKT_ROT_VARIANT", rot_variant); rot_stagger = env_int("MKT_ROT_STAGGER", rot_stagger);

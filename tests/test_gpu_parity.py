@@ -763,7 +763,8 @@ def test_bench_multi_rank_launch_on_a_shared_gpu(require_gpu):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["decrypt_errors"] == 0
     assert abs(j["value"] - 2 * 128 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
-    assert j["roofline"]["kernel"] == "blindrotate_k1_kernel" and 0 < j["roofline"]["frac"] < 1
+    # 128 rotations per rank leave compute units idle: the engine picks the latency variant and the line names THAT kernel
+    assert j["roofline"]["kernel"] == "blindrotate_wide_kernel" and 0 < j["roofline"]["frac"] < 1
 
 
 @pytest.mark.parametrize("workload,batch", [("kms4party", 24), ("ccs8_n2048", 6)])
