@@ -221,7 +221,10 @@ class Scheme:
     def close(self):
         if getattr(self, "h", None):
             if getattr(self, "_owned", True):        # a borrowed view (MultiScheme.shard) never destroys the context
-                _lib.lib().mkt_ctx_destroy(self.h)
+                try:
+                    _lib.lib().mkt_ctx_destroy(self.h)
+                except Exception:                    # interpreter shutdown: the module globals may already be gone
+                    pass
             self.h = None
 
     __del__ = close
@@ -519,7 +522,10 @@ class MultiScheme:
 
     def close(self):
         if getattr(self, "h", None):
-            _lib.lib().mkt_multi_destroy(self.h)
+            try:
+                _lib.lib().mkt_multi_destroy(self.h)
+            except Exception:                        # interpreter shutdown
+                pass
             self.h = None
 
     __del__ = close

@@ -7,7 +7,7 @@ TAG=$1; WL=$2; NAME=$3; shift 3
 FULL=0; if [ "$1" = full ]; then FULL=1; shift; fi
 if [ "$1" = -- ]; then shift; fi
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
-ARGS="--workload $WL --no-cpu-baseline --no-secondary --no-roofline $*"
+ARGS="--workload $WL --no-cpu-baseline --no-secondary ${NOROOF---no-roofline} $*"     # NOROOF= (set, empty) keeps the transform legs in the profiled command
 run() { timeout 400 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/pmc_${NAME}_$1 -- python3 $R/bench.py --steps 2 --warmup 0 $ARGS > /dev/null 2>&1; }
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
