@@ -296,17 +296,36 @@ __device__ __forceinline__ void exchange(cplx (&z)[NB][1 << LOGR], cplx *lds, in
 //   u = a[j+k] * Psi[m + (j >> (b+1))];  a[j], a[j+k] = a[j] + u, a[j] - u
 // In: slot e = point e*NT + t.  Out: slot e = point t*R + e.  NB independent transforms share the
 // twiddle loads and the barriers.
-template <int LOGM, int LOGR, int NB, int PASS = 0, int MO = -1>
-__device__ __forceinline__ void fft_forward_pass(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t, const LaneX &lx) {
+// MO bit 10 (0x400): the twiddles of the NEXT pass are read from the table before the exchange that precedes it, so their LDS
+// latency passes under the exchange instead of in front of the pass's first butterfly (the compiler keeps every table read behind
+// the staging writes it cannot tell apart from the table, and waits for it 1-13 instructions later: tools/isa.sh)
+template <int LOGM, int LOGR, int NB, int PASS>
+__device__ __forceinline__ void tw_load_fwd(const cplx *__restrict__ psi, int t, cplx (&w)[(1 << LOGR) - 1]) {
     using P = Plan<LOGM, LOGR, NB>;
+    constexpr int lo = P::lo(PASS);
+    int n = 0;
+#pragma unroll
+    for (int s = 0; s < P::nst(PASS); s++) {
+        const int b = P::hib(PASS) - s, sb = b - lo;
+        const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
+#pragma unroll
+        for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) w[n++] = psi[twbase + g];
+    }
+}
+template <int LOGM, int LOGR, int NB, int PASS = 0, int MO = -1>
+__device__ __forceinline__ void fft_forward_pass(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t, const LaneX &lx, const cplx (&wpre)[(1 << LOGR) - 1]) {
+    using P = Plan<LOGM, LOGR, NB>;
+    constexpr bool PF = MO >= 0 && (MO & 0x400) != 0;
     constexpr int p = PASS, lo = P::lo(p);
+    int n = 0;
 #pragma unroll
     for (int s = 0; s < P::nst(p); s++) {
         const int b = P::hib(p) - s, sb = b - lo;
         const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
 #pragma unroll
         for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) {
-            const cplx w = psi[twbase + g];
+            const cplx w = PF ? wpre[n] : psi[twbase + g];
+            n++;
 #pragma unroll
             for (int q = 0; q < (1 << sb); q++) {
                 const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
@@ -327,31 +346,52 @@ __device__ __forceinline__ void fft_forward_pass(cplx (&z)[NB][1 << LOGR], const
         }
     }
     if constexpr (p < P::NPASS - 1) {
+        cplx wnext[(1 << LOGR) - 1];
+        if constexpr (PF) tw_load_fwd<LOGM, LOGR, NB, PASS + 1>(psi, t, wnext);
         exchange<LOGM, LOGR, NB, P::lo(p), P::lo(p + 1), true, PASS, MO>(z, lds, t, lx);
-        fft_forward_pass<LOGM, LOGR, NB, PASS + 1, MO>(z, psi, lds, t, lx);
+        fft_forward_pass<LOGM, LOGR, NB, PASS + 1, MO>(z, psi, lds, t, lx, wnext);
     }
 }
 template <int LOGM, int LOGR, int NB, int MO = -1>
 __device__ __forceinline__ void fft_forward(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psi, cplx *lds, int t, const LaneX &lx) {
+    constexpr bool PF = MO >= 0 && (MO & 0x400) != 0;
+    cplx w0[(1 << LOGR) - 1];
+    if constexpr (PF) tw_load_fwd<LOGM, LOGR, NB, 0>(psi, t, w0);
     if (Route<LOGM, LOGR, MO>::guard_fwd) __syncthreads();
-    fft_forward_pass<LOGM, LOGR, NB, 0, MO>(z, psi, lds, t, lx);
+    fft_forward_pass<LOGM, LOGR, NB, 0, MO>(z, psi, lds, t, lx, w0);
 }
 
 // fft.jl:159-209: t, u = a[j], a[j+k];  a[j] = t + u;  a[j+k] = (t - u) * Psiinv[m + (j >> (b+1))]
 // In: slot e = point t*R + e.  Out: slot e = point e*NT + t.
 // CONJ: `psiinv` points at the FORWARD table Psi and the butterflies multiply by its conjugate (Psiinv == conj(Psi)
 // entry for entry, fft.jl:33-34), so one table -- e.g. a copy resident in LDS -- serves both directions.
-template <int LOGM, int LOGR, int NB, bool CONJ, int PASS, int MO = -1>
-__device__ __forceinline__ void fft_inverse_pass(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t, const LaneX &lx) {
+template <int LOGM, int LOGR, int NB, int PASS>
+__device__ __forceinline__ void tw_load_inv(const cplx *__restrict__ psiinv, int t, cplx (&w)[(1 << LOGR) - 1]) {
     using P = Plan<LOGM, LOGR, NB>;
+    constexpr int lo = P::lo(PASS);
+    int n = 0;
+#pragma unroll
+    for (int s = P::nst(PASS) - 1; s >= 0; s--) {
+        const int b = P::hib(PASS) - s, sb = b - lo;
+        const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
+#pragma unroll
+        for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) w[n++] = psiinv[twbase + g];
+    }
+}
+template <int LOGM, int LOGR, int NB, bool CONJ, int PASS, int MO = -1>
+__device__ __forceinline__ void fft_inverse_pass(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t, const LaneX &lx, const cplx (&wpre)[(1 << LOGR) - 1]) {
+    using P = Plan<LOGM, LOGR, NB>;
+    constexpr bool PF = MO >= 0 && (MO & 0x400) != 0;
     constexpr int p = PASS, lo = P::lo(p);
+    int n = 0;
 #pragma unroll
     for (int s = P::nst(p) - 1; s >= 0; s--) {
         const int b = P::hib(p) - s, sb = b - lo;
         const int twbase = (1 << (LOGM - 1 - b)) + ((t >> lo) << (LOGR - 1 - sb));
 #pragma unroll
         for (int g = 0; g < (1 << (LOGR - 1 - sb)); g++) {
-            const cplx w = psiinv[twbase + g];
+            const cplx w = PF ? wpre[n] : psiinv[twbase + g];
+            n++;
 #pragma unroll
             for (int q = 0; q < (1 << sb); q++) {
                 const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
@@ -373,14 +413,19 @@ __device__ __forceinline__ void fft_inverse_pass(cplx (&z)[NB][1 << LOGR], const
         }
     }
     if constexpr (p > 0) {
+        cplx wnext[(1 << LOGR) - 1];
+        if constexpr (PF) tw_load_inv<LOGM, LOGR, NB, PASS - 1>(psiinv, t, wnext);
         exchange<LOGM, LOGR, NB, P::lo(p), P::lo(p - 1), false, PASS, MO>(z, lds, t, lx);
-        fft_inverse_pass<LOGM, LOGR, NB, CONJ, PASS - 1, MO>(z, psiinv, lds, t, lx);
+        fft_inverse_pass<LOGM, LOGR, NB, CONJ, PASS - 1, MO>(z, psiinv, lds, t, lx, wnext);
     }
 }
 template <int LOGM, int LOGR, int NB, bool CONJ = false, int MO = -1>
 __device__ __forceinline__ void fft_inverse(cplx (&z)[NB][1 << LOGR], const cplx *__restrict__ psiinv, cplx *lds, int t, const LaneX &lx) {
+    constexpr bool PF = MO >= 0 && (MO & 0x400) != 0;
+    cplx w0[(1 << LOGR) - 1];
+    if constexpr (PF) tw_load_inv<LOGM, LOGR, NB, Plan<LOGM, LOGR, NB>::NPASS - 1>(psiinv, t, w0);
     if (Route<LOGM, LOGR, MO>::guard_inv) __syncthreads();
-    fft_inverse_pass<LOGM, LOGR, NB, CONJ, Plan<LOGM, LOGR, NB>::NPASS - 1, MO>(z, psiinv, lds, t, lx);
+    fft_inverse_pass<LOGM, LOGR, NB, CONJ, Plan<LOGM, LOGR, NB>::NPASS - 1, MO>(z, psiinv, lds, t, lx, w0);
 }
 
 // The barriers of fft_inverse / fft_forward without the transform: thread groups of a workgroup that sit out a transform

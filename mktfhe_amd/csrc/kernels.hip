@@ -272,7 +272,11 @@ void blindrotate_k1_kernel(const RotArgs a) {
     using P = Plan<LOGM, LR, NB>;   // NB transforms at a time share twiddle loads and barriers
     // exchange routes: the block kernels at even sizes keep every legal exchange in the wave (mode 1: measured +4.5 % at
     // KMS2partyblock), everything else the library default (mode 8)
-    constexpr int MO = (LB > 1 && !(LOGM & 1)) ? 1 : -1;
+#ifndef MKT_TW_PF
+#define MKT_TW_PF 1       // the next pass's twiddles read ahead of the exchange in front of it (fft_device.h, MO bit 10): 1 = plain kernels, 2 = block kernels too
+#endif
+    constexpr int PFB = ((MKT_TW_PF >= 1 && LB == 1) || MKT_TW_PF >= 2) ? 0x400 : 0;
+    constexpr int MO = (LB > 1 && !(LOGM & 1)) ? (1 | PFB) : (PFB ? 0x4ff : -1);
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
@@ -804,7 +808,7 @@ template <int LOGM, typename WORD, int LT = 0, int BT = 0>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2))) void ccs_blindrotate_kernel(const CcsArgs a) {
     using P = Plan<LOGM, LOGR, 1>;
     constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
-    constexpr int MO1 = 0xff;                                  // library-default exchange routes
+    constexpr int MO1 = 0xff;                                  // library-default exchange routes (twiddles read ahead of the exchanges, MO bit 10: -0.7 % here, not used)
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     cplx *psi_l = lds + P::LDS_CPLX;
     const int t = threadIdx.x;

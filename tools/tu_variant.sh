@@ -5,7 +5,7 @@ cd $(dirname $0)/../mktfhe_amd/csrc
 mkdir -p /tmp/mkt_tuv
 OBJ=$(ls build/*.o); NEW=""
 for TU in $TUS; do
-  TF=$(grep "^TUFLAGS_$TU *=" Makefile | sed 's/^[^=]*= *//')        # the unit's own flags (Makefile)
+  TF=$(grep "^TUFLAGS_$TU *=" Makefile | sed 's/^[^=]*= *//' | sed 's/$(OPT_TRACKERS)/-mllvm -amdgpu-use-amdgpu-trackers/; s/$(OPT_MAXILP)/-mllvm -amdgpu-sched-strategy=max-ilp/; s/$(OPT_MEMCLAUSE)/-mllvm -amdgpu-sched-strategy=max-memory-clause/')        # the unit's own flags (Makefile)
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-cuda-compat -Wno-pass-failed -Wno-unused-function \
       $TF $EXTRA -DMKT_TU=$TU -c kernels.hip -o /tmp/mkt_tuv/kernels_tu${TU}_$SFX.o || touch /tmp/mkt_tuv/failed_$SFX ) &
   OBJ=$(echo "$OBJ" | grep -v kernels_tu$TU.o); NEW="$NEW /tmp/mkt_tuv/kernels_tu${TU}_$SFX.o"
