@@ -572,7 +572,8 @@ def main():
         local = int(os.environ["MKT_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    D.init_process_group(backend, device=dev)     # "nccl" is RCCL on ROCm; rendezvous + timing barrier only
+    D.init_process_group(backend, device=dev)     # "nccl" is RCCL on ROCm; rendezvous + timing barrier only (falls back to gloo if RCCL cannot start)
+    backend = D.ACTIVE_BACKEND or backend
     red_dev = dev if backend == "nccl" else "cpu"
     ranks_seen = 1
     if world > 1:
@@ -609,7 +610,7 @@ def main():
             "config": {"workload": desc, "params": pname, "parties": p.k, "N": p.N, "n": p.n, "ring_bits": p.W,
                        "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": args.op.upper(), "inputs": args.inputs, "arith": "F64REF" if args.arith == "f64ref" else "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)", "sharding": "gates across GPUs, keys replicated",
                        "launcher": "ranks (one process per GPU, torch.distributed)"},
-            "ranks_seen": ranks_seen, "per_rank_ms_per_step": t["per_rank_ms"],
+            "ranks_seen": ranks_seen, "per_rank_ms_per_step": t["per_rank_ms"], "rendezvous_backend": backend if world > 1 else None,
             # Wrong decryptions are the parameter set's own output noise (profiles/r03_noise_theory_vs_measured.md: predicted
             # from the schemes' variance formulas, measured on this engine; the oracle produces the identical words --
             # `oracle_bitexact` is the parity gate).  Sets whose margin is >= 6 sigma must decrypt EVERY gate; the noisy ones

@@ -27,16 +27,48 @@ def shard_slices(B, world):
     return out
 
 
-def init_process_group(backend=None, device=None):
+ACTIVE_BACKEND = None      # what init_process_group ended up with ("nccl" = RCCL on ROCm, or "gloo")
+
+
+def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=300):
+    """Rendezvous of the ranks (nothing on the data path: gates shard with no collective).  backend "nccl" is RCCL; it is
+    PROVED with one tiny all-reduce right away, and if creating or proving it fails on every rank -- no peer access between
+    the visible devices, an IPC mode the host driver refuses -- the ranks fall back to `fallback` (gloo over TCP, CPU
+    tensors) instead of losing the run: the barrier, the max-over-ranks and the census are all it carries."""
+    import datetime
+    import sys
+    import torch
     import torch.distributed as dist
+    global ACTIVE_BACKEND
     rank, world, local = env()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        kw = {}
-        if backend == "nccl" and device is not None:
-            kw["device_id"] = device
-        dist.init_process_group(backend or "nccl", rank=rank, world_size=world, **kw)
+        backend = backend or "nccl"
+        to = datetime.timedelta(seconds=timeout_s)
+        try:
+            kw = {}
+            if backend == "nccl" and device is not None:
+                kw["device_id"] = device
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=to, **kw)
+            if backend == "nccl":
+                probe = torch.ones(1, device=device if device is not None else "cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+        except Exception as e:      # noqa: BLE001
+            if not fallback or fallback == backend:
+                raise
+            sys.stderr.write(f"mktfhe_amd.distributed: rank {rank}: backend {backend} failed ({type(e).__name__}: {str(e)[:200]}); falling back to {fallback}\n")
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:       # noqa: BLE001
+                pass
+            os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)      # a fresh store: every rank takes the same step
+            backend = fallback
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=to)
+        ACTIVE_BACKEND = backend
     return rank, world, local
 
 

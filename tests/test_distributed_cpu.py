@@ -51,6 +51,34 @@ def test_sharded_gates_gloo_world2(B):
     assert ret["ok"] and ret["dec"] and ret["tmax"] == 2.0
 
 
+def _fallback_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from mktfhe_amd import distributed as D
+    D.init_process_group("nccl", device=None)          # no GPU here: RCCL cannot start on any rank -> gloo
+    t = torch.ones(1)
+    torch.distributed.all_reduce(t)
+    if rank == 0:
+        ret["backend"], ret["sum"] = D.ACTIVE_BACKEND, float(t.item())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_rendezvous_falls_back_to_gloo_when_rccl_cannot_start():
+    """bench.py's ranks rendezvous over RCCL; where RCCL cannot be created (here: no GPU at all; on a node: no peer access, a
+    refused IPC mode) every rank falls back to gloo instead of losing the run -- the data path has no collective"""
+    world, port = 2, 29900 + (os.getpid() % 90)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, ret)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(180)
+        assert pr.exitcode == 0
+    assert ret["backend"] == "gloo" and ret["sum"] == 2.0
+
+
 def test_shard_slices():
     from mktfhe_amd.distributed import shard_slices
     assert shard_slices(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
