@@ -84,13 +84,19 @@ def allowed_wrong(pname, checked):
 PEAK_F64_NOFMA_TFLOPS = 39.3216
 
 
-def profiled_counters(kernel_prefix, workload, want=("FETCH_SIZE", "WRITE_SIZE")):
+def profiled_counters(kernel_prefix, workload, want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=None):
     """per-launch PMC means of `kernel_prefix` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r*_bench_<workload>_pmc.txt; FETCH_SIZE / WRITE_SIZE in KiB).  PMC cannot be collected from inside the
-    timed run, so these are the profiled figures, newest round last; None when no profile is committed."""
+    (profiles/r*_bench_<workload>[_<batch> | _mux]_pmc.txt; FETCH_SIZE / WRITE_SIZE in KiB).  PMC cannot be collected from inside the
+    timed run, so these are the profiled figures, newest round last; None when no profile is committed.  A profile holds one row
+    per (kernel, grid): the row whose mean duration is nearest `near_ms` (the launch time measured now) is the one of THIS launch
+    shape -- refused if it is more than 30 % off (another batch size) --, without `near_ms` the longest-running grid."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{workload}_pmc.txt"))):
+    import re
+    best, best_err = None, None
+    pat = re.compile(r"^r\d+[a-z]?_bench_" + re.escape(workload) + r"(_\d+|_mux)?_pmc\.txt$")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{workload}*_pmc.txt"))):
+        if not pat.match(os.path.basename(f)):
+            continue
         rows = {}
         for ln in open(f):
             if not ln.startswith(kernel_prefix):
@@ -100,8 +106,14 @@ def profiled_counters(kernel_prefix, workload, want=("FETCH_SIZE", "WRITE_SIZE")
                 rows.setdefault(parts[1], {})[parts[2]] = float(parts[3])
                 rows[parts[1]]["ms:" + parts[2]] = float(parts[4])
         for grid, r in sorted(rows.items(), key=lambda kv: kv[1].get("ms:" + want[0], 0.0)):   # the longest-running grid last
-            if all(w in r for w in want):
+            if not all(w in r for w in want):
+                continue
+            if near_ms is None:
                 best = (r, os.path.relpath(f, ROOT), grid)
+            else:
+                err = abs(r["ms:" + want[0]] / near_ms - 1.0)
+                if err <= 0.30 and (best_err is None or err <= best_err + 0.02):    # newer rounds win ties
+                    best, best_err = (r, os.path.relpath(f, ROOT), grid), err
     return best
 
 
@@ -281,7 +293,7 @@ def rot_roofline(mk, p, B, t, workload, kern=None):
          "algorithmic_flop_per_launch": flop, "rotations_per_launch": rows * B / launches_per_step, "cmux_per_rotation": p.n // max(p.blk_len, 1),
          "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
          "peak_note": "256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz, mul and add issued separately (no FMA: bit parity)"}
-    prof = profiled_counters("mktd::" + kern, workload, want=("FETCH_SIZE", "WRITE_SIZE"))
+    prof = profiled_counters("mktd::" + kern, "kms2_n1024" if workload == "adder8" else workload, want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms)
     if prof:
         c, src, _ = prof
         r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0     # gfx950: FETCH_SIZE counts half (guide, HBM section)
@@ -416,7 +428,7 @@ def exact_rot_roofline(mk, p, B, t, kern, workload):
     r = {"bound": "int32-valu-issue", "kernel": kern, "achieved": ach, "peak": peak, "unit": "T lane-instr/s", "frac": ach / peak, "traffic": None,
          "algorithmic_instr_per_launch": instr / launches_per_step, "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
          "peak_note": "256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 3.6 cycles per wave instruction (60 % multiply-class at 4.4, 40 % at 2.5: tools/valu_probe.hip)"}
-    prof = profiled_counters("mktd::" + kern, workload + "_exact", want=("FETCH_SIZE", "WRITE_SIZE"))
+    prof = profiled_counters("mktd::" + kern, workload + "_exact", want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms)
     if prof:
         c, src, _ = prof
         r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0

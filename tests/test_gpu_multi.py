@@ -333,3 +333,32 @@ def test_last_kernel_name_follows_the_dispatch(require_gpu):
     with pytest.raises(mk.MktError, match="unknown option"):
         sg.set_option("no_such_switch", 1)
     sg.close()
+
+
+@pytest.mark.parametrize("p,B", [(mk.KMS4party, 65536), (mk.CCS8party_N2048, 8192)], ids=lambda v: getattr(v, "name", str(v)))
+def test_baseline_multi_gpu_configs_at_full_batch_on_eight_logical_shards(require_gpu, p, B):
+    """BASELINE.json configs[2] and [3] are FIXED batches over the 8 GPUs of a node (65 536 KMS k = 4 gates, 8 192 CCS k = 8 N = 2048
+    gates).  Here the WHOLE batch runs through one mkt_multi handle with eight shards (logical shards of the one GPU: the same code
+    path, keys shared): every output decrypts, gates sampled at the shard boundaries and inside equal the oracle bit for bit, a gate's
+    words do not depend on which shard evaluated it, and a second evaluation reproduces the first word for word."""
+    crs, keys = keygen(p, 21)
+    multi = multi_scheme(p, crs, keys, [0] * 8, mk.ARITH_F64REF)
+    rng = np.random.default_rng(81)
+    nu = 64 * p.nparty
+    ubits = rng.integers(0, 2, nu).astype(bool)
+    uniq = encrypt_bits(p, keys, ubits, seed=9100)
+    ix, iy = rng.integers(0, nu, B), rng.integers(0, nu, B)
+    x, y = uniq[ix], uniq[iy]
+    out = multi.gate(0, x, y)
+    got = mk.lwe_decrypt(out, keys, p)
+    assert np.array_equal(got, ~(ubits[ix] & ubits[iy]))
+    bounds = [multi.shard_range(B, s) for s in range(8)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == B and all(bounds[s][1] == bounds[s + 1][0] for s in range(7))
+    so = oracle_scheme(p, crs, keys)
+    pick = np.array(sorted({0, B - 1, bounds[3][0] - 1, bounds[3][0], bounds[6][1] - 1, int(rng.integers(0, B))}))
+    assert np.array_equal(out[pick], so.gate_batch(0, x[pick], y[pick], threads=8))
+    perm = rng.permutation(B)                                            # the same gates, dealt to other shards
+    sub = perm[:2048]
+    assert np.array_equal(multi.gate(0, x[sub], y[sub]), out[sub])
+    assert np.array_equal(multi.gate(0, x, y), out)
+    multi.close()
