@@ -84,7 +84,7 @@ def allowed_wrong(pname, checked):
 PEAK_F64_NOFMA_TFLOPS = 39.3216
 
 
-def profiled_counters(kernel_prefix, workload, want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=None):
+def profiled_counters(kernel_prefix, workload, want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=None, variant=None):
     """per-launch PMC means of `kernel_prefix` from the committed rocprofv3 --pmc passes of this same command
     (profiles/r*_bench_<workload>[_<batch> | _mux]_pmc.txt; FETCH_SIZE / WRITE_SIZE in KiB).  PMC cannot be collected from inside the
     timed run, so these are the profiled figures, newest round last; None when no profile is committed.  A profile holds one row
@@ -93,7 +93,7 @@ def profiled_counters(kernel_prefix, workload, want=("FETCH_SIZE", "WRITE_SIZE")
     import glob
     import re
     best, best_err = None, None
-    pat = re.compile(r"^r\d+[a-z]?_bench_" + re.escape(workload) + r"(_\d+|_mux)?_pmc\.txt$")
+    pat = re.compile(r"^r\d+[a-z]?_bench_" + re.escape(workload) + (r"_mux" if variant == "mux" else r"(_\d+)?") + r"_pmc\.txt$")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{workload}*_pmc.txt"))):
         if not pat.match(os.path.basename(f)):
             continue
@@ -279,7 +279,7 @@ def time_gates(mk, torch, dist, D, sch, p, keys, x, y, bits, B, steps, warmup, w
                 decrypt_errors_all=errs_all, decrypt_checked_all=checked_all, per_rank_ms=per_rank)
 
 
-def rot_roofline(mk, p, B, t, workload, kern=None):
+def rot_roofline(mk, p, B, t, workload, kern=None, variant=None):
     """the roofline object of the dominant kernel of this workload; `kern` = the name the engine reports for the kernel it
     actually launched (mkt_last_kernel_name), so the line and the rocprof trace name the same kernel"""
     flop_step, rows = blindrotate_flop(mk, p, B)              # one step = ceil(B / 8192) launches (the engine's workspace chunk)
@@ -293,7 +293,7 @@ def rot_roofline(mk, p, B, t, workload, kern=None):
          "algorithmic_flop_per_launch": flop, "rotations_per_launch": rows * B / launches_per_step, "cmux_per_rotation": p.n // max(p.blk_len, 1),
          "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
          "peak_note": "256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz, mul and add issued separately (no FMA: bit parity)"}
-    prof = profiled_counters("mktd::" + kern, "kms2_n1024" if workload == "adder8" else workload, want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms)
+    prof = profiled_counters("mktd::" + kern, "kms2_n1024" if workload == "adder8" else workload, want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms, variant=variant)
     if prof:
         c, src, _ = prof
         r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0     # gfx950: FETCH_SIZE counts half (guide, HBM section)
@@ -635,7 +635,7 @@ def main():
                                     "keyswitch": t["ks_ms"] / max(args.steps, 1)},
         }
         nrot = B if args.op == "nand" else 2 * B            # a MUX gate is two blind rotations
-        line["roofline"] = rot_roofline(mk, p, nrot, t, args.workload, kern) if args.arith == "f64ref" else exact_rot_roofline(mk, p, nrot, t, kern, args.workload)
+        line["roofline"] = rot_roofline(mk, p, nrot, t, args.workload, kern, "mux" if args.op == "mux" else None) if args.arith == "f64ref" else exact_rot_roofline(mk, p, nrot, t, kern, args.workload)
 
     # ---- circuit throughput (--workload adder8): rank 0, N = 1 ----
     if rank == 0 and world == 1 and args.workload == "adder8":
