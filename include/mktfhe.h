@@ -220,7 +220,9 @@ int mkt_get_monomial(mkt_ctx *ctx, int e, double *out_host);
  *      (hipMemcpyPeer over xGMI; host bounce if refused) and seals them.  A batch call cuts [0, B) into contiguous balanced
  *      slices (the first B mod nshards slices hold one more: mkt_multi_shard_range), one host thread per shard, every shard
  *      writing its slice of the caller's ONE output array; no collective.  MKT_MEM_DEVICE arrays may live on any of the
- *      devices (slices are peer-copied to and from the shards on other devices).  Calls return when all shards are done. ---- */
+ *      devices (slices are peer-copied to and from the shards on other devices).  Calls return when all shards are done; one call
+ *      at a time per handle (the shards' workspaces and staging buffers belong to it) -- concurrent callers take one handle each, or
+ *      fork the shard contexts (mkt_multi_ctx + mkt_ctx_fork). ---- */
 typedef struct mkt_multi mkt_multi;
 /* flags: MKT_MULTI_PRIVATE_KEYS = shards that share a device do NOT share its key set: each gets its own replicated copy, as
  * shards on distinct devices do (exercises the device-to-device replication on a one-GPU box; costs one key copy per shard) */
