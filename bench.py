@@ -94,12 +94,14 @@ def profiled_counters(kernel_prefix, workload, want=("FETCH_SIZE", "WRITE_SIZE")
     import re
     best, best_err = None, None
     pat = re.compile(r"^r\d+[a-z]?_bench_" + re.escape(workload) + (r"_mux" if variant == "mux" else r"(_\d+)?") + r"_pmc\.txt$")
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{workload}*_pmc.txt"))):
-        if not pat.match(os.path.basename(f)):
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{workload}*_pmc.txt"))) if pat.match(os.path.basename(f))]
+    newest = max((int(re.match(r"r(\d+)", os.path.basename(f)).group(1)) for f in files), default=None)
+    for f in files:
+        if int(re.match(r"r(\d+)", os.path.basename(f)).group(1)) != newest:     # earlier rounds profiled other kernels
             continue
         rows = {}
         for ln in open(f):
-            if not ln.startswith(kernel_prefix):
+            if not (ln.startswith(kernel_prefix + ",") or ln.startswith(kernel_prefix + ">")):   # `kernel<first template argument`
                 continue
             parts = ln.rsplit(",", 5)          # kernel, grid, counter, mean, ms, n
             if len(parts) == 6:
@@ -293,7 +295,8 @@ def rot_roofline(mk, p, B, t, workload, kern=None, variant=None):
          "algorithmic_flop_per_launch": flop, "rotations_per_launch": rows * B / launches_per_step, "cmux_per_rotation": p.n // max(p.blk_len, 1),
          "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
          "peak_note": "256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz, mul and add issued separately (no FMA: bit parity)"}
-    prof = profiled_counters("mktd::" + kern, "kms2_n1024" if workload == "adder8" else workload, want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms, variant=variant)
+    # the kernel's first template argument is log2 M: the row of THIS transform size (a profile may also hold the secondary leg's)
+    prof = profiled_counters(f"mktd::{kern}<{int(np.log2(p.N // 2))}", "kms2_n1024" if workload == "adder8" else workload, want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms, variant=variant)
     if prof:
         c, src, _ = prof
         r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0     # gfx950: FETCH_SIZE counts half (guide, HBM section)
@@ -428,7 +431,7 @@ def exact_rot_roofline(mk, p, B, t, kern, workload):
     r = {"bound": "int32-valu-issue", "kernel": kern, "achieved": ach, "peak": peak, "unit": "T lane-instr/s", "frac": ach / peak, "traffic": None,
          "algorithmic_instr_per_launch": instr / launches_per_step, "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
          "peak_note": "256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 3.6 cycles per wave instruction (60 % multiply-class at 4.4, 40 % at 2.5: tools/valu_probe.hip)"}
-    prof = profiled_counters("mktd::" + kern, workload + "_exact", want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms)
+    prof = profiled_counters(f"mktd::{kern}<{lg}", workload + "_exact", want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms)
     if prof:
         c, src, _ = prof
         r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
