@@ -421,8 +421,9 @@ def exact_rot_roofline(mk, p, B, t, kern, workload):
     elif p.W == 64:      # split tables: 2l forward, (low, high) x (b, a) = 4 inverses, 2 x 2 x 2l MACs per key bit
         per_blk = 2 * l * fwd * (LB if LB > 1 else 1) + 4 * inv + LB * (8 * l * mac * N) + 16 * N
         instr = per_blk * (p.n // LB) * rows * B
-    else:                # 32-bit ring: 2l forward, 2 inverses, 2 x 2l MACs per key bit, monomial product in the transform domain
-        per_blk = 2 * l * fwd + 2 * inv + LB * (4 * l * mac * N + 2 * mac * N) + 8 * N
+    else:                # 32-bit ring, RLWE length kr: (kr+1) l forward and kr+1 inverses per block, (kr+1)^2 l MACs per key bit, monomial product in the transform domain
+        kr = p.k
+        per_blk = (kr + 1) * l * fwd + (kr + 1) * inv + LB * ((kr + 1) ** 2 * l * mac * N + (kr + 1) * mac * N) + 4 * (kr + 1) * N
         instr = per_blk * (p.n // LB) * rows * B
     launches_per_step = max(1, -(-B // 8192))
     avg_ms = t["rot_ms"] / max(t["rot_n"], 1)

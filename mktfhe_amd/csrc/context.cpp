@@ -313,6 +313,12 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         HIPCHK(c, mktd::launch_exact_kms(c->logN, c->d_ntt, q, B, c->stream));
         return MKT_OK;
     }
+    if (c->exact && (p.k > 1 || (mkt::is_block(p.scheme) && p.blk_len != 3))) {   // CGGI / LMSS with RLWE length 2, 3 or another block length: the general kernel
+        Timer tm(c, 1);
+        HIPCHK(c, mktd::launch_exact_blindrotate_kr(c->logN, c->d_ntt, reinterpret_cast<const uint64_t *>(c->ks->d_brk), reinterpret_cast<const uint64_t *>(c->ks->d_monomial),
+                                                    lwe, stride, pre, p.n, p.k, p.l_gsw, p.logB_gsw, mkt::is_block(p.scheme) ? p.blk_len : 1, (uint32_t *)acc, B, c->stream));
+        return MKT_OK;
+    }
     if (c->exact) {          // CGGI / LMSS, RLWE length 1, 32-bit ring (exact_gate_ok): every product exact mod 2^32
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_exact_blindrotate(c->logN, c->d_ntt, reinterpret_cast<const uint64_t *>(c->ks->d_brk), reinterpret_cast<const uint64_t *>(c->ks->d_monomial),
@@ -455,14 +461,14 @@ bool exact_gate_ok(const mkt_ctx *c) {
     if (p.scheme == MKT_CCS && p.W == 32)    // tacc.b gathers u_0 and the w of all np + 1 polynomials, then the monomial doubles it
         return 2.0 * (p.k + 2.0) * p.l_uni * std::ldexp(1.0, p.logB_uni - 1) * n31 < half_P;
     const bool lmss = p.scheme == MKT_LMSS;
-    if (!((p.scheme == MKT_CGGI || lmss) && p.k == 1 && p.W == 32)) return false;
-    if (lmss && p.blk_len != 3) return false;             // the block length the kernel is instantiated for (params.jl:8-13)
-    // the kernel multiplies the product sum by the monomial X^a - 1 in the transform domain BEFORE the one lift (ntt_exact.hip
-    // exact_blindrotate_kernel: s2 = tacc * mono), so the lifted integer is up to twice the sum -- for CGGI as for a block
-    const double bound = 2.0 * (lmss ? p.blk_len : 1.0) * 2.0 * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n31;
+    if (!((p.scheme == MKT_CGGI || lmss) && p.k >= 1 && p.k <= 3 && p.W == 32)) return false;     // RLWE length 1 .. 3 (exact_blindrotate_kr_kernel beyond the k = 1, block-length-3 shapes)
+    // the kernels multiply the product sum by the monomial X^a - 1 in the transform domain BEFORE the one lift (ntt_exact.hip
+    // exact_blindrotate_kernel: s2 = tacc * mono), so the lifted integer is up to twice the sum -- for CGGI as for a block;
+    // (k + 1) l digit polynomials per key bit
+    const double bound = 2.0 * (lmss ? p.blk_len : 1.0) * (p.k + 1.0) * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n31;
     return bound < half_P;
 }
-#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1, 32-bit ring, block length 3) for CCS (32-bit ring) and for KMS / KMS_block (64-bit ring, tables split in 32-bit halves), gadgets within the two-prime modulus; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
+#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1 .. 3, 32-bit ring), for CCS (32-bit ring) and for KMS / KMS_block (64-bit ring, tables split in 32-bit halves), gadgets within the two-prime modulus; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
 #define MKT_F64_OR_EXACT_KMS(c) do { if ((c) && (c)->exact && !(mkt::is_mk((c)->p.scheme) && exact_gate_ok(c))) return fail((c), MKT_ERR_UNSUPPORTED, "on an MKT_ARITH_EXACT context this entry point serves the multi-key gate paths only"); } while (0)
 #define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; not offered by an MKT_ARITH_EXACT context"); } while (0)
 

@@ -507,6 +507,94 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same rotation for any RLWE length KR (accumulator (b, a_0 .. a_{KR-1}); bootstrapping.jl:32-76 / :114-165 with k > 1:
+// TFHEparams_bin.k / TFHEparams_block.k, scheme.jl:6-36 -- BASELINE configs[4] is LMSS with k = 2) and any block length.
+// Per key bit: the (KR + 1) l digit polynomials of the accumulator are transformed and multiplied into the key bit's
+// (KR + 1) l x (KR + 1) rows (:62-68 / :146-154); a block sums its key bits' products times their monomials in the transform
+// domain (:157) and lifts ONCE per output polynomial (:162).  The digit transforms are recomputed per key bit of a block (the
+// accumulator does not change inside a block: same values) -- (KR + 1) x 8 point accumulators for one key bit and for the
+// block are what the registers hold.  True coefficients stay below blk_len * 2 (KR + 1) l N 2^(logB-1) 2^31 < P / 2 (host check).
+// ------------------------------------------------------------------------------------------------
+template <int LOGN, int KR>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kr_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk,
+                                                                                 const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe,
+                                                                                 int lwe_stride, int pre_switched, int n, int l, int logB, int blk_len,
+                                                                                 uint32_t *__restrict__ acc_io) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR, NP = KR + 1;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
+    const int t = threadIdx.x;
+    const uint4 *tw[2]; const int which[2] = {0, 1};
+    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
+    const NttConsts k = tab_consts<LOGN>(tab);
+    const size_t rot = blockIdx.x;
+    const uint32_t *at_src = lwe + rot * (size_t)lwe_stride;
+    uint32_t *accg = acc_io + rot * NP * (size_t)N;
+    const Gadget<uint32_t> gd(l, logB);
+    uint32_t acc[NP][8];
+#pragma unroll
+    for (int c = 0; c < NP; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[c][e] = accg[c * N + e * NT + t];
+    const int msbit = 32 - LOGN - 1;
+    for (int blk = 0; blk < n / blk_len; blk++) {
+        bool any = false;
+        for (int q = 0; q < blk_len; q++) {
+            const uint32_t v0 = at_src[blk * blk_len + q];
+            any |= (pre_switched ? v0 : divbits<uint32_t>(v0, msbit)) != 0;
+        }
+        if (!__builtin_amdgcn_readfirstlane((int)any)) continue;                   // :48 / :145 (an all-zero block adds 0)
+        Pt sum[NP][8];
+#pragma unroll
+        for (int pp = 0; pp < NP; pp++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) { sum[pp][e].a = 0; sum[pp][e].b = 0; }
+        for (int q = 0; q < blk_len; q++) {
+            const int i = blk * blk_len + q;
+            const uint32_t v0 = at_src[i];
+            const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+            if (at == 0) continue;
+            Pt tacc[NP][8];
+#pragma unroll
+            for (int pp = 0; pp < NP; pp++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) { tacc[pp][e].a = 0; tacc[pp][e].b = 0; }
+#pragma unroll
+            for (int c = 0; c < NP; c++)
+                for (int j = 0; j < l; j++) {
+                    const uint64_t *row = brk + (((size_t)i * NP * l + (size_t)(c * l + j)) * NP) * N + 8 * t;   // [row c l + j][poly][N]
+                    uint64_t kr0[8];                                               // the first polynomial's row ahead of the transform
+#pragma unroll
+                    for (int e = 0; e < 8; e++) kr0[e] = row[e];
+                    __builtin_amdgcn_sched_barrier(0);
+                    Pt z[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(gd.prep(acc[c][e]), j));   // :50-51 / :131-132 decompto!
+                    ntt_forward<LOGN>(z, tw[0], lds, t);
+#pragma unroll
+                    for (int pp = 0; pp < NP; pp++)
+#pragma unroll
+                        for (int e = 0; e < 8; e++) tacc[pp][e] = pt_mac(tacc[pp][e], z[e], unpack(pp == 0 ? kr0[e] : row[(size_t)pp * N + e]));   // :63-68 / :146-154, exactly
+                }
+            const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
+#pragma unroll
+            for (int pp = 0; pp < NP; pp++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) sum[pp][e] = pt_mac(sum[pp][e], tacc[pp][e], unpack(mrow[e]));       // :71 / :157
+        }
+#pragma unroll
+        for (int pp = 0; pp < NP; pp++) {
+            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(sum[pp], tw[1], lds, t, k.ninv);                       // :72 / :162
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[pp][e] += (uint32_t)crt_signed(sum[pp][e]);                           // :73 / :163
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NP; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) accg[c * N + e * NT + t] = acc[c][e];
+}
+
+// ------------------------------------------------------------------------------------------------
 // The 64-bit ring (KMS) with exact products.  A product  digit polynomial x 64-bit polynomial  exceeds P, so every resident
 // 64-bit table is kept as TWO residue polynomials -- the transforms of its low and of its high 32-bit halves (centered
 // pieces in [-2^31, 2^31), piece_of) -- every sum of such products as a (low, high) pair of transform-domain accumulators,
@@ -1071,6 +1159,22 @@ hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_
             hipLaunchKernelGGL((exact_blindrotate_kernel<LN, 3>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, acc);
         }
     });
+    return hipGetLastError();
+}
+
+hipError_t launch_exact_blindrotate_kr(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
+                                       int pre_switched, int n, int kr, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    if (kr < 1 || kr > 3 || blk_len < 1 || n % blk_len) return hipErrorInvalidValue;
+    last_rot_kernel = "exact_blindrotate_kr_kernel";
+    const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
+#define MKT_EXACT_KR_LAUNCH(KRV) do { hipError_t e = ntt_set_lds(exact_blindrotate_kr_kernel<LN, KRV>, lds); if (e != hipSuccess) return e; \
+        hipLaunchKernelGGL((exact_blindrotate_kr_kernel<LN, KRV>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, blk_len, acc); } while (0)
+    MKT_NTT_DISPATCH(logN, {
+        const size_t lds = lds_bytes<LN>(2);
+        if (kr == 1) MKT_EXACT_KR_LAUNCH(1); else if (kr == 2) MKT_EXACT_KR_LAUNCH(2); else MKT_EXACT_KR_LAUNCH(3);
+    });
+#undef MKT_EXACT_KR_LAUNCH
     return hipGetLastError();
 }
 

@@ -22,43 +22,45 @@ def monomial_minus_one(x, a, N, W):
 
 
 def blindrotate(p, brk, atilde, acc):
-    """brk: integer bootstrapping key [n][2l][2][N]; acc: [2][N] ring words (b, a)"""
-    N, W, l = p.N, p.W, p.l_gsw
+    """brk: integer bootstrapping key [n][(kr+1) l][kr+1][N], kr = p.k the RLWE length; acc: [kr+1][N] ring words (b, a_0 ..)"""
+    N, W, l, kr = p.N, p.W, p.l_gsw, p.k
     mask = np.uint64((1 << W) - 1)
-    acc = acc.reshape(2, N).astype(np.uint64).copy()
-    brk = brk.reshape(p.n, 2 * l, 2, N).astype(np.uint64)
+    acc = acc.reshape(kr + 1, N).astype(np.uint64).copy()
+    brk = brk.reshape(p.n, (kr + 1) * l, kr + 1, N).astype(np.uint64)
     for i in range(p.n):
         a = int(atilde[i])
         if a == 0:
             continue                                                   # bootstrapping.jl:48
-        dig = [O.decomp_poly(acc[c], l, p.logB_gsw, W) for c in range(2)]   # :50-51, [l][N] wrapped signed digits
-        for pp in range(2):
+        dig = [O.decomp_poly(acc[c], l, p.logB_gsw, W) for c in range(kr + 1)]   # :50-51, [l][N] wrapped signed digits
+        new = acc.copy()
+        for pp in range(kr + 1):
             t = np.zeros(N, dtype=np.uint64)
-            for c in range(2):
+            for c in range(kr + 1):
                 for j in range(l):                                     # :63-68, exactly
                     t = (t + O.negacyclic(dig[c][j], brk[i, c * l + j, pp], W)) & mask
-            acc[pp] = (acc[pp] + monomial_minus_one(t, a, N, W)) & mask       # :71-73
+            new[pp] = (acc[pp] + monomial_minus_one(t, a, N, W)) & mask          # :71-73
+        acc = new
     return acc.reshape(-1)
 
 
 def blindrotate_lmss(p, brk, atilde, acc):
     """LMSS (bootstrapping.jl:114-165): one decomposition per block of blk_len key bits, every key bit of the block multiplies
-    the SAME digits into its own rows, the block adds sum_q (X^a_q - 1) * product_q"""
-    N, W, l, L = p.N, p.W, p.l_gsw, p.blk_len
+    the SAME digits into its own rows, the block adds sum_q (X^a_q - 1) * product_q; RLWE length kr = p.k"""
+    N, W, l, L, kr = p.N, p.W, p.l_gsw, p.blk_len, p.k
     mask = np.uint64((1 << W) - 1)
-    acc = acc.reshape(2, N).astype(np.uint64).copy()
-    brk = brk.reshape(p.n, 2 * l, 2, N).astype(np.uint64)
+    acc = acc.reshape(kr + 1, N).astype(np.uint64).copy()
+    brk = brk.reshape(p.n, (kr + 1) * l, kr + 1, N).astype(np.uint64)
     for blk in range(p.n // L):
-        dig = [O.decomp_poly(acc[c], l, p.logB_gsw, W) for c in range(2)]   # :131-132
-        add = np.zeros((2, N), dtype=np.uint64)
+        dig = [O.decomp_poly(acc[c], l, p.logB_gsw, W) for c in range(kr + 1)]   # :131-132
+        add = np.zeros((kr + 1, N), dtype=np.uint64)
         for q in range(L):
             i = blk * L + q
             a = int(atilde[i])
             if a == 0:
                 continue                                                   # :145
-            for pp in range(2):
+            for pp in range(kr + 1):
                 t = np.zeros(N, dtype=np.uint64)
-                for c in range(2):
+                for c in range(kr + 1):
                     for j in range(l):                                     # :146-154
                         t = (t + O.negacyclic(dig[c][j], brk[i, c * l + j, pp], W)) & mask
                 add[pp] = (add[pp] + monomial_minus_one(t, a, N, W)) & mask       # :157

@@ -63,7 +63,8 @@ def test_soak_slice_repeated_batches_are_deterministic(require_gpu, p, arith):
     sg.close()
 
 
-FULL_N = [mk.CGGIparam, mk.Blockparam, mk.KMS2party_N1024_l2, mk.KMS2partyblock.scaled(N=1024), mk.CCS2party.scaled(n=140)]
+FULL_N = [mk.CGGIparam, mk.Blockparam, mk.KMS2party_N1024_l2, mk.KMS2partyblock.scaled(N=1024), mk.CCS2party.scaled(n=140),
+          mk.Blockparam_k2.scaled(n=345, blk_d=115)]          # BASELINE configs[4] (LMSS, RLWE length 2) at half its key length: its restatement is 18 products per key bit
 
 
 @pytest.mark.parametrize("p", FULL_N, ids=lambda p: f"{p.name}-n{p.n}-N{p.N}")

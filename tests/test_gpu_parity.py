@@ -332,7 +332,7 @@ def test_errors(require_gpu):
         s.gate(0, x[:, :-1], x[:, :-1])
     # EXACT: a gadget whose product sums would not fit the two-prime modulus (P / 2 = 2^58.9998), or an RLWE length it has no kernel
     # for, is refused instead of computing something else
-    for pk in (mk.KMS2party.scaled(n=8, N=2048, l_gsw=2, logB_gsw=20), mk.CGGIparam.scaled(n=8, N=256, k=2)):
+    for pk in (mk.KMS2party.scaled(n=8, N=2048, l_gsw=2, logB_gsw=20), mk.CGGIparam.scaled(n=8, N=256, k=4)):
         ex = mk.Scheme(pk, arith=mk.ARITH_EXACT)
         xk = np.zeros((2, pk.lwe_len), dtype=np.uint32)
         with pytest.raises(mk.MktError, match="MKT_ARITH_EXACT evaluates gates for CGGI"):
@@ -1076,8 +1076,12 @@ def test_exact_mode_ccs_gates(require_gpu, p):
 
 @pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=12, N=256), mk.CGGIparam.scaled(n=10, N=1024), mk.CGGI_N1024_l2.scaled(n=10),
                                mk.CGGIparam.scaled(n=6, N=2048, l_gsw=4, logB_gsw=7),
-                               mk.Blockparam.scaled(n=12, N=256, blk_d=4), mk.Blockparam.scaled(n=9, N=1024, blk_d=3)],
-                         ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-l{p.l_gsw}")
+                               mk.Blockparam.scaled(n=12, N=256, blk_d=4), mk.Blockparam.scaled(n=9, N=1024, blk_d=3),
+                               # RLWE length 2 / 3 and other block lengths: exact_blindrotate_kr_kernel (BASELINE configs[4] = LMSS, k = 2, in the integer arithmetic)
+                               mk.Blockparam_k2.scaled(n=9, blk_d=3), mk.Blockparam_k2.scaled(n=12, N=256, blk_d=4), mk.CGGIparam.scaled(n=8, N=256, k=2),
+                               mk.CGGIparam.scaled(n=6, N=512, k=3, l_gsw=2, logB_gsw=10), mk.Blockparam.scaled(n=8, N=256, blk_d=4, blk_len=2),
+                               mk.Blockparam.scaled(n=8, N=128, blk_d=2, blk_len=4, k=2)],
+                         ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-l{p.l_gsw}-k{p.k}-b{p.blk_len}")
 def test_exact_mode_cggi_gates(require_gpu, p):
     """MKT_ARITH_EXACT gate path (CGGI and LMSS, 32-bit ring): blind rotation with integer-NTT products.  Accumulators and
     gate outputs equal the exact-arithmetic restatement (tests/ref_exact.py: the oracle's integer steps + exact schoolbook

@@ -259,13 +259,14 @@ def test_every_shipped_set_fits_the_exact_modulus():
             b = 2.0 * (p.k + 2.0) * p.l_uni * 2.0**(p.logB_uni - 1) * n31
         else:
             # CGGI too carries the doubling: the kernel multiplies the product sum by X^a - 1 in the transform domain before its one lift
-            b = 2.0 * (p.blk_len if p.scheme == mk.LMSS else 1.0) * 2.0 * p.l_gsw * 2.0**(p.logB_gsw - 1) * n31
+            b = 2.0 * (p.blk_len if p.scheme == mk.LMSS else 1.0) * (p.k + 1.0) * p.l_gsw * 2.0**(p.logB_gsw - 1) * n31   # (k + 1) l digit polynomials per key bit
         worst[name] = b
         assert b < half_P, (name, np.log2(b))
     assert len(worst) >= 19 and abs(np.log2(worst["KMS2party_N1024_l2"]) - 58.0) < 1e-9
 
 
-@pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=9, N=128), mk.Blockparam.scaled(n=9, N=128, blk_d=3)], ids=lambda p: p.name)
+@pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=9, N=128), mk.Blockparam.scaled(n=9, N=128, blk_d=3),
+                               mk.CGGIparam.scaled(n=8, N=128, k=2), mk.Blockparam_k2.scaled(n=9, N=128, blk_d=3)], ids=lambda p: f"{p.name}-k{p.k}")
 def test_exact_gate_restatement_decrypts(p):
     """tests/ref_exact.py (the checker of the MKT_ARITH_EXACT gate path on the GPU): gates bootstrapped with exact products
     decrypt to the plaintext gate, and one CMux step / block differs from the oracle's Float64 step by 0..2 per coefficient
@@ -287,7 +288,7 @@ def test_exact_gate_restatement_decrypts(p):
     ex = rot(p, keys[0].brk, one, acc0).astype(np.int64)
     fl = so.blindrotate(one, acc0.copy()).astype(np.int64).reshape(-1)
     d = (ex - fl + (1 << 31)) % (1 << 32) - (1 << 31)
-    assert d.min() >= 0 and d.max() <= 2 * L
+    assert d.min() >= 0 and d.max() <= 2 * L * p.k                  # one truncation per product sum; (k + 1) l products per sum
 
 
 def test_monomial_table_semantics():
