@@ -29,7 +29,8 @@ def run(rounds=8, seed=91, log=print):
             elif kind == 3:
                 p = mk.CGGIparam.scaled(n=int(rng.integers(4, 12)), N=N, l_gsw=min(l, 3), logB_gsw=min(logB, 10)); fn = T.test_exact_mode_cggi_gates
             else:
-                d = int(rng.integers(2, 5)); p = mk.Blockparam.scaled(n=3 * d, N=N, blk_d=d); fn = T.test_exact_mode_cggi_gates
+                d = int(rng.integers(2, 5)); L = int(rng.choice([2, 3, 4])); kk = int(rng.choice([1, 2]))      # any block length, RLWE length 1 / 2 (exact_blindrotate_kr_kernel)
+                p = mk.Blockparam.scaled(n=L * d, N=N, blk_d=d, blk_len=L, k=kk, logB_gsw=7 if kk == 2 else 9); fn = T.test_exact_mode_cggi_gates
             fn(None, p)
             st = "ok"
         except MktError as e:

@@ -5,13 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))));
 import numpy as np, torch
 from helpers import *
 REPS = int(os.environ.get("REPS", "40"))
-ARITH = mk.ARITH_EXACT if os.environ.get("ARITH") == "exact" else mk.ARITH_F64REF   # ARITH=exact: the integer-NTT gate paths (k = 1 only for CGGI / LMSS)
+ARITH = mk.ARITH_EXACT if os.environ.get("ARITH") == "exact" else mk.ARITH_F64REF   # ARITH=exact: the integer-NTT gate paths (all five schemes; CGGI / LMSS up to RLWE length 3)
 sets = [mk.CGGIparam, mk.KMS2party_N1024_l2, mk.KMS2party, mk.Blockparam, mk.Blockparam_k2, mk.KMS2partyblock, mk.CCS2party,
         mk.CGGIparam.scaled(n=64, N=256), mk.KMS2party.scaled(n=64, N=512), mk.KMS4party.scaled(n=32, N=4096), mk.CGGIparam.scaled(n=64, N=2048, k=2)]
 bad = 0
 SMALL = {mk.CGGIparam.name, mk.KMS2party_N1024_l2.name, mk.Blockparam_k2.name}      # also at 64 gates: the latency variant of the rotation / ragged groups
-if ARITH != mk.ARITH_F64REF:
-    sets = [p for p in sets if p.multikey or p.k == 1]
 if os.environ.get("ONLY"):
     sets = [p for p in sets if p.name in os.environ["ONLY"].split(",")]
 for p, Bs in [(p, None) for p in sets] + [(p, 64) for p in sets if p.name in SMALL and p.n > 100]:
