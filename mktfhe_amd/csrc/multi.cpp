@@ -112,8 +112,12 @@ int run_sharded(mkt_multi *m, size_t B, const std::function<int(int, size_t, siz
         rc[s] = fn((int)s, sl[s].lo, sl[s].hi, msg[s]);
     };
     std::vector<std::thread> th;
-    for (size_t s = 1; s < n; s++) th.emplace_back(body, s);
+    std::vector<size_t> inline_shards;                        // shards whose thread could not be started run on the calling thread
+    for (size_t s = 1; s < n; s++) {
+        try { th.emplace_back(body, s); } catch (...) { inline_shards.push_back(s); }   // nothing may escape the C ABI
+    }
     body(0);                                                  // the calling thread drives shard 0
+    for (size_t s : inline_shards) body(s);
     for (auto &t : th) t.join();
     for (size_t s = 0; s < n; s++)
         if (rc[s] != MKT_OK) return mfail(m, rc[s], "shard " + std::to_string(s) + " (device " + std::to_string(m->devices[s]) + "): " + msg[s]);
