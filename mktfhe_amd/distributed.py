@@ -30,7 +30,7 @@ def shard_slices(B, world):
 ACTIVE_BACKEND = None      # what init_process_group ended up with ("nccl" = RCCL on ROCm, or "gloo")
 
 
-def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=300):
+def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900):
     """Rendezvous of the ranks (nothing on the data path: gates shard with no collective).  backend "nccl" is RCCL; it is
     PROVED with one tiny all-reduce right away, and if creating or proving it fails on every rank -- no peer access between
     the visible devices, an IPC mode the host driver refuses -- the ranks fall back to `fallback` (gloo over TCP, CPU
