@@ -181,6 +181,10 @@ int mkt_gate_batch_gather(mkt_ctx *ctx, const uint8_t *ops, const uint32_t *pool
  *   acc = blindrotate!(AND-linear(s, a)) + blindrotate!(AND-linear(NOT! s, b)), + 1/8 at X^0 of acc.b;  out = keyswitch!(acc)
  * (a composite OR(AND(s, a), AND(NOT s, b)) of the reference's gates takes three full bootstraps).  s, a, b, out: [B][k*n+1] */
 int mkt_mux_batch(mkt_ctx *ctx, const uint32_t *s, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t B, int mem);
+/* a circuit level of MUX gates: gate j = MUX(pool[is[j]], a', b') -> out[j], a' = pool[ia[j]] or its negation (NOT!) if bit 0 of
+ * not_ab[j] is set, b' likewise with bit 1; not_ab may be NULL (rows of pool [pool_rows][k*n+1]; a negated selector = a and b swapped) */
+int mkt_mux_batch_gather(mkt_ctx *ctx, const uint32_t *pool, size_t pool_rows, const uint32_t *is, const uint32_t *ia, const uint32_t *ib,
+                         const uint8_t *not_ab, uint32_t *out, size_t B, int mem);
 /* gate.jl:55-58 NOT!: in-place negation, no bootstrap */
 int mkt_not_batch(mkt_ctx *ctx, uint32_t *x, size_t B, int mem);
 /* bootstrapping.jl:4-27 bootstrapping!: in place on [B][k*n+1] */

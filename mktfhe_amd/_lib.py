@@ -53,6 +53,7 @@ SYMBOLS = {
     "mkt_gate_batch_ops": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
     "mkt_gate_batch_gather": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _i]),
     "mkt_mux_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "mkt_mux_batch_gather": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i]),
     "mkt_not_batch": (_i, [_vp, _vp, _sz, _i]),
     "mkt_bootstrap_batch": (_i, [_vp, _vp, _sz, _i]),
     "mkt_modswitch_batch": (_i, [_vp, _vp, _vp, _vp, _sz, _i]),

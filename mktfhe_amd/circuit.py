@@ -13,6 +13,7 @@ import numpy as np
 from .params import NAND_OP, AND_OP, OR_OP, XOR_OP, XNOR_OP, NOR_OP
 
 _NOT = -1
+_MUX = 6        # native three-input node (mkt_mux_batch_gather): nodes entry (_MUX, s, (a, b))
 
 
 class Circuit:
@@ -47,6 +48,13 @@ class Circuit:
         OR(AND(s, a), AND(NOT s, b)) of its gates: two levels, three bootstraps, the two ANDs in one batch."""
         return self.OR(self.AND(s, a), self.AND(self.NOT(s), b))
 
+    def MUXN(self, s, a, b):
+        """s ? a : b as ONE node: the engine's native MUX (two blind rotations + one key switch; mkt_mux_batch) instead of the three
+        bootstraps of the composite.  One level deep."""
+        assert all(0 <= v < len(self.nodes) for v in (s, a, b))
+        self.nodes.append((_MUX, s, (a, b)))
+        return len(self.nodes) - 1
+
     def output(self, w):
         self.outputs.append(w)
         return w
@@ -59,6 +67,8 @@ class Circuit:
                 depth.append(0)
             elif op == _NOT:
                 depth.append(depth[a])
+            elif op == _MUX:
+                depth.append(1 + max(depth[a], depth[b[0]], depth[b[1]]))
             else:
                 depth.append(1 + max(depth[a], depth[b]))
         sched = defaultdict(lambda: defaultdict(list))
@@ -73,7 +83,10 @@ class Circuit:
              4: lambda x, y: ~(x ^ y), 5: lambda x, y: ~(x | y)}
         v = []
         for op, a, b in self.nodes:
-            v.append(bits[a] if op == "in" else (~v[a] if op == _NOT else f[op](v[a], v[b])))
+            if op == _MUX:
+                v.append(np.where(v[a], v[b[0]], v[b[1]]))
+            else:
+                v.append(bits[a] if op == "in" else (~v[a] if op == _NOT else f[op](v[a], v[b])))
         return [v[w] for w in self.outputs]
 
 
@@ -84,9 +97,10 @@ def _cat(xs):
     return np.concatenate(xs, 0)
 
 
-def evaluate(circ: Circuit, inputs, gate_fn, not_fn):
+def evaluate(circ: Circuit, inputs, gate_fn, not_fn, mux_fn=None):
     """inputs: list of n_inputs arrays [B, lwe_len] (numpy or GPU tensors).  gate_fn(op, x, y) -> out is the
-    batched gate (Scheme.gate), not_fn(x) -> negated COPY.  Returns the output ciphertext arrays [B, lwe_len].
+    batched gate (Scheme.gate), not_fn(x) -> negated COPY, mux_fn(s, a, b) -> out the native MUX (needed only for MUXN nodes).
+    Returns the output ciphertext arrays [B, lwe_len].
     Number of gate_fn calls = number of distinct (level, op) pairs, independent of the circuit width."""
     assert len(inputs) == circ.n_inputs
     depth, sched = circ.levels()
@@ -102,8 +116,11 @@ def evaluate(circ: Circuit, inputs, gate_fn, not_fn):
     for lvl in sorted(sched):
         for op, ids in sched[lvl].items():
             x = _cat([resolve(circ.nodes[i][1]) for i in ids])
-            y = _cat([resolve(circ.nodes[i][2]) for i in ids])
-            out = gate_fn(op, x, y)
+            if op == _MUX:
+                out = mux_fn(x, _cat([resolve(circ.nodes[i][2][0]) for i in ids]), _cat([resolve(circ.nodes[i][2][1]) for i in ids]))
+            else:
+                y = _cat([resolve(circ.nodes[i][2]) for i in ids])
+                out = gate_fn(op, x, y)
             for j, i in enumerate(ids):
                 val[i] = out[j * B:(j + 1) * B]
     return [resolve(w) for w in circ.outputs]
@@ -124,7 +141,7 @@ class Plan:
         nslots = circ.n_inputs
         order = []
         for lvl in sorted(sched):
-            ids = sorted(i for lst in sched[lvl].values() for i in lst)
+            ids = sorted((i for lst in sched[lvl].values() for i in lst), key=lambda i: (circ.nodes[i][0] == _MUX, i))   # two-input gates first, native MUX nodes after: each kind one contiguous region of the pool
             for i in ids:
                 slot[i] = nslots
                 nslots += 1
@@ -138,20 +155,36 @@ class Plan:
             return slot[i], n
 
         inst = np.arange(B, dtype=np.uint32)
-        self.levels = []
+        self.levels = []        # two-input gates of a level: (first slot, count, ops, ix, iy)
+        self.mux_levels = []    # its native MUX nodes, if any: (first slot, count, is, ia, ib, not_ab) or None
         for ids in order:
-            ops = np.empty((len(ids), B), dtype=np.uint8)
-            ix = np.empty((len(ids), B), dtype=np.uint32)
-            iy = np.empty((len(ids), B), dtype=np.uint32)
-            for j, i in enumerate(ids):
+            g2 = [i for i in ids if circ.nodes[i][0] != _MUX]
+            g3 = [i for i in ids if circ.nodes[i][0] == _MUX]
+            ops = np.empty((len(g2), B), dtype=np.uint8)
+            ix = np.empty((len(g2), B), dtype=np.uint32)
+            iy = np.empty((len(g2), B), dtype=np.uint32)
+            for j, i in enumerate(g2):
                 op, a, b = circ.nodes[i]
                 (sa, na), (sb, nb) = src(a), src(b)
                 ops[j] = op | (8 if na else 0) | (16 if nb else 0)
                 ix[j] = sa * B + inst
                 iy[j] = sb * B + inst
-            self.levels.append((slot[ids[0]], len(ids), ops.ravel(), ix.ravel(), iy.ravel()))
+            self.levels.append((slot[g2[0]] if g2 else 0, len(g2), ops.ravel(), ix.ravel(), iy.ravel()))
+            if g3:
+                js, ja, jb = (np.empty((len(g3), B), dtype=np.uint32) for _ in range(3))
+                fl = np.empty((len(g3), B), dtype=np.uint8)
+                for j, i in enumerate(g3):
+                    _, s_, (a, b) = circ.nodes[i]
+                    (ss, ns), (sa, na), (sb, nb) = src(s_), src(a), src(b)
+                    if ns:                                   # MUX(NOT s, a, b) = MUX(s, b, a)
+                        (sa, na), (sb, nb) = (sb, nb), (sa, na)
+                    js[j], ja[j], jb[j] = ss * B + inst, sa * B + inst, sb * B + inst
+                    fl[j] = (1 if na else 0) | (2 if nb else 0)
+                self.mux_levels.append((slot[g3[0]], len(g3), js.ravel(), ja.ravel(), jb.ravel(), fl.ravel()))
+            else:
+                self.mux_levels.append(None)
         self.rows = nslots * B
-        self.gates = sum(n for _, n, _, _, _ in self.levels) * B
+        self.gates = (sum(n for _, n, _, _, _ in self.levels) + sum(m[1] for m in self.mux_levels if m)) * B
         self.outputs = [src(w) for w in circ.outputs]
 
 
@@ -172,9 +205,12 @@ def evaluate_on(circ: Circuit, inputs, scheme, plan: Plan = None):
         up = lambda a: a                                                                              # noqa: E731
     for s, x in enumerate(inputs):
         pool[s * B:(s + 1) * B] = x
-    for slot0, ngates, ops, ix, iy in plan.levels:
-        out = pool[slot0 * B:(slot0 + ngates) * B]
-        scheme.gate_gather(up(ops), pool, up(ix), up(iy), out)
+    for (slot0, ngates, ops, ix, iy), mx in zip(plan.levels, plan.mux_levels):
+        if ngates:
+            scheme.gate_gather(up(ops), pool, up(ix), up(iy), pool[slot0 * B:(slot0 + ngates) * B])
+        if mx:
+            m0, nm, js, ja, jb, fl = mx
+            scheme.mux_gather(pool, up(js), up(ja), up(jb), pool[m0 * B:(m0 + nm) * B], not_ab=up(fl))
     res = []
     for sl, negated in plan.outputs:
         o = pool[sl * B:(sl + 1) * B]

@@ -924,6 +924,38 @@ int mkt_mux_batch(mkt_ctx *c, const uint32_t *sel, const uint32_t *a, const uint
     return so.out(out);
 }
 
+// the same MUX with its operands picked by row index from a ciphertext pool (a circuit level of MUX gates): gate j = MUX(pool[is[j]],
+// pool[ia[j]], pool[ib[j]]) -> out[j]; out may be a later region of the pool that no gate of this call reads
+// not_ab (optional, lives where the indices live): bit 0 / bit 1 of not_ab[j] = the a / b operand of gate j is negated first (a circuit's
+// free NOTs; a negated SELECTOR is the caller swapping a and b)
+int mkt_mux_batch_gather(mkt_ctx *c, const uint32_t *pool, size_t pool_rows, const uint32_t *is, const uint32_t *ia, const uint32_t *ib, const uint8_t *not_ab,
+                         uint32_t *out, size_t B, int mem) {
+    if (!c || !pool || !is || !ia || !ib || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (mem == MKT_MEM_HOST)
+        for (size_t j = 0; j < B; j++) if (is[j] >= pool_rows || ia[j] >= pool_rows || ib[j] >= pool_rows || (not_ab && (not_ab[j] & ~3u))) return fail(c, MKT_ERR_ARG, "mkt_mux_batch_gather: operand index outside the pool, or unknown flag");
+    MKT_EXACT_GATE(c);
+    int r;
+    if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
+    DevGuard dg(c->device);
+    Timer whole(c, 0);
+    const size_t len = (size_t)c->sh.lwe_len, words = (size_t)(1 + c->sh.kacc) * c->p.N;
+    Staged sp{c}, ss{c}, sa{c}, sb{c}, so{c}, sf{c};
+    if ((r = sp.in(pool, pool_rows * len * 4, mem, true)) || (r = ss.in(is, B * 4, mem, true)) || (r = sa.in(ia, B * 4, mem, true)) || (r = sb.in(ib, B * 4, mem, true)) || (r = so.in(out, B * len * 4, mem, false))) return r;
+    if (not_ab && (r = sf.in(not_ab, B, mem, true))) return r;
+    constexpr size_t HALF = CHUNK_GATES / 2;
+    for (size_t off = 0; off < B; off += HALF) {
+        const size_t nb = std::min(HALF, B - off);
+        if ((r = ensure_workspace(c, 2 * nb))) return r;
+        const uint32_t *pp = (const uint32_t *)sp.dev, *js = (const uint32_t *)ss.dev + off;
+        const uint8_t *fl = not_ab ? (const uint8_t *)sf.dev + off : nullptr;
+        HIPCHK(c, mktd::launch_mux_linear(pp, js, (const uint32_t *)sa.dev + off, (const uint32_t *)sb.dev + off, fl, c->ws_lin, (int)len, nb, c->stream));
+        if ((r = rotate_chunk(c, c->ws_lin, 2 * nb))) return r;
+        HIPCHK(c, mktd::launch_mux_combine(c->p.W, c->ws_acc, nb, words, c->stream));
+        if ((r = do_keyswitch(c, c->ws_acc, (uint32_t *)so.dev + off * len, nb))) return r;
+    }
+    return so.out(out);
+}
+
 int mkt_not_batch(mkt_ctx *c, uint32_t *x, size_t B, int mem) {
     if (!c || !x || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
     DevGuard dg(c->device);

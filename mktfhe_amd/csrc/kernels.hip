@@ -219,6 +219,24 @@ __global__ void mux_combine_kernel(WORD *__restrict__ acc, size_t B, size_t word
     }
 }
 
+// the two AND-linear parts of a level of MUX gates gathered from a pool: out[g] = AND(s, a'), out[B + g] = AND(NOT s, b'), a' / b' = the
+// operand or its negation (flag bits 0 / 1)
+__global__ void mux_linear_kernel(const uint32_t *__restrict__ pool, const uint32_t *__restrict__ is, const uint32_t *__restrict__ ia, const uint32_t *__restrict__ ib,
+                                  const uint8_t *__restrict__ fl, uint32_t *__restrict__ out, int len, size_t B) {
+    const size_t total = B * (size_t)len;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / len; const int c = (int)(i % len);
+        const uint32_t k = c == len - 1 ? (7u << 29) : 0u;                       // AND, gate.jl:10-17
+        const int f = fl ? fl[g] : 0;
+        const uint32_t s = pool[(size_t)is[g] * len + c];
+        uint32_t a = pool[(size_t)ia[g] * len + c], b = pool[(size_t)ib[g] * len + c];
+        if (f & 1) a = 0u - a;
+        if (f & 2) b = 0u - b;
+        out[i] = k + s + a;
+        out[total + i] = k + (0u - s) + b;
+    }
+}
+
 __global__ void negate_kernel(uint32_t *x, size_t total) {   // gate.jl:55-58
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) x[i] = 0u - x[i];
 }
@@ -1190,6 +1208,12 @@ hipError_t launch_gate_linear(int op, const uint8_t *ops, const uint32_t *x, con
     const size_t total = B * (size_t)len;
     if (!total) return hipSuccess;
     hipLaunchKernelGGL(gate_linear_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, op, ops, x, y, ix, iy, out, len, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_mux_linear(const uint32_t *pool, const uint32_t *is, const uint32_t *ia, const uint32_t *ib, const uint8_t *fl, uint32_t *out, int len, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    hipLaunchKernelGGL(mux_linear_kernel, dim3(blocks_for(B * (size_t)len, 256)), dim3(256), 0, s, pool, is, ia, ib, fl, out, len, B);
     return hipGetLastError();
 }
 

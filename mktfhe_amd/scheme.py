@@ -404,6 +404,23 @@ class Scheme:
         self._ck(_lib.lib().mkt_mux_batch(self.h, ps, pa, pb, po, self._batch(ks), mem))
         return ko
 
+    def mux_gather(self, pool, i_s, i_a, i_b, out, not_ab=None):
+        """a circuit level of native MUX gates (mkt_mux_batch_gather): out[j] = MUX(pool[i_s[j]], a', b'), a' = pool[i_a[j]] or its
+        negation if bit 0 of not_ab[j] is set (b' likewise, bit 1)"""
+        pp, mem, kp = _arg(pool, np.uint32, scheme=self)
+        ps, m1, ks = _arg(i_s, np.uint32, scheme=self)
+        pa, m2, ka = _arg(i_a, np.uint32, scheme=self)
+        pb, m3, kb = _arg(i_b, np.uint32, scheme=self)
+        po, m4, ko = _arg(out, np.uint32, writable=True, scheme=self)
+        pf, m5, kf = (None, mem, None) if not_ab is None else _arg(not_ab, np.uint8, scheme=self)
+        if not (mem == m1 == m2 == m3 == m4 == m5):
+            raise ValueError("all arguments must live in the same memory")
+        B = int(np.prod(ks.shape))
+        if kp.shape[-1] != self.params.lwe_len or int(np.prod(ka.shape)) != B or int(np.prod(kb.shape)) != B or self._batch(ko) != B:
+            raise ValueError("shape mismatch")
+        self._ck(_lib.lib().mkt_mux_batch_gather(self.h, pp, self._batch(kp), ps, pa, pb, pf, po, B, mem))
+        return ko
+
     def bootstrapping_(self, ctxt):
         p, mem, k = _arg(ctxt, np.uint32, writable=True, scheme=self)
         if k.shape[-1] != self.params.lwe_len:

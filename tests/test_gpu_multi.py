@@ -218,6 +218,39 @@ def test_native_mux_full_size_exact_and_sharded(require_gpu):
     sx.close()
 
 
+@pytest.mark.parametrize("p", [mk.KMS2party.scaled(n=16, N=256), mk.CGGIparam.scaled(n=20, N=256), mk.CCS2party.scaled(n=12, N=256)], ids=lambda p: p.name)
+def test_circuit_with_native_mux_nodes(require_gpu, p):
+    """Circuit.MUXN: a level of native MUX gates is ONE mkt_mux_batch_gather (operands from the pool, free NOTs as flags / swapped
+    operands), mixed with two-input gates of the same level; the ciphertext words equal the evaluation through the oracle backend, whose MUX
+    is the composite-free restatement"""
+    import torch
+    from mktfhe_amd import circuit as CI
+    crs, keys = keygen(p, 65)
+    so, sg = oracle_scheme(p, crs, keys), gpu_scheme(p, crs, keys)
+    c = CI.Circuit(); s_, a_, b_, d_ = (c.input() for _ in range(4))
+    m = c.MUXN(c.NOT(s_), a_, c.NOT(b_)); x = c.XOR(a_, d_)
+    c.output(c.MUXN(m, x, d_)); c.output(m); c.output(c.NOT(c.MUXN(s_, c.NOT(a_), b_)))
+    B = 6
+    rng = np.random.default_rng(66)
+    bits = rng.integers(0, 2, (4, B)).astype(bool)
+    k = p.nparty
+    inputs = [np.stack([mk.lwe_ith_encrypt(int(bits[i, j]), (i + j) % k, keys[(i + j) % k], p, deterministic_seed=6600 + 10 * i + j) for j in range(B)]) for i in range(4)]
+    mux_o = lambda S, A, Bv: np.stack([oracle_mux(so, p, S[j], A[j], Bv[j]) for j in range(len(S))])   # noqa: E731
+    ref = CI.evaluate(c, inputs, lambda op, xx, yy: so.gate_batch(op, xx, yy, threads=8), _neg, mux_fn=mux_o)
+    outs = CI.evaluate_on(c, inputs, sg)
+    kk = keys if p.multikey else keys[0]
+    for o, r, w in zip(outs, ref, c.plain(bits)):
+        assert np.array_equal(o, r)
+        assert np.array_equal(mk.lwe_decrypt(o, kk, p), w)
+    outs_d = CI.evaluate_on(c, [torch.from_numpy(v.view(np.int32)).cuda() for v in inputs], sg)
+    torch.cuda.synchronize()
+    for o, r in zip(outs_d, ref):
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), r)
+    with pytest.raises(mk.MktError):
+        sg.mux_gather(inputs[0], np.array([0], np.uint32), np.array([9], np.uint32), np.array([0], np.uint32), np.empty((1, p.lwe_len), np.uint32))
+    sg.close()
+
+
 # ---------------------------------------------------------------- the multi-shard evaluator
 MULTI_SETS = [
     (mk.KMS2party.scaled(n=16, N=256), mk.ARITH_F64REF),

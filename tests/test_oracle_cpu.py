@@ -549,21 +549,47 @@ def test_circuit_plan_one_call_per_level_with_oracle_backend():
         def not_(self, x):
             x[...] = neg(x)
             return x
+        def mux_gather(self, pool, js, ja, jb, out, not_ab=None):
+            self.calls.append(len(js))
+            for j in range(len(js)):
+                a = neg(pool[ja[j]]) if not_ab is not None and not_ab[j] & 1 else pool[ja[j]]
+                b = neg(pool[jb[j]]) if not_ab is not None and not_ab[j] & 2 else pool[jb[j]]
+                out[j] = oracle_mux(pool[js[j]], a, b)
+            return out
+
+    def oracle_mux(sel, a, b):
+        """the native MUX on the oracle's operators (no composite gate): two blindrotate! of the AND-linear parts, accumulators added,
+        + 1/8 at X^0 of b, one keyswitch!"""
+        accs = []
+        for x, y in ((sel, a), (neg(sel), b)):
+            at, bt = so.modswitch(O.gate_linear(1, x, y))
+            accs.append(so.blindrotate(at, so.testvector(bt)).astype(np.uint64))
+        acc = ((accs[0] + accs[1]) & np.uint64(0xFFFFFFFF)).reshape(-1, p.N)
+        acc[0, 0] = np.uint64((int(acc[0, 0]) + (1 << 29)) & 0xFFFFFFFF)
+        return so.keyswitch(acc)
 
     B = 3
     rng = np.random.default_rng(74)
     circ = CI.ripple_adder(2)
     c2 = CI.Circuit(); u, v, w = c2.input(), c2.input(), c2.input()
     c2.output(c2.NOT(c2.XOR(c2.NOT(c2.NOT(u)), c2.NOT(v)))); c2.output(c2.MUX(u, v, w))
-    for cc in (circ, c2):
+    # native MUX nodes mixed with two-input gates in one level, a negated selector (= operands swapped) and a negated data operand
+    c3 = CI.Circuit(); s3, a3, b3, d3 = (c3.input() for _ in range(4))
+    m3 = c3.MUXN(c3.NOT(s3), a3, c3.NOT(b3)); x3 = c3.XOR(a3, d3)
+    c3.output(c3.MUXN(m3, x3, d3)); c3.output(m3)
+    mux_batch = lambda S, A, Bv: np.stack([oracle_mux(S[j], A[j], Bv[j]) for j in range(len(S))])   # noqa: E731
+    for cc in (circ, c2, c3):
         bits = rng.integers(0, 2, (cc.n_inputs, B)).astype(bool)
         inputs = [np.stack([mk.lwe_encrypt(int(bits[i, j]), keys[0], p, deterministic_seed=7400 + 10 * i + j) for j in range(B)]) for i in range(cc.n_inputs)]
         fake = OracleAsScheme(); fake.calls = []
         plan = CI.Plan(cc, B)
         outs = CI.evaluate_on(cc, inputs, fake, plan)
         depth, sched = cc.levels()
-        assert len(fake.calls) == max(depth) and sum(fake.calls) == plan.gates
-        ref = CI.evaluate(cc, inputs, lambda op, x, y: so.gate_batch(op, x, y, threads=4), neg)
+        ncalls = sum((1 if l[1] else 0) + (1 if m else 0) for l, m in zip(plan.levels, plan.mux_levels))
+        assert len(fake.calls) == ncalls and max(depth) <= ncalls <= 2 * max(depth) and sum(fake.calls) == plan.gates
+        if cc is not c3:
+            assert ncalls == max(depth)                     # no native MUX nodes: one call per level
+        ref = CI.evaluate(cc, inputs, lambda op, x, y: so.gate_batch(op, x, y, threads=4), neg, mux_fn=mux_batch)
         for o, r, wv in zip(outs, ref, cc.plain(bits)):
             assert np.array_equal(o, r)
             assert np.array_equal(mk.lwe_decrypt(o, keys[0], p), wv)
