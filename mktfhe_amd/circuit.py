@@ -221,6 +221,37 @@ def evaluate_on(circ: Circuit, inputs, scheme, plan: Plan = None):
     return res
 
 
+def evaluate_sharded(circ: Circuit, inputs, multi):
+    """The B instances of a circuit sharded over the shards of a MultiScheme (one process, all GPUs): gates of different instances
+    never meet, so every shard evaluates the WHOLE circuit on its contiguous slice of the instances (mkt_multi_shard_range), one host
+    thread per shard, ciphertexts of a slice staying on that shard's device between levels; no exchange between shards.  inputs:
+    host arrays, or GPU tensors (then all shards must sit on the tensors' device: logical shards)."""
+    import threading
+    B, n = inputs[0].shape[0], multi.nshards
+    parts, errs = [None] * n, []
+
+    def work(i):
+        try:
+            lo, hi = multi.shard_range(B, i)
+            if lo < hi:
+                sh = multi.shard(i)
+                sh._user_stream = False            # GPU tensors: the shard enqueues on torch's current stream of its device, like Scheme
+                parts[i] = evaluate_on(circ, [x[lo:hi] for x in inputs], sh)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(1, n)]
+    for t in th:
+        t.start()
+    work(0)
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    done = [p for p in parts if p is not None]
+    return [_cat([p[w] for p in done]) for w in range(len(circ.outputs))]
+
+
 def ripple_adder(nbits):
     """nbits-bit adder: inputs a0..a{n-1}, b0..b{n-1} (LSB first), outputs s0..s{n-1}, carry"""
     c = Circuit()

@@ -317,6 +317,33 @@ def test_multi_shard_evaluator_equals_the_single_context(require_gpu, p, arith, 
     multi.close(); single.close()
 
 
+def test_circuit_instances_sharded_over_a_multi_scheme(require_gpu):
+    """circuit.evaluate_sharded: every shard of a MultiScheme evaluates the whole circuit on its slice of the instances (7 instances over
+    3 shards: 3 + 2 + 2), host arrays and GPU tensors: the same words as one context on all instances"""
+    import torch
+    from mktfhe_amd import circuit as CI
+    p = mk.KMS2party.scaled(n=16, N=256)
+    crs, keys = keygen(p, 57)
+    single = gpu_scheme(p, crs, keys)
+    multi = multi_scheme(p, crs, keys, [0, 0, 0], mk.ARITH_F64REF)
+    circ = CI.ripple_adder(2)
+    cm = CI.Circuit(); s_, a_, b_ = cm.input(), cm.input(), cm.input(); cm.output(cm.MUXN(s_, a_, cm.NOT(b_))); cm.output(cm.NAND(a_, b_))
+    B = 7
+    rng = np.random.default_rng(58)
+    for cc in (circ, cm):
+        bits = rng.integers(0, 2, (cc.n_inputs, B)).astype(bool)
+        inputs = [np.stack([mk.lwe_ith_encrypt(int(bits[i, j]), (i + j) % 2, keys[(i + j) % 2], p, deterministic_seed=5800 + 10 * i + j) for j in range(B)]) for i in range(cc.n_inputs)]
+        want = CI.evaluate_on(cc, inputs, single)
+        got = CI.evaluate_sharded(cc, inputs, multi)
+        got_d = CI.evaluate_sharded(cc, [torch.from_numpy(v.view(np.int32)).cuda() for v in inputs], multi)
+        torch.cuda.synchronize()
+        for w, g, gd, pl in zip(want, got, got_d, cc.plain(bits)):
+            assert np.array_equal(g, w) and np.array_equal(gd.cpu().numpy().view(np.uint32), w)
+            assert np.array_equal(mk.lwe_decrypt(g, keys, p), pl)
+    assert np.array_equal(multi.gate(0, inputs[0], inputs[1]), single.gate(0, inputs[0], inputs[1]))      # the handle's own calls still work after the shards were borrowed
+    multi.close(); single.close()
+
+
 def test_multi_shard_evaluator_full_size_and_errors(require_gpu):
     """the headline shape (BASELINE configs[1]) on three logical shards == one context == the oracle sample; keys are
     immutable once replicated; calls before mkt_multi_replicate are refused"""
