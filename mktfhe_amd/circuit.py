@@ -235,8 +235,13 @@ def evaluate_sharded(circ: Circuit, inputs, multi):
             lo, hi = multi.shard_range(B, i)
             if lo < hi:
                 sh = multi.shard(i)
+                own = sh.get_stream()              # the shard's own stream: put back afterwards
                 sh._user_stream = False            # GPU tensors: the shard enqueues on torch's current stream of its device, like Scheme
-                parts[i] = evaluate_on(circ, [x[lo:hi] for x in inputs], sh)
+                try:
+                    parts[i] = evaluate_on(circ, [x[lo:hi] for x in inputs], sh)
+                    sh.synchronize()
+                finally:
+                    sh.set_stream(own or None)
         except Exception as e:      # noqa: BLE001
             errs.append(e)
 
