@@ -50,3 +50,20 @@ def test_kms_linear_noise_model_matches_the_engine():
     br, ks = T.kms(mk.KMS2party_N1024_l2, trials=40, seed=3)
     ratio = measured()["KMS2party_N1024_l2"] / math.sqrt(br + ks)
     assert 0.8 < ratio < 1.3, ratio
+
+
+@pytest.mark.parametrize("name,trials", [("KMS2party_N1024_l2", 40), ("KMS2party", 16)])
+def test_kms_exact_mode_noise_matches_the_rounding_only_model(name, trials, monkeypatch):
+    """The same linear error model with the Float64 product error set to ZERO -- nothing empirical is left in it: gadget rounding, key
+    noise and the key switch only -- against the noise measured on the engine's EXACT (integer NTT) path, whose products are exact
+    (profiles/r03_noise_measured_exact.jsonl).  0.87-1.03 on KMS2party_N1024_l2, KMS2party and KMS4party: the KMS phase-1 / phase-2
+    control flow, key layouts and gadget order (shared word for word with the Float64 path, which differs in the product arithmetic
+    only) carry exactly the noise the scheme's own identities give them."""
+    monkeypatch.setattr(T, "float64_product_error", lambda N, logB, W, ndig: 0.0)
+    meas = {}
+    for ln in open(os.path.join(ROOT, "profiles", "r03_noise_measured_exact.jsonl")):
+        d = json.loads(ln)
+        meas[d["set"]] = d["sigma"]
+    br, ks = T.kms(getattr(mk, name), trials=trials, seed=7)
+    ratio = meas[name] / math.sqrt(br + ks)
+    assert 0.8 < ratio < 1.2, (name, ratio)
