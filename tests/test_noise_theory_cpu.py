@@ -56,14 +56,24 @@ def test_kms_linear_noise_model_matches_the_engine():
 def test_kms_exact_mode_noise_matches_the_rounding_only_model(name, trials, monkeypatch):
     """The same linear error model with the Float64 product error set to ZERO -- nothing empirical is left in it: gadget rounding, key
     noise and the key switch only -- against the noise measured on the engine's EXACT (integer NTT) path, whose products are exact
-    (profiles/r03_noise_measured_exact.jsonl).  0.87-1.03 on KMS2party_N1024_l2, KMS2party and KMS4party: the KMS phase-1 / phase-2
+    (profiles/r04_noise_measured_exact.jsonl, 512 gates per set on the round-4 kernels).  0.87-0.94 on KMS2party_N1024_l2, KMS2party and
+    KMS4party: the KMS phase-1 / phase-2
     control flow, key layouts and gadget order (shared word for word with the Float64 path, which differs in the product arithmetic
     only) carry exactly the noise the scheme's own identities give them."""
     monkeypatch.setattr(T, "float64_product_error", lambda N, logB, W, ndig: 0.0)
     meas = {}
-    for ln in open(os.path.join(ROOT, "profiles", "r03_noise_measured_exact.jsonl")):
+    for ln in open(os.path.join(ROOT, "profiles", "r04_noise_measured_exact.jsonl")):
         d = json.loads(ln)
         meas[d["set"]] = d["sigma"]
     br, ks = T.kms(getattr(mk, name), trials=trials, seed=7)
     ratio = meas[name] / math.sqrt(br + ks)
     assert 0.8 < ratio < 1.2, (name, ratio)
+
+
+@pytest.mark.parametrize("name", ["CGGIparam", "Blockparam", "Blockparam_k2", "CCS2party"])
+def test_closed_form_noise_matches_the_exact_path(name):
+    """the closed forms of CGGI / LMSS (RLWE length 1 and 2: BASELINE configs[4]) / CCS against the noise measured on the EXACT path
+    (integer NTT kernels, incl. the RLWE-length-2 kernel of round 4): measured / predicted 0.96-1.01"""
+    meas = {json.loads(ln)["set"]: json.loads(ln)["sigma"] for ln in open(os.path.join(ROOT, "profiles", "r04_noise_measured_exact.jsonl"))}
+    _, _, tot = T.predict(getattr(mk, name))
+    assert 0.9 < meas[name] / tot < 1.1, (name, meas[name] / tot)
