@@ -52,7 +52,7 @@ def test_kms_linear_noise_model_matches_the_engine():
     assert 0.8 < ratio < 1.3, ratio
 
 
-@pytest.mark.parametrize("name,trials", [("KMS2party_N1024_l2", 40), ("KMS2party", 16)])
+@pytest.mark.parametrize("name,trials", [("KMS2party_N1024_l2", 40), ("KMS2party", 16), ("KMS2partyblock", 12)])
 def test_kms_exact_mode_noise_matches_the_rounding_only_model(name, trials, monkeypatch):
     """The same linear error model with the Float64 product error set to ZERO -- nothing empirical is left in it: gadget rounding, key
     noise and the key switch only -- against the noise measured on the engine's EXACT (integer NTT) path, whose products are exact
@@ -65,7 +65,7 @@ def test_kms_exact_mode_noise_matches_the_rounding_only_model(name, trials, monk
     for ln in open(os.path.join(ROOT, "profiles", "r04_noise_measured_exact.jsonl")):
         d = json.loads(ln)
         meas[d["set"]] = d["sigma"]
-    br, ks = T.kms(getattr(mk, name), trials=trials, seed=7)
+    br, ks = T.kms(getattr(mk, name), trials=trials, seed=7, block=name.endswith("block"))
     ratio = meas[name] / math.sqrt(br + ks)
     assert 0.8 < ratio < 1.2, (name, ratio)
 
