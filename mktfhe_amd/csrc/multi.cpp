@@ -111,6 +111,8 @@ int run_sharded(mkt_multi *m, size_t B, const std::function<int(int, size_t, siz
         if (hipSetDevice(m->devices[s]) != hipSuccess) { rc[s] = MKT_ERR_HIP; msg[s] = "hipSetDevice failed"; return; }
         rc[s] = fn((int)s, sl[s].lo, sl[s].hi, msg[s]);
     };
+    int caller_dev = -1;
+    if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;   // shard 0 runs on the calling thread: its current device is put back below
     std::vector<std::thread> th;
     std::vector<size_t> inline_shards;                        // shards whose thread could not be started run on the calling thread
     for (size_t s = 1; s < n; s++) {
@@ -119,6 +121,7 @@ int run_sharded(mkt_multi *m, size_t B, const std::function<int(int, size_t, siz
     body(0);                                                  // the calling thread drives shard 0
     for (size_t s : inline_shards) body(s);
     for (auto &t : th) t.join();
+    if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
     for (size_t s = 0; s < n; s++)
         if (rc[s] != MKT_OK) return mfail(m, rc[s], "shard " + std::to_string(s) + " (device " + std::to_string(m->devices[s]) + "): " + msg[s]);
     return MKT_OK;
