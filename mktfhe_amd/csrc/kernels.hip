@@ -1034,7 +1034,7 @@ constexpr int KS_BATCH = 8;
 // BAL: balanced (signed) digits of the block schemes -- a template flag so the unbalanced path carries none of the
 // sign handling on the scalar unit (one per CU, and the busiest unit of this kernel)
 template <typename WORD, int G, int WAVES, bool BAL>
-__global__ __launch_bounds__(KS_LANES * WAVES) void keyswitch_mg_kernel(const KsArgs a, int B, int ngroups, int jslab) {
+__global__ __launch_bounds__(KS_LANES * WAVES, G == 32 ? 3 : 1) void keyswitch_mg_kernel(const KsArgs a, int B, int ngroups, int jslab) {
     // digit table: [stage][1 + drows (+ drows negated rows for balanced digits)][lane]
     uint4 *tabp = reinterpret_cast<uint4 *>(mkt_smem);
     const int trows = 1 + a.drows * (BAL ? 2 : 1);
@@ -1115,6 +1115,121 @@ __global__ __launch_bounds__(KS_LANES * WAVES) void keyswitch_mg_kernel(const Ks
     }
 #undef tab
     if (!active) return;
+    const int blk = a.mk ? c_begin : 0;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        if (g_base + g >= B) break;
+        uint32_t *outg = a.out + (size_t)(g_base + g) * lwe_len;
+        const uint32_t v[4] = {sum[g].x, sum[g].y, sum[g].z, sum[g].w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = q0 + u;
+            if (q < n) { if (v[u]) atomicAdd(&outg[(size_t)blk * n + q], v[u]); }
+            else if (q == n) { if (v[u]) atomicAdd(&outg[lwe_len - 1], v[u]); }
+        }
+    }
+}
+
+
+// Digit pairs (D = 4, f even: every shipped set has f = 8).  The staged table holds the 16 sums row(d1, td) + row(d2, td+1)
+// of two consecutive digits, so a ciphertext takes ONE ds_read_b128 and four adds per pair of digits: the loop above is bound
+// by LDS bandwidth (one 1 KiB read per ciphertext, coefficient, digit and column chunk), and this halves it; the 16 sums cost
+// a wave four row loads and twelve adds per pair whatever the number of ciphertexts.  The index is the raw 4-bit field of the
+// prepared word for both digit kinds (balanced digits: the sign lives in the table), and wrap-around addition is associative,
+// so the result is the same word for word.
+#ifndef MKT_KSP_BATCH
+#define MKT_KSP_BATCH 4
+#endif
+#ifndef MKT_KSP_OCC
+#define MKT_KSP_OCC 3
+#endif
+constexpr int KSP_BATCH = MKT_KSP_BATCH;
+template <typename WORD, int G, int WAVES, bool BAL>
+__global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_kernel(const KsArgs a, int B, int ngroups, int jslab) {
+    uint4 *tabp = reinterpret_cast<uint4 *>(mkt_smem);   // [stage][16][lane]
+#define tab(s, r, l) tabp[((s) * 16 + (r)) * KS_LANES + (l)]
+    const int lane = threadIdx.x & (KS_LANES - 1);
+    const int wv = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / KS_LANES)) : 0;
+    const int gblocks = (ngroups + WAVES - 1) / WAVES;
+    const int gg = (int)(blockIdx.x % (unsigned)gblocks) * WAVES + wv, slab = (int)(blockIdx.x / (unsigned)gblocks);
+    const int N = a.N, n = a.n, n1p = a.n1p, f = a.f;
+    const int q0 = (int)blockIdx.z * KS_CHUNK_WORDS + 4 * lane;
+    const bool active = q0 < n1p;
+    const int nblocks_out = a.mk ? a.kacc : 1;
+    const int lwe_len = nblocks_out * n + 1;
+    const int c_begin = a.mk ? (int)blockIdx.y : 0, c_end = a.mk ? c_begin + 1 : a.kacc;
+    const Gadget<uint32_t> gb(f, 2);
+    const int drows = a.drows;
+    const size_t comp_words = (size_t)N * drows * f * n1p;
+    const int g_base = gg * G;
+    uint4 sum[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) sum[g] = make_uint4(0, 0, 0, 0);
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    auto neg = [](uint4 r) { return make_uint4(0u - r.x, 0u - r.y, 0u - r.z, 0u - r.w); };
+    auto add = [](uint4 x, uint4 y) { return make_uint4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
+
+    int it = 0;
+    for (int c = c_begin; c < c_end; c++) {
+        const uint32_t *ksk = a.mk ? a.ksk + (size_t)c * a.ksk_party_stride : a.ksk + (size_t)c * comp_words;
+        int jstart = 0;
+        if (BAL) {
+            if (a.lmss) { const long cur = (long)c * N; jstart = cur >= n ? 0 : (cur + N <= n ? N : (int)(n - cur)); }
+            else jstart = n;
+        }
+        int j0 = slab * jslab, j1 = j0 + jslab;
+        if (j0 < jstart) j0 = jstart;
+        if (j1 > N) j1 = N;
+        for (int j = j0; j < j1; j++) {
+            uint32_t tt[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int gi = g_base + g < B ? g_base + g : B - 1;
+                const WORD *ac = reinterpret_cast<const WORD *>(a.acc) + ((size_t)gi * (1 + a.kacc) + 1 + c) * N;
+                const uint32_t w = extract_word<WORD>(ac, j, N);
+                tt[g] = BAL ? gb.prep(w) : divbits<uint32_t>(w, 32 - f * 2);
+            }
+            const uint32_t *rowj = ksk + (size_t)j * drows * f * n1p + q0;
+            auto ld = [=](int r, int t) { return active ? *reinterpret_cast<const uint4 *>(rowj + ((size_t)r * f + t) * n1p) : make_uint4(0, 0, 0, 0); };
+            for (int td = 0; td < f; td += 2) {
+                const int st = (it++) & (KS_STAGES - 1);
+                const int shift = 2 * (f - 2 - td);
+                // second digit: values 0, 1, 2, 3 (rows 1..3) or -2, -1, 0, 1 (balanced: rows 2, 1 negated, nothing, row 1)
+                // second digit: values 0, 1, 2, 3 (rows 1..3) or -2, -1, 0, 1 (balanced: rows 2, 1 negated, nothing, row 1)
+                uint4 r2[BAL ? 2 : 3];
+#pragma unroll
+                for (int r = 0; r < (BAL ? 2 : 3); r++) r2[r] = ld(r, td + 1);
+                for (int d1 = wv; d1 < 4; d1 += WAVES) {    // the waves share the sixteen sums
+                    uint4 e1;
+                    if (BAL) e1 = d1 == 2 ? zero : (d1 == 3 ? ld(0, td) : neg(ld(1 - d1, td)));
+                    else e1 = d1 ? ld(d1 - 1, td) : zero;
+                    if (BAL) {
+                        tab(st, d1 * 4 + 0, lane) = add(e1, neg(r2[1])); tab(st, d1 * 4 + 1, lane) = add(e1, neg(r2[0]));
+                        tab(st, d1 * 4 + 2, lane) = e1; tab(st, d1 * 4 + 3, lane) = add(e1, r2[0]);
+                    } else {
+                        tab(st, d1 * 4 + 0, lane) = e1; tab(st, d1 * 4 + 1, lane) = add(e1, r2[0]);
+                        tab(st, d1 * 4 + 2, lane) = add(e1, r2[1]); tab(st, d1 * 4 + 3, lane) = add(e1, r2[2]);
+                    }
+                }
+                if (WAVES > 1) __syncthreads();
+#pragma unroll
+                for (int g0 = 0; g0 < G; g0 += KSP_BATCH) {
+                    uint4 v[KSP_BATCH];
+#pragma unroll
+                    for (int u = 0; u < KSP_BATCH; u++) v[u] = tab(st, (int)((tt[g0 + u] >> shift) & 15u), lane);
+#pragma unroll
+                    for (int u = 0; u < KSP_BATCH; u++) {
+                        sum[g0 + u].x += v[u].x; sum[g0 + u].y += v[u].y; sum[g0 + u].z += v[u].z; sum[g0 + u].w += v[u].w;
+                    }
+                }
+            }
+        }
+    }
+#undef tab
+    if (!active) return;
+#ifdef MKT_KS_DBG_NOATOMIC
+    if (sum[0].x != 0x12345u) return;       // timing experiment only
+#endif
     const int blk = a.mk ? c_begin : 0;
 #pragma unroll
     for (int g = 0; g < G; g++) {
@@ -1487,6 +1602,10 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     const LaunchTuning &lt = launch_tuning();
     if (lt.ks_g > 0) G = lt.ks_g;
     if (lt.ks_blocks > 0) target_blocks = lt.ks_blocks;
+    // digit pairs (keyswitch_pair_kernel): D = 4 and an even digit count, 32 ciphertexts per wave
+    const bool pair = lt.ks_pair != 0 && a.logD == 2 && a.f % 2 == 0 && G == 32;
+    // (measured and left out: eight waves of 16 ciphertexts around one table -- half the slabs and atomics; KMS k=2 0.94 vs 0.79 ms, CGGIparam 0.51 vs 0.52)
+    if (pair && lt.ks_blocks <= 0) target_blocks = a.balanced && !a.mk ? 2048 : 1024;   // tools/ks_pair_sweep.sh: Blockparam 1024 gates 0.32 ms at 2048 against 0.48 at 8192 (16 384 gates: equal), KMS2partyblock 1.52 at 1024 against 1.60 at 4096
     const int ngroups = (int)((B + G - 1) / G);
     const int parties = a.mk ? a.kacc : 1;
     // enough workgroups to fill the chip (~8 per CU), slabs of at least 8 coefficients
@@ -1498,7 +1617,7 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     int waves = lt.ks_waves > 0 ? lt.ks_waves : 4;
     if (waves != 2 && waves != 4) waves = 1;
     if (G != 32) waves = 1;
-    if (a.balanced && lt.ks_waves <= 0) waves = 1;   // balanced digits: every wave stages its own table (KMS2partyblock 2.7 ms alone vs 4.0 ms shared; Blockparam 16 384 gates 4.98 -> 4.11 ms, RLWE length 2 19.3 -> 14.9 ms)
+    if (a.balanced && lt.ks_waves <= 0 && !pair) waves = 1;   // balanced digits: every wave stages its own table (KMS2partyblock 2.7 ms alone vs 4.0 ms shared; Blockparam 16 384 gates 4.98 -> 4.11 ms, RLWE length 2 19.3 -> 14.9 ms)
     const int gblocks = (ngroups + waves - 1) / waves;
     if (waves > 1) {   // same number of waves in flight as the single-wave launch
         slabs = (target_blocks + ngroups * parties - 1) / (ngroups * parties);
@@ -1506,9 +1625,23 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
         if (slabs > a.N / 8) slabs = a.N / 8;
     }
     const dim3 grid((unsigned)(gblocks * slabs), (unsigned)parties, (unsigned)((a.n1p + KS_CHUNK_WORDS - 1) / KS_CHUNK_WORDS));
-    const size_t ks_lds = (size_t)KS_STAGES * (1 + a.drows * (a.balanced ? 2 : 1)) * KS_LANES * sizeof(uint4);
+    const size_t ks_lds = pair ? (size_t)KS_STAGES * 16 * KS_LANES * sizeof(uint4) : (size_t)KS_STAGES * (1 + a.drows * (a.balanced ? 2 : 1)) * KS_LANES * sizeof(uint4);
     if (ks_lds > 64 * 1024) return hipErrorInvalidValue;   // logD <= 5
     const size_t total = B * (size_t)(parties * a.n + 1);
+    if (pair) {
+#define MKT_KSP_LAUNCH_B(WT, BV) do { if (waves == 4) hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 4, BV>), grid, dim3(KS_LANES * 4), ks_lds, s, a, (int)B, ngroups, jslab); \
+        else if (waves == 2) hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 2, BV>), grid, dim3(KS_LANES * 2), ks_lds, s, a, (int)B, ngroups, jslab); \
+        else hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 1, BV>), grid, dim3(KS_LANES), ks_lds, s, a, (int)B, ngroups, jslab); } while (0)
+        if (W == 64) {
+            hipLaunchKernelGGL(ks_init_kernel<uint64_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
+            if (a.balanced) MKT_KSP_LAUNCH_B(uint64_t, true); else MKT_KSP_LAUNCH_B(uint64_t, false);
+        } else {
+            hipLaunchKernelGGL(ks_init_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
+            if (a.balanced) MKT_KSP_LAUNCH_B(uint32_t, true); else MKT_KSP_LAUNCH_B(uint32_t, false);
+        }
+#undef MKT_KSP_LAUNCH_B
+        return hipGetLastError();
+    }
 #define MKT_KS_LAUNCH_B(WT, GV, BV) do { if (GV == 32 && waves == 4) hipLaunchKernelGGL((keyswitch_mg_kernel<WT, 32, 4, BV>), grid, dim3(KS_LANES * 4), ks_lds, s, a, (int)B, ngroups, jslab); \
         else if (GV == 32 && waves == 2) hipLaunchKernelGGL((keyswitch_mg_kernel<WT, 32, 2, BV>), grid, dim3(KS_LANES * 2), ks_lds, s, a, (int)B, ngroups, jslab); \
         else hipLaunchKernelGGL((keyswitch_mg_kernel<WT, GV, 1, BV>), grid, dim3(KS_LANES), ks_lds, s, a, (int)B, ngroups, jslab); } while (0)

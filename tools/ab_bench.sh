@@ -7,7 +7,7 @@ for sfx in ${LIBS:-base}; do
 import sys,json
 for l in sys.stdin:
     d=json.loads(l)
-    print('$sfx', d['config']['params'], 'gates/s %.0f'%d['value'], 'rot ms %.2f'%d['kernels_ms_per_step']['blindrotate'], 'ks ms %.2f'%d['kernels_ms_per_step']['keyswitch'], 'ok', d['decrypt_ok'])
+    print('$sfx', d['config']['params'], 'gates/s %.0f'%d['value'], 'rot ms %.2f'%d['kernels_ms_per_step']['blindrotate'], 'ks ms %.3f'%d['kernels_ms_per_step']['keyswitch'], 'ok', d['decrypt_ok'])
 "
  done
 done
