@@ -108,6 +108,7 @@ struct mkt_ctx {
     uint32_t *ws_lin = nullptr;
     void *ws_acc = nullptr;
     cplx *ws_lev = nullptr, *ws_scratch = nullptr;
+    uint32_t *ws_ksd = nullptr; size_t ws_ksd_words = 0;   // key switch: prepared digit words (grows with the largest batch seen)
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -360,6 +361,14 @@ int do_keyswitch(mkt_ctx *c, const void *acc, uint32_t *out, size_t B) {
     a.acc = acc; a.out = out; a.ksk = c->ks->d_ksk; a.ksk_party_stride = c->ks->ksk_party_words; a.n1p = c->ks->n1p;
     a.N = p.N; a.n = p.n; a.f = p.f; a.logD = p.logD; a.drows = c->sh.ksk_drows; a.kacc = c->sh.kacc;
     a.mk = mkt::is_mk(p.scheme) ? 1 : 0; a.balanced = mkt::is_block(p.scheme) ? 1 : 0; a.lmss = p.scheme == MKT_LMSS ? 1 : 0;
+    const size_t dw = mktd::ks_digits_words(B, a.kacc, p.N);
+    if (dw > c->ws_ksd_words) {
+        if (c->ws_ksd) (void)hipFree(c->ws_ksd);
+        c->ws_ksd = nullptr; c->ws_ksd_words = 0;
+        HIPCHK(c, hipMalloc((void **)&c->ws_ksd, dw * 4));
+        c->ws_ksd_words = dw;
+    }
+    a.digits = c->ws_ksd;
     Timer tm(c, 2);
     HIPCHK(c, mktd::launch_keyswitch(p.W, a, B, c->stream));
     return MKT_OK;
@@ -558,7 +567,7 @@ int mkt_ctx_destroy(mkt_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);   // before the workspace goes: work queued on the fork's own stream may still use it
     clear_spans(c);
-    void *ptrs[] = {c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch};
+    void *ptrs[] = {c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch, c->ws_ksd};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;                      // drops this context's reference to the key set; the last one frees it

@@ -99,7 +99,10 @@ struct KsArgs {
     int mk;                   // 1: component i -> party i's KSK and mask block i; 0: single block, ksk comp i
     int balanced;             // block schemes: copy the first words, balanced digits
     int lmss;                 // LMSS flavour of the copy rule (global coefficient index across components)
+    uint32_t *digits;         // scratch of ks_digits_words(B, kacc, N) words (digit-pair kernel); null: the per-digit kernel
 };
+// words of KsArgs::digits for a batch: [kacc][ceil(B / 32)][N][32]
+inline size_t ks_digits_words(size_t B, int kacc, int N) { return (size_t)kacc * ((B + 31) / 32) * (size_t)N * 32; }
 
 // Evaluation-key generation on the device (keygen.hip): one party's secrets and the stream key of client.cpp
 struct KeygenArgs {

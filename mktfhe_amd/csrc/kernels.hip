@@ -1131,6 +1131,22 @@ __global__ __launch_bounds__(KS_LANES * WAVES, G == 32 ? 3 : 1) void keyswitch_m
 }
 
 
+// The prepared digit word of every extracted coefficient (gsw.jl:34-52 on the sample-extracted mask, bootstrapping.jl:91,:99 / :575,:583),
+// once per key switch: [component][group of 32 ciphertexts][j][32] so that a wave of the pair kernel reads the words of its 32
+// ciphertexts for one coefficient as 128 contiguous bytes.  Block = 32 ciphertexts x 8 coefficients: reads are one or two 64-byte
+// lines per ciphertext, writes 1 KiB contiguous.
+template <typename WORD, bool BAL>
+__global__ __launch_bounds__(256) void ks_digits_kernel(const KsArgs a, int B, int ngroups) {
+    const int g = threadIdx.x & 31, j = (int)blockIdx.x * 8 + (int)(threadIdx.x >> 5);
+    if (j >= a.N) return;
+    const int grp = blockIdx.y, c = blockIdx.z;
+    const int gi = grp * 32 + g < B ? grp * 32 + g : B - 1;
+    const WORD *ac = reinterpret_cast<const WORD *>(a.acc) + ((size_t)gi * (1 + a.kacc) + 1 + c) * a.N;
+    const uint32_t w = extract_word<WORD>(ac, j, a.N);
+    const Gadget<uint32_t> gb(a.f, 2);
+    a.digits[(((size_t)c * ngroups + grp) * a.N + j) * 32 + g] = BAL ? gb.prep(w) : divbits<uint32_t>(w, 32 - a.f * 2);
+}
+
 // Digit pairs (D = 4, f even: every shipped set has f = 8).  The staged table holds the 16 sums row(d1, td) + row(d2, td+1)
 // of two consecutive digits, so a ciphertext takes ONE ds_read_b128 and four adds per pair of digits: the loop above is bound
 // by LDS bandwidth (one 1 KiB read per ciphertext, coefficient, digit and column chunk), and this halves it; the 16 sums cost
@@ -1158,7 +1174,6 @@ __global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_
     const int nblocks_out = a.mk ? a.kacc : 1;
     const int lwe_len = nblocks_out * n + 1;
     const int c_begin = a.mk ? (int)blockIdx.y : 0, c_end = a.mk ? c_begin + 1 : a.kacc;
-    const Gadget<uint32_t> gb(f, 2);
     const int drows = a.drows;
     const size_t comp_words = (size_t)N * drows * f * n1p;
     const int g_base = gg * G;
@@ -1180,15 +1195,13 @@ __global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_
         int j0 = slab * jslab, j1 = j0 + jslab;
         if (j0 < jstart) j0 = jstart;
         if (j1 > N) j1 = N;
+        // the prepared digit words of this wave's 32 ciphertexts: 128 contiguous bytes per coefficient (ks_digits_kernel), read on
+        // the scalar unit -- extracting them here cost 32 scattered scalar loads per coefficient, 40 % of the kernel
+        const uint32_t *dg = a.digits + (((size_t)c * ngroups + (gg < ngroups ? gg : ngroups - 1)) * N) * G;
         for (int j = j0; j < j1; j++) {
             uint32_t tt[G];
 #pragma unroll
-            for (int g = 0; g < G; g++) {
-                const int gi = g_base + g < B ? g_base + g : B - 1;
-                const WORD *ac = reinterpret_cast<const WORD *>(a.acc) + ((size_t)gi * (1 + a.kacc) + 1 + c) * N;
-                const uint32_t w = extract_word<WORD>(ac, j, N);
-                tt[g] = BAL ? gb.prep(w) : divbits<uint32_t>(w, 32 - f * 2);
-            }
+            for (int g = 0; g < G; g++) tt[g] = dg[(size_t)j * G + g];
             const uint32_t *rowj = ksk + (size_t)j * drows * f * n1p + q0;
             auto ld = [=](int r, int t) { return active ? *reinterpret_cast<const uint4 *>(rowj + ((size_t)r * f + t) * n1p) : make_uint4(0, 0, 0, 0); };
             for (int td = 0; td < f; td += 2) {
@@ -1227,9 +1240,6 @@ __global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_
     }
 #undef tab
     if (!active) return;
-#ifdef MKT_KS_DBG_NOATOMIC
-    if (sum[0].x != 0x12345u) return;       // timing experiment only
-#endif
     const int blk = a.mk ? c_begin : 0;
 #pragma unroll
     for (int g = 0; g < G; g++) {
@@ -1603,7 +1613,7 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
     if (lt.ks_g > 0) G = lt.ks_g;
     if (lt.ks_blocks > 0) target_blocks = lt.ks_blocks;
     // digit pairs (keyswitch_pair_kernel): D = 4 and an even digit count, 32 ciphertexts per wave
-    const bool pair = lt.ks_pair != 0 && a.logD == 2 && a.f % 2 == 0 && G == 32;
+    const bool pair = lt.ks_pair != 0 && a.logD == 2 && a.f % 2 == 0 && G == 32 && a.digits;
     // (measured and left out: eight waves of 16 ciphertexts around one table -- half the slabs and atomics; KMS k=2 0.94 vs 0.79 ms, CGGIparam 0.51 vs 0.52)
     if (pair && lt.ks_blocks <= 0) target_blocks = a.balanced && !a.mk ? 2048 : 1024;   // tools/ks_pair_sweep.sh: Blockparam 1024 gates 0.32 ms at 2048 against 0.48 at 8192 (16 384 gates: equal), KMS2partyblock 1.52 at 1024 against 1.60 at 4096
     const int ngroups = (int)((B + G - 1) / G);
@@ -1632,13 +1642,19 @@ hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
 #define MKT_KSP_LAUNCH_B(WT, BV) do { if (waves == 4) hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 4, BV>), grid, dim3(KS_LANES * 4), ks_lds, s, a, (int)B, ngroups, jslab); \
         else if (waves == 2) hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 2, BV>), grid, dim3(KS_LANES * 2), ks_lds, s, a, (int)B, ngroups, jslab); \
         else hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 1, BV>), grid, dim3(KS_LANES), ks_lds, s, a, (int)B, ngroups, jslab); } while (0)
+        const dim3 dgrid((unsigned)((a.N + 7) / 8), (unsigned)ngroups, (unsigned)a.kacc);
+#define MKT_KSD_LAUNCH(WT) do { if (a.balanced) hipLaunchKernelGGL((ks_digits_kernel<WT, true>), dgrid, dim3(256), 0, s, a, (int)B, ngroups); \
+        else hipLaunchKernelGGL((ks_digits_kernel<WT, false>), dgrid, dim3(256), 0, s, a, (int)B, ngroups); } while (0)
         if (W == 64) {
             hipLaunchKernelGGL(ks_init_kernel<uint64_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
+            MKT_KSD_LAUNCH(uint64_t);
             if (a.balanced) MKT_KSP_LAUNCH_B(uint64_t, true); else MKT_KSP_LAUNCH_B(uint64_t, false);
         } else {
             hipLaunchKernelGGL(ks_init_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
+            MKT_KSD_LAUNCH(uint32_t);
             if (a.balanced) MKT_KSP_LAUNCH_B(uint32_t, true); else MKT_KSP_LAUNCH_B(uint32_t, false);
         }
+#undef MKT_KSD_LAUNCH
 #undef MKT_KSP_LAUNCH_B
         return hipGetLastError();
     }
