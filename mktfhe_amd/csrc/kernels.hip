@@ -1496,6 +1496,26 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
         b.block0 = (unsigned)head;
         return launch_blindrotate_wide(logM, W, b, rem, s);
     }
+    // ONE chip-fill and a remainder of 288..512 rotations run as two EQUAL launches (three workgroups per CU each) instead of four
+    // per CU and then two: a round costs 3.4 / 5.0 / 5.35 / 6.3 ms at 1 / 2 / 3 / 4 workgroups per CU (KMS k = 2, N = 1024: two
+    // workgroups of a CU land on the same SIMD pair), so 2 x 5.35 beats 6.3 + 5.0 -- measured 512 KMS gates 11.2 -> 10.1 ms, 470:
+    // 11.1 -> 10.1, 448: equal, 427 (remainder 257): 9.6 -> 10.0, hence the lower bound; CGGIparam 1300 / 1536 gates 15.6 / 16.3 ->
+    // 14.5 / 14.7 ms.  Behind two or more fills the single launch drains better (853 gates: 15.6 vs 16.0 ms) and keeps the batch.
+    // Same (ciphertext, slot) numbering via block0; gates/s no longer dips below the 256-gate rate at 512 gates.
+    if (a.blk_len == 1 && logM == 9 && a.split == 0 && nrot > FILL && nrot <= 2 * FILL && nrot % FILL >= 288 && nrot % FILL <= 512) {
+        const size_t tail = FILL + nrot % FILL, head = nrot - tail, half = (tail + 1) / 2;
+        RotArgs b = a;
+        const size_t part[3] = {head, half, tail - half};
+        size_t b0 = 0;
+        for (int i = 0; i < 3; i++) {
+            if (!part[i]) continue;
+            b.block0 = a.block0 + (unsigned)b0;
+            const hipError_t e = W == 64 ? launch_rot_plain_u64(logM, b, part[i], s) : launch_rot_plain_u32(logM, b, part[i], s);
+            if (e != hipSuccess) return e;
+            b0 += part[i];
+        }
+        return hipSuccess;
+    }
     if (a.blk_len > 1) {
         // block schemes: G rotations of one slot per workgroup (rot_block.hip) once the batch fills the chip that way
         // automatic: four rotations per workgroup where that workgroup exists (M <= 512) and the batch still fills the

@@ -835,6 +835,28 @@ def test_latency_variant_of_the_rotation_is_bit_identical(require_gpu, p, monkey
     sg.close()
 
 
+@pytest.mark.parametrize("name,B", [("CGGIparam", 1024 + 100), ("CGGIparam", 1024 + 400), ("CGGIparam", 2048 + 300),
+                                     ("KMS2party_N1024_l2", 375), ("KMS2party_N1024_l2", 475), ("KMS2party_N1024_l2", 1125)])
+def test_rotation_launch_plans_agree(require_gpu, name, B):
+    """A batch past one chip-fill (1024 rotations at N = 1024) is cut into launches by its remainder (launch_blindrotate_k1):
+    up to 256 rotations go to the latency variant, 257..512 make two equal launches with the last fill, the rest one launch.
+    Each plan against the single launch (rot_split past the batch) and against the oracle, word for word, at reduced n."""
+    p = getattr(mk, name).scaled(n=8)
+    crs, keys = keygen(p, 71)
+    so = oracle_scheme(p, crs, keys)
+    sg = gpu_scheme(p, crs, keys)
+    rng = np.random.default_rng(72)
+    bits = rng.integers(0, 2, 2 * B).astype(bool)
+    c = encrypt_bits(p, keys, bits, seed=7200)
+    x, y = c[:B], c[B:]
+    planned = sg.gate(0, x, y)
+    sg.set_option("rot_split", 1 << 30)
+    single = sg.gate(0, x, y)
+    assert np.array_equal(planned, single)
+    assert np.array_equal(planned, so.gate_batch(0, x, y, threads=16))
+    sg.close()
+
+
 def test_forked_contexts_share_one_key_set(require_gpu):
     """mkt_ctx_fork: the reference's contract is ONE read-only scheme shared by concurrent bootstrapping! calls (all
     scratch per call, bootstrapping.jl:38-45).  Forks share the resident keys (no second copy in HBM), each with its own
