@@ -90,7 +90,7 @@ typedef struct {
     int32_t scheme;          /* MKT_CGGI .. MKT_KMS_BLOCK */
     int32_t n;               /* LWE dimension per party (block schemes: blk_d * blk_len) */
     int32_t N;               /* ring dimension (power of two, 256..4096) */
-    int32_t k;               /* SK: RLWE length; MK: number of parties */
+    int32_t k;               /* SK: RLWE length (any; beyond 3 on a run-time-k kernel, F64REF only); MK: number of parties */
     int32_t W;               /* ring word bits: 32 or 64 */
     int32_t l_gsw, logB_gsw; /* RGSW gadget (CGGI/LMSS/KMS) */
     int32_t l_lev, logB_lev; /* LEV gadget (KMS) */

@@ -230,6 +230,8 @@ int ensure_workspace(mkt_ctx *c, size_t gates) {
     } else if (p.scheme == MKT_CCS) {
         HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * 3 * poly_bytes(c)));    // v scratch (ring words): parked v + two hand-off slots
         HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)(p.k + 1) * c->M * sizeof(cplx)));
+    } else if (p.k > 3) {                                                          // CGGI / LMSS beyond RLWE length 3: tacc and tacc2 of blindrotate_kany_kernel
+        HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)2 * (p.k + 1) * c->M * sizeof(cplx)));
     }
     c->ws_gates = gates;
     return MKT_OK;
@@ -245,11 +247,6 @@ int check_ready(mkt_ctx *c, bool need_brk, bool need_ksk) {
         if (need_brk && mkt::is_kms(c->p.scheme) && (!c->ks->rlk_loaded[i] || !c->ks->pub_loaded[i])) return fail(c, MKT_ERR_STATE, "rlk / public key not loaded");
     }
     if (need_brk && mkt::is_mk(c->p.scheme) && !c->ks->crs_loaded) return fail(c, MKT_ERR_STATE, "crs not loaded");
-    return MKT_OK;
-}
-
-int unsupported_scheme(mkt_ctx *c) {
-    if ((c->p.scheme == MKT_CGGI || c->p.scheme == MKT_LMSS) && c->p.k > 3) return fail(c, MKT_ERR_UNSUPPORTED, "CGGI / LMSS are implemented for RLWE length k <= 3");
     return MKT_OK;
 }
 
@@ -330,7 +327,12 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         mktd::RotArgs a = rot_args(c, lwe, stride, pre);
         a.init_mode = 0; a.out_mode = 0; a.acc_io = acc;
         Timer tm(c, 1);
-        if (p.k > 1) {   // general RLWE length (CGGI, LMSS)
+        if (p.k > 3) {   // any RLWE length: accumulators in memory (blindrotate_kany_kernel)
+            a.ngates = B;
+            HIPCHK(c, mktd::launch_blindrotate_kany(c->logM, p.W, p.k, a, scratch, B, c->stream));
+            return MKT_OK;
+        }
+        if (p.k > 1) {   // RLWE length 2, 3 (CGGI, LMSS): accumulators in registers
             a.ngates = B;
             HIPCHK(c, mktd::launch_blindrotate_kr(c->logM, p.W, p.k, a, B, c->stream));
             return MKT_OK;
@@ -853,7 +855,7 @@ static int gate_impl(mkt_ctx *c, int op, const uint8_t *ops, const uint32_t *x, 
                      uint32_t *out, size_t B, int mem) {
     MKT_EXACT_GATE(c);
     int r;
-    if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
+    if ((r = check_ready(c, true, true))) return r;
     DevGuard dg(c->device);
     Timer whole(c, 0);
     const size_t len = (size_t)c->sh.lwe_len;
@@ -913,7 +915,7 @@ int mkt_mux_batch(mkt_ctx *c, const uint32_t *sel, const uint32_t *a, const uint
     if (!c || !sel || !a || !b || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
     MKT_EXACT_GATE(c);
     int r;
-    if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
+    if ((r = check_ready(c, true, true))) return r;
     DevGuard dg(c->device);
     Timer whole(c, 0);
     const size_t len = (size_t)c->sh.lwe_len, words = (size_t)(1 + c->sh.kacc) * c->p.N;
@@ -944,7 +946,7 @@ int mkt_mux_batch_gather(mkt_ctx *c, const uint32_t *pool, size_t pool_rows, con
         for (size_t j = 0; j < B; j++) if (is[j] >= pool_rows || ia[j] >= pool_rows || ib[j] >= pool_rows || (not_ab && (not_ab[j] & ~3u))) return fail(c, MKT_ERR_ARG, "mkt_mux_batch_gather: operand index outside the pool, or unknown flag");
     MKT_EXACT_GATE(c);
     int r;
-    if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
+    if ((r = check_ready(c, true, true))) return r;
     DevGuard dg(c->device);
     Timer whole(c, 0);
     const size_t len = (size_t)c->sh.lwe_len, words = (size_t)(1 + c->sh.kacc) * c->p.N;
@@ -980,7 +982,7 @@ int mkt_bootstrap_batch(mkt_ctx *c, uint32_t *lwe, size_t B, int mem) {
     if (!c || !lwe || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
     MKT_EXACT_GATE(c);
     int r;
-    if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, true))) return r;
+    if ((r = check_ready(c, true, true))) return r;
     DevGuard dg(c->device);
     Timer whole(c, 0);
     const size_t len = (size_t)c->sh.lwe_len;
@@ -1012,7 +1014,7 @@ int mkt_blindrotate_batch(mkt_ctx *c, const uint32_t *atilde, void *acc, size_t 
     if (!c || !atilde || !acc || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
     MKT_EXACT_GATE(c);
     int r;
-    if ((r = unsupported_scheme(c)) || (r = check_ready(c, true, false))) return r;
+    if ((r = check_ready(c, true, false))) return r;
     DevGuard dg(c->device);
     Timer whole(c, 0);
     const size_t alen = (size_t)c->sh.lwe_len - 1, accb = (size_t)(1 + c->sh.kacc) * poly_bytes(c);

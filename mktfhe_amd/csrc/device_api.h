@@ -137,6 +137,8 @@ bool blockg_supported(int logM, int G);
 hipError_t launch_rot_blockg_u32(int logM, int G, int npolys, const RotArgs &a, size_t nslots, hipStream_t s);   // npolys = RLWE length + 1 (2; 3 at block length 1 or 3 and 4 at block length 1, 32-bit ring, G = 4)
 hipError_t launch_rot_blockg_u64(int logM, int G, int npolys, const RotArgs &a, size_t nslots, hipStream_t s);
 hipError_t launch_blindrotate_kr(int logM, int W, int kr, const RotArgs &a, size_t nrot, hipStream_t s);
+// any RLWE length (run-time k; accumulators in memory): scratch = 2 * (kr + 1) * M points per rotation
+hipError_t launch_blindrotate_kany(int logM, int W, int kr, const RotArgs &a, cplx *scratch, size_t nrot, hipStream_t s);
 hipError_t launch_kms_phase2(int logM, int W, const Phase2Args &a, size_t B, hipStream_t s);
 hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, hipStream_t s);
 hipError_t launch_ccs_pipe(int logM, int W, const CcsArgs &a, size_t B, hipStream_t s);   // one ciphertext on two thread groups (ccs_pipe.hip); vscratch [B][3][N]

@@ -680,6 +680,133 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kr_kernel(
 #pragma unroll
         for (int e = 0; e < R; e++) { accg[c * N + e * NT + t] = acc[c][e][0]; accg[c * N + M + e * NT + t] = acc[c][e][1]; }
 }
+
+// ------------------------------------------------------------------------------------------------
+// CGGI / LMSS blind rotation for ANY RLWE length (TFHEparams_bin.k / TFHEparams_block.k are unrestricted, scheme.jl:6-20,
+// :22-38): the loop nest of the kernel above with np = k + 1 a run-time value.  What that kernel holds in registers lives in
+// memory here -- the accumulator stays in acc_io, the transform-domain sums tacc (:60 / :143) and tacc2 (:142) in a scratch
+// area of 2 * np * M points per rotation -- and every thread only ever touches its own coefficients and points, so nothing
+// but the transforms needs ordering.  Used above k = 3 only (no shipped set has k > 1); same operation order as
+// blindrotate_kr_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int LOGM, typename WORD>
+__global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void blindrotate_kany_kernel(const RotArgs a, int np, cplx *scratch) {
+    using P = Plan<LOGM, LOGR>;
+    constexpr int R = P::R, NT = P::NT, M = P::M, N = 2 * M;
+    cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
+    cplx *psi_l = lds + P::LDS_CPLX;
+    const int t = threadIdx.x;
+    XS xs = make_xs();
+    for (int i = t; i < M; i += NT) psi_l[i] = a.tw.psi[i];
+    __syncthreads();
+    const size_t rot = blockIdx.x;
+    const uint32_t *at_src = a.lwe + rot * (size_t)a.lwe_stride;
+    const Gadget<WORD> gd(a.l, a.logB);
+    const int l = a.l;
+    int dp[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) dp[e] = dev_pos(MKT_DEVORDER_KR, t * R + e, NT);
+    WORD *accg = reinterpret_cast<WORD *>(a.acc_io) + rot * (size_t)np * N;
+    cplx *tacc = scratch + rot * (size_t)2 * np * M, *t2 = tacc + (size_t)np * M;
+    const int msbit = 32 - a.logN - 1;
+    const bool blk_mode = a.blk_len > 1;
+    const int blen = blk_mode ? a.blk_len : 1;
+    auto add_native = [&](int q, cplx (&s2)[R]) {                        // acc[q] += native(ifft(s2)) (:71-73 / :162-163)
+        fft_inverse<LOGM, LOGR, 1, true>(reinterpret_cast<cplx(&)[1][R]>(s2), psi_l, lds, t, xs.lx);
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            const cplx v = cmul(s2[e], a.tw.rootsinv[e * NT + t]);
+            WORD *lo = accg + (size_t)q * N + e * NT + t, *hi = lo + M;
+            *lo = (WORD)(*lo + native<WORD>(v.re));
+            *hi = (WORD)(*hi + native<WORD>(-v.im));
+        }
+    };
+    for (int blk = 0; blk < a.n / blen; blk++) {
+        if (blk_mode) {
+            for (int q = 0; q < np; q++)
+#pragma unroll
+                for (int e = 0; e < R; e++) { t2[(size_t)q * M + dp[e]].re = 0.0; t2[(size_t)q * M + dp[e]].im = 0.0; }
+        }
+        bool any = false;
+        for (int qb = 0; qb < blen; qb++) {
+            const int idx = blk * blen + qb;
+            const uint32_t v0 = at_src[idx];
+            const uint32_t at = a.pre_switched ? v0 : divbits<uint32_t>(v0, msbit);
+            if (at == 0) continue;                                       // :48 / :145
+            any = true;
+            for (int q = 0; q < np; q++)
+#pragma unroll
+                for (int e = 0; e < R; e++) { tacc[(size_t)q * M + dp[e]].re = 0.0; tacc[(size_t)q * M + dp[e]].im = 0.0; }
+            const cplx *brk = a.brk + (size_t)idx * np * l * np * M;
+            for (int c = 0; c < np; c++) {                               // b digits, then a_0, a_1 ... (:63-68 / :146-154)
+                WORD tp[R][2];
+#pragma unroll
+                for (int e = 0; e < R; e++) {
+                    tp[e][0] = gd.prep(accg[(size_t)c * N + e * NT + t]);
+                    tp[e][1] = gd.prep(accg[(size_t)c * N + M + e * NT + t]);
+                }
+                for (int j = 0; j < l; j++) {
+                    cplx z[R];
+#pragma unroll
+                    for (int e = 0; e < R; e++) {
+                        const int d0 = gd.digit(tp[e][0], j), d1 = gd.digit(tp[e][1], j);
+                        cplx v; v.re = (double)d0; v.im = (double)(-d1);
+                        z[e] = cmul(v, a.tw.roots[e * NT + t]);
+                    }
+                    fft_forward1<LOGM>(z, psi_l, lds, t, xs);
+                    const cplx *row = brk + (size_t)(c * l + j) * np * M;
+                    for (int q = 0; q < np; q++)
+#pragma unroll
+                        for (int e = 0; e < R; e++) {
+                            cplx *ta = tacc + (size_t)q * M + dp[e];
+                            *ta = cadd(*ta, cmul(z[e], row[(size_t)q * M + dp[e]]));
+                        }
+                }
+            }
+            const cplx *mono = a.monomial + (size_t)(at - 1) * M;
+            for (int q = 0; q < np; q++) {
+                if (blk_mode) {                                          // :157 tacc2 += monomial * tacc
+#pragma unroll
+                    for (int e = 0; e < R; e++) {
+                        cplx *tb = t2 + (size_t)q * M + dp[e];
+                        *tb = cadd(*tb, cmul(mono[dp[e]], tacc[(size_t)q * M + dp[e]]));
+                    }
+                } else {                                                 // :71-73
+                    cplx s2[R];
+#pragma unroll
+                    for (int e = 0; e < R; e++) s2[e] = cmul(mono[dp[e]], tacc[(size_t)q * M + dp[e]]);
+                    add_native(q, s2);
+                }
+            }
+        }
+        if (blk_mode && any) {                                           // :162-163 (an all-zero block adds native(0) = 0)
+            for (int q = 0; q < np; q++) {
+                cplx s2[R];
+#pragma unroll
+                for (int e = 0; e < R; e++) s2[e] = t2[(size_t)q * M + dp[e]];
+                add_native(q, s2);
+            }
+        }
+    }
+}
+
+hipError_t launch_blindrotate_kany(int logM, int W, int kr, const RotArgs &a, cplx *scratch, size_t nrot, hipStream_t s) {
+    if (!nrot) return hipSuccess;
+    if (kr < 1 || !scratch) return hipErrorInvalidValue;
+    last_rot_kernel = "blindrotate_kany_kernel";
+    MKT_DISPATCH_LOGM(logM, {
+        using P = Plan<LM, LOGR>;
+        constexpr size_t LB = P::LDS_BYTES + (size_t)P::M * sizeof(cplx);
+        if (W == 64) {
+            hipError_t e = set_lds(blindrotate_kany_kernel<LM, uint64_t>, LB); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((blindrotate_kany_kernel<LM, uint64_t>), dim3((unsigned)nrot), dim3(P::NT), LB, s, a, kr + 1, scratch);
+        } else {
+            hipError_t e = set_lds(blindrotate_kany_kernel<LM, uint32_t>, LB); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((blindrotate_kany_kernel<LM, uint32_t>), dim3((unsigned)nrot), dim3(P::NT), LB, s, a, kr + 1, scratch);
+        }
+    });
+    return hipGetLastError();
+}
 #endif  // TU 7
 
 #if MKT_IN_TU(4)

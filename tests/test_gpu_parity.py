@@ -113,6 +113,10 @@ SMALL = [
     mk.Blockparam.scaled(n=150, N=128, blk_d=50, k=2, blk_len=3),
     mk.Blockparam_k2.scaled(n=24, blk_d=8),                 # BASELINE configs[4] shape (N = 1024, k = 2, block length 3) at reduced n
     mk.Blockparam_k2.scaled(n=24, blk_d=12, blk_len=2),     # other block lengths take the generic path
+    mk.CGGIparam.scaled(n=10, N=256, k=4),                  # RLWE length > 3: the run-time-k kernel (accumulators in memory)
+    mk.CGGIparam.scaled(n=8, N=128, k=6, l_gsw=2, logB_gsw=10),
+    mk.Blockparam.scaled(n=24, N=256, blk_d=8, k=4),
+    mk.Blockparam.scaled(n=20, N=128, blk_d=10, k=5, blk_len=2),
 ]
 
 
@@ -607,7 +611,7 @@ def test_two_contexts_two_host_threads(require_gpu):
 
 KEYGEN_SETS = [
     mk.CGGIparam.scaled(n=20, N=256), mk.CGGIparam.scaled(n=16, N=256, k=2), mk.Blockparam.scaled(n=30, N=256, blk_d=10),
-    mk.Blockparam.scaled(n=150, N=128, blk_d=50, k=2),
+    mk.Blockparam.scaled(n=150, N=128, blk_d=50, k=2), mk.CGGIparam.scaled(n=10, N=256, k=4),
     mk.KMS2party.scaled(n=16, N=256), mk.KMS2partyblock.scaled(n=24, N=256, blk_d=8), mk.CCS2party.scaled(n=12, N=256),
     mk.KMS4party.scaled(n=10, N=512), mk.CCS4party.scaled(n=6, N=1024), mk.CGGIparam, mk.KMS2party,
 ]
