@@ -108,7 +108,7 @@ struct mkt_ctx {
     uint32_t *ws_lin = nullptr;
     void *ws_acc = nullptr;
     cplx *ws_lev = nullptr, *ws_scratch = nullptr;
-    uint32_t *ws_ksd = nullptr; size_t ws_ksd_words = 0;   // key switch: prepared digit words (grows with the largest batch seen)
+    uint32_t *ws_ksd = nullptr; size_t ws_ksd_words = 0;   // key switch: prepared digit words + partial sums per slab (grows with the largest batch seen)
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -363,14 +363,15 @@ int do_keyswitch(mkt_ctx *c, const void *acc, uint32_t *out, size_t B) {
     a.acc = acc; a.out = out; a.ksk = c->ks->d_ksk; a.ksk_party_stride = c->ks->ksk_party_words; a.n1p = c->ks->n1p;
     a.N = p.N; a.n = p.n; a.f = p.f; a.logD = p.logD; a.drows = c->sh.ksk_drows; a.kacc = c->sh.kacc;
     a.mk = mkt::is_mk(p.scheme) ? 1 : 0; a.balanced = mkt::is_block(p.scheme) ? 1 : 0; a.lmss = p.scheme == MKT_LMSS ? 1 : 0;
-    const size_t dw = mktd::ks_digits_words(B, a.kacc, p.N);
-    if (dw > c->ws_ksd_words) {
+    size_t dw = 0, pw = 0;
+    mktd::ks_scratch_words(a, B, &dw, &pw);
+    if (dw + pw > c->ws_ksd_words) {
         if (c->ws_ksd) (void)hipFree(c->ws_ksd);
         c->ws_ksd = nullptr; c->ws_ksd_words = 0;
-        HIPCHK(c, hipMalloc((void **)&c->ws_ksd, dw * 4));
-        c->ws_ksd_words = dw;
+        HIPCHK(c, hipMalloc((void **)&c->ws_ksd, (dw + pw) * 4));
+        c->ws_ksd_words = dw + pw;
     }
-    a.digits = c->ws_ksd;
+    if (dw) { a.digits = c->ws_ksd; a.partial = c->ws_ksd + dw; }
     Timer tm(c, 2);
     HIPCHK(c, mktd::launch_keyswitch(p.W, a, B, c->stream));
     return MKT_OK;

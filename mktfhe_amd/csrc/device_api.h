@@ -99,10 +99,11 @@ struct KsArgs {
     int mk;                   // 1: component i -> party i's KSK and mask block i; 0: single block, ksk comp i
     int balanced;             // block schemes: copy the first words, balanced digits
     int lmss;                 // LMSS flavour of the copy rule (global coefficient index across components)
-    uint32_t *digits;         // scratch of ks_digits_words(B, kacc, N) words (digit-pair kernel); null: the per-digit kernel
+    uint32_t *digits;         // scratch of the digit-pair kernel (both or neither; sizes: ks_scratch_words): prepared digit words
+    uint32_t *partial;        //   and the partial sums of every slab; null: the per-digit kernel with atomics
 };
-// words of KsArgs::digits for a batch: [kacc][ceil(B / 32)][N][32]
-inline size_t ks_digits_words(size_t B, int kacc, int N) { return (size_t)kacc * ((B + 31) / 32) * (size_t)N * 32; }
+// words of KsArgs::digits / KsArgs::partial for a batch of B ciphertexts (0, 0: this shape runs on the per-digit kernel)
+void ks_scratch_words(const KsArgs &a, size_t B, size_t *digit_words, size_t *partial_words);
 
 // Evaluation-key generation on the device (keygen.hip): one party's secrets and the stream key of client.cpp
 struct KeygenArgs {

@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(256) void ks_digits_kernel(const KsArgs a, int B, i
 #endif
 constexpr int KSP_BATCH = MKT_KSP_BATCH;
 template <typename WORD, int G, int WAVES, bool BAL>
-__global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_kernel(const KsArgs a, int B, int ngroups, int jslab) {
+__global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_kernel(const KsArgs a, int B, int ngroups) {
     uint4 *tabp = reinterpret_cast<uint4 *>(mkt_smem);   // [stage][16][lane]
 #define tab(s, r, l) tabp[((s) * 16 + (r)) * KS_LANES + (l)]
     const int lane = threadIdx.x & (KS_LANES - 1);
@@ -1298,8 +1298,6 @@ __global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_
     const int N = a.N, n = a.n, n1p = a.n1p, f = a.f;
     const int q0 = (int)blockIdx.z * KS_CHUNK_WORDS + 4 * lane;
     const bool active = q0 < n1p;
-    const int nblocks_out = a.mk ? a.kacc : 1;
-    const int lwe_len = nblocks_out * n + 1;
     const int c_begin = a.mk ? (int)blockIdx.y : 0, c_end = a.mk ? c_begin + 1 : a.kacc;
     const int drows = a.drows;
     const size_t comp_words = (size_t)N * drows * f * n1p;
@@ -1319,8 +1317,11 @@ __global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_
             if (a.lmss) { const long cur = (long)c * N; jstart = cur >= n ? 0 : (cur + N <= n ? N : (int)(n - cur)); }
             else jstart = n;
         }
-        int j0 = slab * jslab, j1 = j0 + jslab;
-        if (j0 < jstart) j0 = jstart;
+        // the slabs share the coefficients that ARE switched, [jstart, N): equal work per slab also for the block schemes, whose
+        // first n coefficients are copied (Blockparam: 337 of 1024 left)
+        const int nslabs = (int)(gridDim.x / (unsigned)gblocks), js = (N - jstart + nslabs - 1) / nslabs;
+        const int j0 = jstart + slab * js;
+        int j1 = j0 + js;
         if (j1 > N) j1 = N;
         // the prepared digit words of this wave's 32 ciphertexts: 128 contiguous bytes per coefficient (ks_digits_kernel), read on
         // the scalar unit -- extracting them here cost 32 scattered scalar loads per coefficient, 40 % of the kernel
@@ -1343,7 +1344,7 @@ __global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_
                     uint4 e1;
                     if (BAL) e1 = d1 == 2 ? zero : (d1 == 3 ? ld(0, td) : neg(ld(1 - d1, td)));
                     else e1 = d1 ? ld(d1 - 1, td) : zero;
-                    if (BAL) {
+                    if constexpr (BAL) {
                         tab(st, d1 * 4 + 0, lane) = add(e1, neg(r2[1])); tab(st, d1 * 4 + 1, lane) = add(e1, neg(r2[0]));
                         tab(st, d1 * 4 + 2, lane) = e1; tab(st, d1 * 4 + 3, lane) = add(e1, r2[0]);
                     } else {
@@ -1367,18 +1368,43 @@ __global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_
     }
 #undef tab
     if (!active) return;
+    // this wave's share of the sum over (component, coefficient, digit): one 16-byte store per ciphertext into the partial-sum rows
+    // [slab][party][ciphertext][n1p]; ks_reduce_kernel adds the slabs (atomics on the output words cost 0.2 ms of a 0.6 ms kernel)
     const int blk = a.mk ? c_begin : 0;
 #pragma unroll
     for (int g = 0; g < G; g++) {
         if (g_base + g >= B) break;
-        uint32_t *outg = a.out + (size_t)(g_base + g) * lwe_len;
-        const uint32_t v[4] = {sum[g].x, sum[g].y, sum[g].z, sum[g].w};
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int q = q0 + u;
-            if (q < n) { if (v[u]) atomicAdd(&outg[(size_t)blk * n + q], v[u]); }
-            else if (q == n) { if (v[u]) atomicAdd(&outg[lwe_len - 1], v[u]); }
+        *reinterpret_cast<uint4 *>(a.partial + (((size_t)slab * gridDim.y + blk) * B + (g_base + g)) * n1p + q0) = sum[g];
+    }
+}
+
+// out = what the key switch leaves alone (b, and for the block schemes the extracted words that are copied, :180-191 / :676-679:
+// ks_init_kernel's words) + the partial sums of every slab (and, for b, of every party).
+template <typename WORD>
+__global__ void ks_reduce_kernel(const KsArgs a, size_t B, int slabs, int parties) {
+    constexpr int sh = WordTraits<WORD>::W - 32;
+    const int nblocks_out = a.mk ? a.kacc : 1;
+    const int lwe_len = nblocks_out * a.n + 1;
+    const size_t total = B * (size_t)lwe_len;
+    const size_t row = (size_t)a.n1p, slab_stride = (size_t)parties * B * row;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / lwe_len; const int q = (int)(i % lwe_len);
+        const WORD *accg = reinterpret_cast<const WORD *>(a.acc) + g * (size_t)(1 + a.kacc) * a.N;
+        uint32_t v = 0;
+        if (q == lwe_len - 1) {
+            v = (uint32_t)(accg[0] >> sh);
+            for (int sl = 0; sl < slabs; sl++)
+                for (int pt = 0; pt < parties; pt++) v += a.partial[sl * slab_stride + ((size_t)pt * B + g) * row + a.n];
+        } else {
+            if (a.balanced) {
+                if (a.lmss) { const int c = q / a.N, j = q % a.N; v = extract_word<WORD>(accg + (size_t)(1 + c) * a.N, j, a.N); }
+                else { const int c = q / a.n, j = q % a.n; v = extract_word<WORD>(accg + (size_t)(1 + c) * a.N, j, a.N); }
+            }
+            const int pt = a.mk ? q / a.n : 0, w = a.mk ? q % a.n : q;
+            const uint32_t *src = a.partial + ((size_t)pt * B + g) * row + w;
+            for (int sl = 0; sl < slabs; sl++) v += src[sl * slab_stride];
         }
+        a.out[i] = v;
     }
 }
 
@@ -1749,57 +1775,75 @@ hipError_t launch_ccs_blindrotate(int logM, int W, const CcsArgs &a, size_t B, h
 #endif  // TU 4
 
 #if MKT_IN_TU(0)
-hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
-    if (!B) return hipSuccess;
-    int G = 32, target_blocks = 1024;   // swept on MI355X (tools/ks_sweep.sh): 1.6 ms vs 4.7 ms single-gate at KMS k=2 N=1024
-    // the balanced-digit variant (block schemes) does its sign handling on the scalar unit and wants four to eight times the workgroups once
-    // the batch leaves few slabs (and one wave per staged table, below): Blockparam 4096 gates 2.12 -> 1.32 ms, 16 384 gates 8.49 -> 4.94 ms, KMS2partyblock 1024 gates
-    // 2.73 -> 2.35 ms, neutral at 1024 LMSS gates; the unbalanced variant is fastest at 1024 at every batch size (tools/ks_blocks_sweep*.sh)
+namespace {
+struct KsPlan { int G, waves, ngroups, parties, gblocks, slabs, jslab; bool pair; };
+// launch shape of a key switch; pair: digit pairs (keyswitch_pair_kernel: D = 4 and an even digit count, 32 ciphertexts per wave,
+// scratch present), else the per-digit kernel with atomics
+KsPlan ks_plan(const KsArgs &a, size_t B, bool have_scratch) {
+    KsPlan q{};
+    q.G = 32;
+    int target_blocks = 1024;   // swept on MI355X (tools/ks_sweep.sh): 1.6 ms vs 4.7 ms single-gate at KMS k=2 N=1024
+    // per-digit kernel, balanced digits (block schemes): sign handling on the scalar unit wants four to eight times the workgroups once the
+    // batch leaves few slabs (and one wave per staged table, below): Blockparam 4096 gates 2.12 -> 1.32 ms, 16 384 gates 8.49 -> 4.94 ms,
+    // KMS2partyblock 1024 gates 2.73 -> 2.35 ms; the unbalanced variant is fastest at 1024 at every batch size (tools/ks_blocks_sweep*.sh)
     if (a.balanced) target_blocks = a.mk ? 4096 : 8192;
     const LaunchTuning &lt = launch_tuning();
-    if (lt.ks_g > 0) G = lt.ks_g;
+    if (lt.ks_g > 0) q.G = lt.ks_g;
     if (lt.ks_blocks > 0) target_blocks = lt.ks_blocks;
-    // digit pairs (keyswitch_pair_kernel): D = 4 and an even digit count, 32 ciphertexts per wave
-    const bool pair = lt.ks_pair != 0 && a.logD == 2 && a.f % 2 == 0 && G == 32 && a.digits;
-    // (measured and left out: eight waves of 16 ciphertexts around one table -- half the slabs and atomics; KMS k=2 0.94 vs 0.79 ms, CGGIparam 0.51 vs 0.52)
-    if (pair && lt.ks_blocks <= 0) target_blocks = a.balanced && !a.mk ? 2048 : 1024;   // tools/ks_pair_sweep.sh: Blockparam 1024 gates 0.32 ms at 2048 against 0.48 at 8192 (16 384 gates: equal), KMS2partyblock 1.52 at 1024 against 1.60 at 4096
-    const int ngroups = (int)((B + G - 1) / G);
-    const int parties = a.mk ? a.kacc : 1;
-    // enough workgroups to fill the chip (~8 per CU), slabs of at least 8 coefficients
-    int slabs = (target_blocks + ngroups * parties - 1) / (ngroups * parties);
-    if (slabs < 1) slabs = 1;
-    if (slabs > a.N / 8) slabs = a.N / 8;
-    const int jslab = (a.N + slabs - 1) / slabs;
-    slabs = (a.N + jslab - 1) / jslab;
-    int waves = lt.ks_waves > 0 ? lt.ks_waves : 4;
-    if (waves != 2 && waves != 4) waves = 1;
-    if (G != 32) waves = 1;
-    if (a.balanced && lt.ks_waves <= 0 && !pair) waves = 1;   // balanced digits: every wave stages its own table (KMS2partyblock 2.7 ms alone vs 4.0 ms shared; Blockparam 16 384 gates 4.98 -> 4.11 ms, RLWE length 2 19.3 -> 14.9 ms)
-    const int gblocks = (ngroups + waves - 1) / waves;
-    if (waves > 1) {   // same number of waves in flight as the single-wave launch
-        slabs = (target_blocks + ngroups * parties - 1) / (ngroups * parties);
-        if (slabs < 1) slabs = 1;
-        if (slabs > a.N / 8) slabs = a.N / 8;
-    }
+    q.pair = lt.ks_pair != 0 && a.logD == 2 && a.f % 2 == 0 && q.G == 32 && have_scratch;
+    // (measured and left out: eight waves of 16 ciphertexts around one table -- half the slabs; KMS k=2 0.94 vs 0.79 ms, CGGIparam 0.51 vs 0.52)
+    if (q.pair && lt.ks_blocks <= 0) target_blocks = 1024;   // tools/ks_pair_sweep.sh, every kind of set: one round of three 4-wave workgroups per CU (Blockparam 1024 / 16 384 gates 0.12 / 1.35 ms; 0.19 / 1.44 at 2048)
+    q.ngroups = (int)((B + q.G - 1) / q.G);
+    q.parties = a.mk ? a.kacc : 1;
+    // enough workgroups to fill the chip, slabs of at least 8 coefficients
+    auto nslabs = [&] {
+        int sl = (target_blocks + q.ngroups * q.parties - 1) / (q.ngroups * q.parties);
+        if (sl < 1) sl = 1;
+        if (sl > a.N / 8) sl = a.N / 8;
+        return sl < 1 ? 1 : sl;
+    };
+    q.slabs = nslabs();
+    q.jslab = (a.N + q.slabs - 1) / q.slabs;
+    q.slabs = (a.N + q.jslab - 1) / q.jslab;
+    q.waves = lt.ks_waves > 0 ? lt.ks_waves : 4;
+    if (q.waves != 2 && q.waves != 4) q.waves = 1;
+    if (q.G != 32) q.waves = 1;
+    if (a.balanced && lt.ks_waves <= 0 && !q.pair) q.waves = 1;   // per-digit kernel, balanced digits: every wave stages its own table (KMS2partyblock 2.7 ms alone vs 4.0 ms shared; Blockparam 16 384 gates 4.98 -> 4.11 ms, RLWE length 2 19.3 -> 14.9 ms)
+    q.gblocks = (q.ngroups + q.waves - 1) / q.waves;
+    return q;
+}
+}  // namespace
+
+void ks_scratch_words(const KsArgs &a, size_t B, size_t *digit_words, size_t *partial_words) {
+    const KsPlan q = ks_plan(a, B, true);
+    *digit_words = q.pair ? (size_t)a.kacc * q.ngroups * (size_t)a.N * 32 : 0;                    // [kacc][ceil(B / 32)][N][32]
+    *partial_words = q.pair ? (size_t)q.slabs * q.parties * B * (size_t)a.n1p : 0;                 // [slab][party][B][n1p]
+}
+
+hipError_t launch_keyswitch(int W, const KsArgs &a, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    const KsPlan q = ks_plan(a, B, a.digits && a.partial);
+    const int G = q.G, waves = q.waves, ngroups = q.ngroups, parties = q.parties, gblocks = q.gblocks, slabs = q.slabs, jslab = q.jslab;
+    const bool pair = q.pair;
     const dim3 grid((unsigned)(gblocks * slabs), (unsigned)parties, (unsigned)((a.n1p + KS_CHUNK_WORDS - 1) / KS_CHUNK_WORDS));
     const size_t ks_lds = pair ? (size_t)KS_STAGES * 16 * KS_LANES * sizeof(uint4) : (size_t)KS_STAGES * (1 + a.drows * (a.balanced ? 2 : 1)) * KS_LANES * sizeof(uint4);
     if (ks_lds > 64 * 1024) return hipErrorInvalidValue;   // logD <= 5
     const size_t total = B * (size_t)(parties * a.n + 1);
-    if (pair) {
-#define MKT_KSP_LAUNCH_B(WT, BV) do { if (waves == 4) hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 4, BV>), grid, dim3(KS_LANES * 4), ks_lds, s, a, (int)B, ngroups, jslab); \
-        else if (waves == 2) hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 2, BV>), grid, dim3(KS_LANES * 2), ks_lds, s, a, (int)B, ngroups, jslab); \
-        else hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 1, BV>), grid, dim3(KS_LANES), ks_lds, s, a, (int)B, ngroups, jslab); } while (0)
+    if (pair) {      // digit words -> partial sums per slab -> output
+#define MKT_KSP_LAUNCH_B(WT, BV) do { if (waves == 4) hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 4, BV>), grid, dim3(KS_LANES * 4), ks_lds, s, a, (int)B, ngroups); \
+        else if (waves == 2) hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 2, BV>), grid, dim3(KS_LANES * 2), ks_lds, s, a, (int)B, ngroups); \
+        else hipLaunchKernelGGL((keyswitch_pair_kernel<WT, 32, 1, BV>), grid, dim3(KS_LANES), ks_lds, s, a, (int)B, ngroups); } while (0)
         const dim3 dgrid((unsigned)((a.N + 7) / 8), (unsigned)ngroups, (unsigned)a.kacc);
 #define MKT_KSD_LAUNCH(WT) do { if (a.balanced) hipLaunchKernelGGL((ks_digits_kernel<WT, true>), dgrid, dim3(256), 0, s, a, (int)B, ngroups); \
         else hipLaunchKernelGGL((ks_digits_kernel<WT, false>), dgrid, dim3(256), 0, s, a, (int)B, ngroups); } while (0)
         if (W == 64) {
-            hipLaunchKernelGGL(ks_init_kernel<uint64_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
             MKT_KSD_LAUNCH(uint64_t);
             if (a.balanced) MKT_KSP_LAUNCH_B(uint64_t, true); else MKT_KSP_LAUNCH_B(uint64_t, false);
+            hipLaunchKernelGGL(ks_reduce_kernel<uint64_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B, slabs, parties);
         } else {
-            hipLaunchKernelGGL(ks_init_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B);
             MKT_KSD_LAUNCH(uint32_t);
             if (a.balanced) MKT_KSP_LAUNCH_B(uint32_t, true); else MKT_KSP_LAUNCH_B(uint32_t, false);
+            hipLaunchKernelGGL(ks_reduce_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, B, slabs, parties);
         }
 #undef MKT_KSD_LAUNCH
 #undef MKT_KSP_LAUNCH_B
