@@ -9,7 +9,8 @@ for f in glob.glob(f"{src}/bench_*.json"):
     lines = [l for l in open(f) if l.startswith('{"metric"')]
     if lines:
         open(f"{dst}/{tag}_{os.path.basename(f)}", "w").write("".join(lines))
-for f in glob.glob(f"{src}/trace_{wl}/*/*kernel_stats.csv"):
+newest = lambda files: sorted(files, key=os.path.getmtime)[-1:]          # a directory keeps the files of earlier runs of the round: the last run counts
+for f in newest(glob.glob(f"{src}/trace_{wl}/*/*kernel_stats.csv")):
     shutil.copy(f, f"{dst}/{tag}_bench_{wl}_kernel_stats.csv")
 dirs = sorted(d for d in glob.glob(f"{src}/pmc_{wl}_*") if os.path.basename(d)[len(f"pmc_{wl}_"):] in ("fetch", "write", "clk", "sq1", "sq2"))   # exactly this name's passes (kms2_n1024 must not swallow kms2_n1024_exact)
 if dirs:
@@ -19,7 +20,7 @@ if dirs:
         out.write("# kernel, grid, counter, mean value over the full-work dispatches (within 15 % of the longest of that kernel and grid), mean duration ms, dispatches\n")
         for d in dirs:
             agg = {}
-            for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+            for f in newest(glob.glob(f"{d}/*/*counter_collection.csv")):
                 for r in csv.DictReader(open(f)):
                     k = r["Kernel_Name"]
                     if "mktd" not in k: continue
