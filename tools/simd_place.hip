@@ -12,7 +12,9 @@
 #include <string>
 
 extern __shared__ char smem[];
-__global__ void place(uint32_t *out, int spin) {
+// live: waves of the workgroup that stay (the others leave at once): does a 4-wave launch with two live waves spread better than a 2-wave one?
+__global__ void place(uint32_t *out, int spin, int live) {
+    if ((int)(threadIdx.x / 64) >= live) return;
     uint32_t hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -20,7 +22,7 @@ __global__ void place(uint32_t *out, int spin) {
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
     while ((int64_t)(__builtin_amdgcn_s_memtime() - t0) < spin) __builtin_amdgcn_s_sleep(8);
     if ((threadIdx.x & 63) == 0) {
-        const size_t w = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+        const size_t w = (size_t)blockIdx.x * live + threadIdx.x / 64;
         out[2 * w] = hw; out[2 * w + 1] = xcc;
     }
 }
@@ -28,24 +30,25 @@ __global__ void place(uint32_t *out, int spin) {
 int main() {
     hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, 0);
     const int ncu = pr.multiProcessorCount;
-    for (int waves : {2, 4}) for (int per_cu : {1, 2, 3, 4}) {
+    for (int mode : {0, 1, 2}) for (int per_cu : {1, 2, 3, 4}) {
+        const int waves = mode == 0 ? 2 : 4, live = mode == 2 ? 2 : waves;      // mode 2: four waves launched, two stay
         const int wgs = ncu * per_cu;
         const size_t lds = (size_t)(160 * 1024 / 4) - 512;                     // four workgroups per CU at most
-        uint32_t *d; (void)hipMalloc((void **)&d, (size_t)wgs * waves * 8);
+        uint32_t *d; (void)hipMalloc((void **)&d, (size_t)wgs * live * 8);
         (void)hipFuncSetAttribute((const void *)place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(place, dim3(wgs), dim3(64 * waves), lds, 0, d, 100000);     // 100 MHz counter: 1 ms
+        hipLaunchKernelGGL(place, dim3(wgs), dim3(64 * waves), lds, 0, d, 100000, live);     // 100 MHz counter: 1 ms
         (void)hipDeviceSynchronize();
-        std::vector<uint32_t> h((size_t)wgs * waves * 2);
+        std::vector<uint32_t> h((size_t)wgs * live * 2);
         (void)hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost);
         std::map<uint32_t, std::array<int, 4>> cu;                              // (xcc, se, sh, cu) -> waves per SIMD
-        for (size_t w = 0; w < (size_t)wgs * waves; w++) {
+        for (size_t w = 0; w < (size_t)wgs * live; w++) {
             const uint32_t hw = h[2 * w], xcc = h[2 * w + 1] & 0xf;
             const uint32_t simd = (hw >> 4) & 3, cuid = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
             cu[(xcc << 16) | (se << 8) | (sh << 4) | cuid][simd]++;
         }
         std::map<std::string, int> pat;
         for (auto &kv : cu) { char b[32]; snprintf(b, sizeof b, "%d %d %d %d", kv.second[0], kv.second[1], kv.second[2], kv.second[3]); pat[b]++; }
-        printf("%d-wave workgroups, %d per CU (%d workgroups on %zu CUs seen): waves on SIMD 0 1 2 3 -> CUs:", waves, per_cu, wgs, cu.size());
+        printf("%d-wave workgroups (%d live), %d per CU (%d workgroups on %zu CUs seen): waves on SIMD 0 1 2 3 -> CUs:", waves, live, per_cu, wgs, cu.size());
         for (auto &kv : pat) printf("  [%s] x %d", kv.first.c_str(), kv.second);
         printf("\n");
         (void)hipFree(d);
