@@ -97,3 +97,34 @@ def test_exact_gate_at_full_key_length(require_gpu, p):
     assert np.array_equal(out[0], want)
     assert np.array_equal(mk.lwe_decrypt(out, keys if p.multikey else keys[0], p), GATE_FUNCS[0](bits[:1], bits[1:]))
     sx.close()
+
+
+@pytest.mark.gpu
+def test_wrong_decryptions_of_a_large_kms_batch_are_the_reference_arithmetic(require_gpu):
+    """KMS2partyblock at 16 384 gates on all-party inputs (themselves gate outputs) decrypts a few gates wrongly in the Float64 arithmetic
+    (5 of 16 384 in round 4: 3e-4 per gate, where the Gaussian its sigma predicts gives 5e-6 -- the output noise of the Float64 path on
+    the 64-bit ring is heavier-tailed, and it is the noise of a gate's INPUTS that decides its decryption).  Those are not engine
+    defects: every wrongly decrypting gate (and a sample of the others) is the oracle's output word for word; the same pipeline in the
+    EXACT arithmetic decrypts every gate.  Bounds the Float64 rate at 3x the measured one (bench.py NOISY_SETS)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench as BN
+    p, B = mk.KMS2partyblock, 16384
+    dev = torch.device("cuda", 0)
+    crs, keys, sch = BN.make_scheme(mk, p, 0, True, mk.ARITH_F64REF)
+    bits, x, y = BN.make_inputs(mk, torch, p, keys, sch, B, 0, dev, "mixed")
+    out = mk.NAND(x, y, sch).cpu().numpy().view(np.uint32)
+    want = ~(bits[:B] & bits[B:])
+    wrong = np.flatnonzero(mk.lwe_decrypt(out, keys, p) != want)
+    assert len(wrong) <= BN.allowed_wrong(p.name, B), f"{len(wrong)} wrong decryptions of {B}"
+    pick = np.unique(np.concatenate([wrong, np.arange(0, B, B // 8)]))[:24]
+    so = oracle_scheme(p, crs, keys)
+    xh, yh = x.cpu().numpy().view(np.uint32), y.cpu().numpy().view(np.uint32)
+    assert np.array_equal(out[pick], so.gate_batch(0, xh[pick], yh[pick], threads=min(16, len(pick))))
+    sch.close()
+    Be = 4096
+    _, _, ex = BN.make_scheme(mk, p, 0, False, mk.ARITH_EXACT)
+    be, xe, ye = BN.make_inputs(mk, torch, p, keys, ex, Be, 0, dev, "mixed")
+    oe = mk.NAND(xe, ye, ex).cpu().numpy().view(np.uint32)
+    assert np.array_equal(mk.lwe_decrypt(oe, keys, p), ~(be[:Be] & be[Be:]))
+    ex.close()
