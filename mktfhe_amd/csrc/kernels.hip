@@ -1676,6 +1676,9 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
         // workgroup below that, and at M = 1024 where only two rotations fit and run 15 % slower)
         int G = a.blk_group;
         if (G == 0) G = (blockg_supported(logM, 4) && logM == 9 && nrot >= 1024) ? ((W == 32 && nrot >= 4096) ? 2 : 4) : 1;   // from 4096 rotations two rotations per workgroup, two workgroups per CU: 204 k against 196 k gates/s (Blockparam, 8192 and 16 384 gates)
+        // 257..512 rotations: one 4-wave workgroup of two rotations per CU instead of two 2-wave workgroups, which share a SIMD pair
+        // (tools/simd_place.hip): Blockparam 384 / 512 gates 4.51 -> 3.90 ms; up to 256 and from 513 to 1023 one rotation per workgroup is ahead
+        if (a.blk_group == 0 && W == 32 && logM == 9 && nrot > 256 && nrot <= 512 && blockg_supported(logM, 2)) G = 2;
         if (G > 1 && blockg_supported(logM, G) && a.blk_len >= 2 && a.blk_len <= 4) {
             const size_t nslots = (size_t)a.rows_per_gate;
             const hipError_t e = W == 64 ? launch_rot_blockg_u64(logM, G, 2, a, nslots, s) : launch_rot_blockg_u32(logM, G, 2, a, nslots, s);
