@@ -1274,12 +1274,15 @@ __global__ __launch_bounds__(256) void ks_digits_kernel(const KsArgs a, int B, i
     a.digits[(((size_t)c * ngroups + grp) * a.N + j) * 32 + g] = BAL ? gb.prep(w) : divbits<uint32_t>(w, 32 - a.f * 2);
 }
 
-// Digit pairs (D = 4, f even: every shipped set has f = 8).  The staged table holds the 16 sums row(d1, td) + row(d2, td+1)
-// of two consecutive digits, so a ciphertext takes ONE ds_read_b128 and four adds per pair of digits: the loop above is bound
-// by LDS bandwidth (one 1 KiB read per ciphertext, coefficient, digit and column chunk), and this halves it; the 16 sums cost
-// a wave four row loads and twelve adds per pair whatever the number of ciphertexts.  The index is the raw 4-bit field of the
-// prepared word for both digit kinds (balanced digits: the sign lives in the table), and wrap-around addition is associative,
-// so the result is the same word for word.
+// Digit pairs (D = 4, f even: every shipped set has f = 8) -- the key switch of those sets.  Same tiling as the per-digit kernel above
+// (a wave = 32 ciphertexts x a slab of coefficients x a 256-word column chunk, sums in registers, rows through a lane-private LDS
+// table), but the staged table holds the 16 sums row(d1, td) + row(d2, td+1) of two consecutive digits, built by the waves that
+// share it (four row loads, twelve adds, four ds_write_b128 per wave and pair): ONE ds_read_b128 and four adds per ciphertext and
+// PAIR of digits.  The index is the raw 4-bit field of the prepared word for both digit kinds (balanced digits: the sign lives in
+// the table).  The digit words come prepared (ks_digits_kernel: two s_load_dwordx16 per coefficient), the sums leave as plain
+// stores into per-slab partial rows (ks_reduce_kernel adds them: no atomics), and the slabs cut only the coefficients that are
+// switched.  Wrap-around addition is associative and commutative, so every grouping gives the per-digit kernel's words.
+// 168 VGPRs (three 4-wave workgroups per CU: the launch is sized for exactly one such round), table reads four at a time.
 #ifndef MKT_KSP_BATCH
 #define MKT_KSP_BATCH 4
 #endif
@@ -1335,7 +1338,6 @@ __global__ __launch_bounds__(KS_LANES * WAVES, MKT_KSP_OCC) void keyswitch_pair_
             for (int td = 0; td < f; td += 2) {
                 const int st = (it++) & (KS_STAGES - 1);
                 const int shift = 2 * (f - 2 - td);
-                // second digit: values 0, 1, 2, 3 (rows 1..3) or -2, -1, 0, 1 (balanced: rows 2, 1 negated, nothing, row 1)
                 // second digit: values 0, 1, 2, 3 (rows 1..3) or -2, -1, 0, 1 (balanced: rows 2, 1 negated, nothing, row 1)
                 uint4 r2[BAL ? 2 : 3];
 #pragma unroll
