@@ -839,6 +839,23 @@ def test_latency_variant_of_the_rotation_is_bit_identical(require_gpu, p, monkey
     sg.close()
 
 
+@pytest.mark.parametrize("p", [mk.CGGIparam, mk.Blockparam_k2, mk.KMS2partyblock, mk.CCS2party], ids=lambda p: p.name)
+def test_keyswitch_at_full_key_length_over_batch_sizes(require_gpu, p):
+    """keyswitch! (bootstrapping.jl:81-109, :170-229, :333-364, :664-695) alone, on random accumulators, at the shipped key lengths and at
+    batch sizes that leave ragged groups of 32 ciphertexts, one or many slabs and partly filled column chunks in the digit-pair kernel
+    (digit words -> per-slab partial sums -> reduce): first, last and random ciphertexts of every batch equal the oracle's output."""
+    crs, keys = keygen(p, 81)
+    so = oracle_scheme(p, crs, keys)
+    sg = gpu_scheme(p, crs, keys)
+    rng = np.random.default_rng(82)
+    for B in (1, 33, 257, 1000, 2049):
+        acc = rng.integers(0, 2**p.W, (B, 1 + p.k, p.N), dtype=np.uint64)
+        out = sg.keyswitch(acc.astype(p.ring_dtype))
+        for j in sorted({0, B - 1, *rng.integers(0, B, 6).tolist()}):
+            assert np.array_equal(out[j], so.keyswitch(acc[j])), (B, j)
+    sg.close()
+
+
 @pytest.mark.parametrize("name,B", [("CGGIparam", 1024 + 100), ("CGGIparam", 1024 + 400), ("CGGIparam", 2048 + 300),
                                      ("KMS2party_N1024_l2", 375), ("KMS2party_N1024_l2", 475), ("KMS2party_N1024_l2", 1125)])
 def test_rotation_launch_plans_agree(require_gpu, name, B):
