@@ -141,16 +141,26 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 __host__ __device__ constexpr int ntt_pos(int i) { return MKT_NTT_LAYOUT ? i + 2 * (i >> 4) : (i ^ ((i >> 3) & 15)); }
 __host__ __device__ constexpr int ntt_join(int base, int off) { return MKT_NTT_LAYOUT ? base + off : (base ^ off); }
 template <int LOGN> struct NttLds { static constexpr int WORDS = MKT_NTT_LAYOUT ? ntt_pos(1 << LOGN) : (1 << LOGN); };   // 64-bit words of one polynomial's staging buffer
-template <int LOGN>
-__device__ __forceinline__ void ntt_exchange(Pt (&z)[8], uint64_t *lds, int t, int lo_from, int lo_to) {
-    __syncthreads();
-    const int wr = ntt_pos(pt_index<NLR>(t, 0, lo_from));
+// Which exchanges cross waves: thread bit j holds point bit j (j < lo) or j + 3 (j >= lo), so with both windows at lo <= 6 every wave bit
+// (j >= 6) keeps its point bit (j + 3 >= 9, above the swizzled bits): the exchange moves points between the lanes of ONE wave, inside that
+// wave's own part of the staging buffer, and needs no barrier -- a wave's LDS operations complete in order.  At N = 1024 .. 4096 that is
+// two of a transform's three exchanges.  What remains: a cross-wave exchange keeps its two barriers, and the first wave-private one
+// behind a cross-wave one (LEAD) opens with a barrier, so that no wave overwrites its part while another still reads it: 3 barriers per
+// transform instead of 6 (MKT_NTT_XPRIV=0: all six).  Single-wave workgroups keep the plain form (their barriers cost nothing).
+#ifndef MKT_NTT_XPRIV
+#define MKT_NTT_XPRIV 1
+#endif
+template <int LOGN, int LO_FROM, int LO_TO, bool LEAD = true>
+__device__ __forceinline__ void ntt_exchange(Pt (&z)[8], uint64_t *lds, int t) {
+    constexpr bool priv = MKT_NTT_XPRIV && LOGN - NLR > 6 && LO_FROM <= 6 && LO_TO <= 6;
+    if (!priv || LEAD) __syncthreads();
+    const int wr = ntt_pos(pt_index<NLR>(t, 0, LO_FROM));
 #pragma unroll
-    for (int e = 0; e < 8; e++) lds[ntt_join(wr, ntt_pos(e << lo_from))] = pack(z[e]);
-    __syncthreads();
-    const int rd = ntt_pos(pt_index<NLR>(t, 0, lo_to));
+    for (int e = 0; e < 8; e++) lds[ntt_join(wr, ntt_pos(e << LO_FROM))] = pack(z[e]);
+    if (!priv) __syncthreads();
+    const int rd = ntt_pos(pt_index<NLR>(t, 0, LO_TO));
 #pragma unroll
-    for (int e = 0; e < 8; e++) z[e] = unpack(lds[ntt_join(rd, ntt_pos(e << lo_to))]);
+    for (int e = 0; e < 8; e++) z[e] = unpack(lds[ntt_join(rd, ntt_pos(e << LO_TO))]);
 }
 
 // In: slot e = point e*NT + t; slots 0..3 in [0, 2P), slots 4..7 any 32-bit value (fwd_in, res_small).  Out: slot e = point 8t + e (bit-reversed
@@ -177,7 +187,7 @@ __device__ __forceinline__ void ntt_forward(Pt (&z)[8], const uint4 *__restrict_
         }
     }
     if constexpr (p < P::NPASS - 1) {
-        ntt_exchange<LOGN>(z, lds, t, P::lo(p), P::lo(p + 1));
+        ntt_exchange<LOGN, P::lo(p), P::lo(p + 1), (p <= 1)>(z, lds, t);      // the exchange behind pass 0 crosses waves; LEAD for the one after it
         ntt_forward<LOGN, PASS + 1>(z, psi, lds, t);
     }
 }
@@ -208,7 +218,7 @@ __device__ __forceinline__ void ntt_inverse(Pt (&z)[8], const uint4 *__restrict_
         }
     }
     if constexpr (p > 0) {
-        ntt_exchange<LOGN>(z, lds, t, P::lo(p), P::lo(p - 1));
+        ntt_exchange<LOGN, P::lo(p), P::lo(p - 1), (p == P::NPASS - 1)>(z, lds, t);   // an inverse opens behind whatever used the buffer last: LEAD
         ntt_inverse<LOGN, PASS - 1>(z, psiinv, lds, t, sc);
     }
 }
@@ -323,7 +333,7 @@ __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_fwd_kernel
 #pragma unroll
             for (int e = 0; e < 8; e++) z[e] = pt_canon4(z[e]);
         }
-        ntt_exchange<LOGN>(z, lds, t, 0, Plan<LOGN, NLR>::lo(0));        // thread-contiguous stores: point e*NT + t of the output order
+        ntt_exchange<LOGN, 0, Plan<LOGN, NLR>::lo(0)>(z, lds, t);        // thread-contiguous stores: point e*NT + t of the output order
 #pragma unroll
         for (int e = 0; e < 8; e++) __builtin_nontemporal_store(pack(z[e]), &out[b * N + e * NT + t]);
     }
@@ -355,7 +365,7 @@ __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_inv_kernel
 #pragma unroll
             for (int e = 0; e < 8; e++) nxt[e] = __builtin_nontemporal_load(&in[bn * N + e * NT + t]);
         }
-        ntt_exchange<LOGN>(z, lds, t, Plan<LOGN, NLR>::lo(0), 0);
+        ntt_exchange<LOGN, Plan<LOGN, NLR>::lo(0), 0>(z, lds, t);
         ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(z, tw[0], lds, t, k.ninv);
 #pragma unroll
         for (int e = 0; e < 8; e++) __builtin_nontemporal_store((WORD)crt_signed(z[e]), &p[b * N + e * NT + t]);
