@@ -504,6 +504,9 @@ __device__ __forceinline__ double word_to_f64(WORD x) { return (double)(typename
 #ifndef MKT_NATIVE_MAGIC
 #define MKT_NATIVE_MAGIC 1
 #endif
+#ifndef MKT_NATIVE_CARRY
+#define MKT_NATIVE_CARRY 1
+#endif
 __device__ __forceinline__ uint32_t low_dword_of_sum_2p52(double v) {
     const double s = v + 4503599627370496.0;   // 2^52
     return (uint32_t)__double2loint(s);
@@ -525,6 +528,24 @@ template <> __device__ __forceinline__ uint64_t native<uint64_t>(double x) {
     return ((uint64_t)low_dword_of_sum_2p52(hi) << 32) | (uint64_t)low_dword_of_sum_2p52(lo);
 #else
     return x == 1.8446744073709552e19 ? (uint64_t)0 : (uint64_t)x;
+#endif
+}
+
+// acc + native(x) mod 2^W.  64-bit ring: the two 32-bit halves of native(x) are added with a carry (v_add_co_u32, v_addc_co_u32) instead of
+// being joined into a register pair first (two v_mov and two 64-bit adds per coefficient in the rotation kernels' CMux)
+template <typename WORD> __device__ __forceinline__ WORD native_add(WORD acc, double x);
+template <> __device__ __forceinline__ uint32_t native_add<uint32_t>(uint32_t acc, double x) { return acc + native<uint32_t>(x); }
+template <> __device__ __forceinline__ uint64_t native_add<uint64_t>(uint64_t acc, double x) {
+#if MKT_NATIVE_MAGIC && MKT_NATIVE_CARRY
+    x -= floor(x * 5.421010862427522e-20) * 1.8446744073709552e19;
+    const double hi = trunc(x * 2.3283064365386963e-10);
+    const double lo = trunc(x - hi * 4.294967296e9);
+    const uint32_t h = low_dword_of_sum_2p52(hi), l = low_dword_of_sum_2p52(lo);
+    const uint32_t al = (uint32_t)acc, s = al + l;
+    const uint32_t ah = (uint32_t)(acc >> 32) + h + (s < l ? 1u : 0u);
+    return ((uint64_t)ah << 32) | s;
+#else
+    return acc + native<uint64_t>(x);
 #endif
 }
 

@@ -460,8 +460,8 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
             for (int c = 0; c < 2; c++) {                                // fft.jl:76-80 untwist + native; :73 add!
                 const cplx v = cmul(t2[c][e], ri);
-                acc[c][e][0] = (WORD)(acc[c][e][0] + native<WORD>(v.re));
-                acc[c][e][1] = (WORD)(acc[c][e][1] + native<WORD>(-v.im));
+                acc[c][e][0] = native_add<WORD>(acc[c][e][0], v.re);
+                acc[c][e][1] = native_add<WORD>(acc[c][e][1], -v.im);
             }
         }
     }
