@@ -57,7 +57,7 @@ const mktd::LaunchTuning &mktd::launch_tuning() {
     static const LaunchTuning t = [] {
         LaunchTuning q{};
         q.fft_grid = env_int("MKT_FFT_GRID", 0); q.fft_nb = env_int("MKT_FFT_NB", 1); q.fft_igrid = env_int("MKT_FFT_IGRID", 0);
-        q.ks_g = env_int("MKT_KS_G", 32); q.ks_blocks = env_int("MKT_KS_BLOCKS", 0); q.ks_waves = env_int("MKT_KS_WAVES", 0); q.ks_pair = env_int("MKT_KS_PAIR", -1);
+        q.ks_g = env_int("MKT_KS_G", 32); q.ks_blocks = env_int("MKT_KS_BLOCKS", 0); q.ks_waves = env_int("MKT_KS_WAVES", 0); q.ks_pair = env_int("MKT_KS_PAIR", -1); q.ntt_grid = env_int("MKT_NTT_GRID", 0);
         return q;
     }();
     return t;

@@ -12,7 +12,7 @@ struct TwPtrs { const cplx *psi, *psiinv, *roots, *rootsinv; };
 
 // Launcher-level A/B switches (grid shapes of the transform and key-switch kernels): process-wide, read from the
 // environment on FIRST USE only -- the call path never calls getenv (context.cpp).  0 = the built-in default.
-struct LaunchTuning { int fft_grid, fft_nb, fft_igrid, ks_g, ks_blocks, ks_waves, ks_pair; };
+struct LaunchTuning { int fft_grid, fft_nb, fft_igrid, ks_g, ks_blocks, ks_waves, ks_pair, ntt_grid; };
 const LaunchTuning &launch_tuning();
 // base name of the blind-rotation kernel the calling thread launched last (set by every rotation launcher; read by
 // mkt_last_kernel_name so that bench.py's roofline names the kernel that actually ran)

@@ -1437,7 +1437,9 @@ hipError_t launch_transform_fwd(int logM, int W, TwPtrs tw, const void *p, cplx 
     // swept on MI355X (tools/fft_sweep.py): with nontemporal streams many short-lived workgroups (8-16 polynomials each
     // at a 4 GiB batch) beat few long-lived ones, as a flat copy beats a grid-stride one on this part (tools/membench2.hip)
     const LaunchTuning &lt = launch_tuning();
-    const int gmax = lt.fft_grid > 0 ? lt.fft_grid : 32768, nbt = lt.fft_nb;
+    // N = 2048 (round 4, tools/fft_w64_sweep.sh / fft_w32_sweep.sh): a cap of 2048 .. 16 384 workgroups is 3-5 % ahead of 32 768 on both rings
+    // (64-bit: forward 0.619 -> 0.636, inverse 0.630 -> 0.649 of 8 TB/s); N = 1024 keeps the many short-lived workgroups (0.683 vs 0.585)
+    const int gmax = lt.fft_grid > 0 ? lt.fft_grid : (logM >= 10 ? 4096 : 32768), nbt = lt.fft_nb;
     MKT_DISPATCH_LOGM(logM, {
         if (nbt == 2 && LM <= 10) {
             if (W == 64) return launch_fwd_one<LM, uint64_t, 2>(tw, p, t, B, dev_order, gmax, s);
@@ -1459,7 +1461,7 @@ hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, in
 
 hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void *p, size_t B, hipStream_t s) {
     if (B == 0) return hipSuccess;
-    const size_t gmax = launch_tuning().fft_igrid > 0 ? (size_t)launch_tuning().fft_igrid : 32768;
+    const size_t gmax = launch_tuning().fft_igrid > 0 ? (size_t)launch_tuning().fft_igrid : (logM >= 10 ? 4096 : 32768);   // as the forward launch
     const int grid = (int)(B < gmax ? B : gmax);
     MKT_DISPATCH_LOGM(logM, {
         using P = Plan<LM, LOGR>;
