@@ -79,7 +79,7 @@ struct KeySet {
     // rotation slots (KMS phase 1: party-major rows)
     int rtot = 1;
     int *d_slot_party = nullptr, *d_slot_row = nullptr;
-    uint64_t *d_ntt = nullptr;   // MKT_ARITH_EXACT: psi_rev (negated) | psiinv_rev | N^-1, N^-1 w | N^-1 2^32, N^-1 2^32 w, with Shoup companions
+    uint64_t *d_ntt = nullptr;   // MKT_ARITH_EXACT: psi_rev (negated) | N^-1, N^-1 w | N^-1 2^32, N^-1 2^32 w, with Shoup companions
     ~KeySet() {
         int prev = -1;
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
@@ -424,11 +424,11 @@ uint32_t ntt_mulmod(uint32_t a, uint32_t b, uint32_t p) { return (uint32_t)((uin
 uint32_t ntt_powmod(uint32_t a, uint64_t e, uint32_t p) { uint32_t r = 1; while (e) { if (e & 1) r = ntt_mulmod(r, a, p); a = ntt_mulmod(a, a, p); e >>= 1; } return r; }
 uint32_t ntt_shoup(uint32_t w, uint32_t p) { return (uint32_t)(((uint64_t)w << 32) / p); }
 
-// per point (w mod p1, companion, w mod p2, companion; the forward table holds 2^32 - w): psi_rev[N] | psiinv_rev[N] | N^-1, N^-1 w | N^-1 2^32, N^-1 2^32 w, for the transform of
-// size N; psi = g^((p - 1) / 2N) with g the smallest quadratic non-residue of p (so psi^N = -1: a primitive 2N-th root of unity)
+// per point (w mod p1, companion, w mod p2, companion; the table holds 2^32 - w): psi_rev[N] | N^-1, N^-1 w | N^-1 2^32, N^-1 2^32 w, for the transform of
+// size N (no inverse table: psiinv_rev[m + i] = -psi_rev[2m - 1 - i], which the inverse butterflies read off the forward table, ntt_exact.hip bfly_inv); psi = g^((p - 1) / 2N) with g the smallest quadratic non-residue of p (so psi^N = -1: a primitive 2N-th root of unity)
 int upload_ntt_tables(mkt_ctx *c) {
     const int N = c->p.N, logN = c->logN;
-    std::vector<uint32_t> tab((size_t)(2 * N + 4) * 4);
+    std::vector<uint32_t> tab((size_t)(N + 4) * 4);
     for (int k = 0; k < 2; k++) {
         const uint32_t p = NTT_P[k];
         uint32_t g = 2;
@@ -438,15 +438,14 @@ int upload_ntt_tables(mkt_ctx *c) {
         for (int i = 0; i < N; i++) {
             int r = 0;
             for (int b = 0; b < logN; b++) r |= ((i >> b) & 1) << (logN - 1 - b);
-            const uint32_t w = ntt_powmod(psi, (uint64_t)r, p), wi = ntt_powmod(psiinv, (uint64_t)r, p);
-            tab[(size_t)i * 4 + 2 * k] = 0u - w; tab[(size_t)i * 4 + 2 * k + 1] = ntt_shoup(w, p);   // forward table: the NEGATED twiddle (ntt_exact.hip bfly_fwd)
-            tab[((size_t)N + i) * 4 + 2 * k] = wi; tab[((size_t)N + i) * 4 + 2 * k + 1] = ntt_shoup(wi, p);
+            const uint32_t w = ntt_powmod(psi, (uint64_t)r, p);
+            tab[(size_t)i * 4 + 2 * k] = 0u - w; tab[(size_t)i * 4 + 2 * k + 1] = ntt_shoup(w, p);   // the NEGATED twiddle (ntt_exact.hip bfly_fwd, bfly_inv)
         }
         // N^-1 and N^-1 2^32, each followed by its product with the one twiddle of the inverse's last stage (psiinv_rev[1])
         const uint32_t ninv = ntt_powmod((uint32_t)N, p - 2, p), ninv_r = (uint32_t)(((uint64_t)ninv << 32) % p);
         const uint32_t wlast = ntt_powmod(psiinv, (uint64_t)N / 2, p);                    // bitrev(1) = N / 2
         const uint32_t cs[4] = {ninv, ntt_mulmod(ninv, wlast, p), ninv_r, ntt_mulmod(ninv_r, wlast, p)};
-        for (int q = 0; q < 4; q++) { tab[(size_t)(2 * N + q) * 4 + 2 * k] = cs[q]; tab[(size_t)(2 * N + q) * 4 + 2 * k + 1] = ntt_shoup(cs[q], p); }
+        for (int q = 0; q < 4; q++) { tab[(size_t)(N + q) * 4 + 2 * k] = cs[q]; tab[(size_t)(N + q) * 4 + 2 * k + 1] = ntt_shoup(cs[q], p); }
     }
     HIPCHK(c, hipMalloc((void **)&c->ks->d_ntt, tab.size() * 4));
     c->d_ntt = c->ks->d_ntt;

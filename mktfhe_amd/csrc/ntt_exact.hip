@@ -119,11 +119,15 @@ template <uint32_t P> __device__ __forceinline__ void bfly_inv_scaled(uint32_t &
     const uint32_t s = x + y, d = x - y + 2u * P;
     x = shoup<P>(s, c, cs); y = shoup<P>(d, cw, cws);
 }
-// inverse (Gentleman-Sande): x, y in [0, 2P) -> x + y, w (x - y) in [0, 2P)
-template <uint32_t P> __device__ __forceinline__ void bfly_inv(uint32_t &x, uint32_t &y, uint32_t w, uint32_t ws) {
+// inverse (Gentleman-Sande): x, y in [0, 2P] -> x + y, winv (x - y) in [0, 2P] (closed: every consumer takes 2P -- sums stay <= 4P < 2^32,
+// Shoup products take any 32-bit value).  There is NO inverse table: in bit-reversed order psiinv_rev[m + i] = -psi_rev[m + (m - 1 - i)]
+// mod p (psi^N = -1), so the inverse reads the FORWARD table's mirrored entry (nw = 2^32 - w, the companion ws of w) and multiplies by
+// p - w:  with r = d w - floor(d ws / 2^32) p in [0, 2P) (Shoup),  (p - w) d = -r = 2P - r mod p, and 2P - r = (d nw + 2P) + q p mod 2^32 --
+// two multiply-adds and a v_mul_hi, the count of the table-driven form, and a workgroup stages one table instead of two.
+template <uint32_t P> __device__ __forceinline__ void bfly_inv(uint32_t &x, uint32_t &y, uint32_t nw, uint32_t ws) {
     const uint32_t s = x + y, d = x - y + 2u * P, v = s - 2u * P;
     x = umin32(s, v);
-    y = d * w - __umulhi(d, ws) * P;
+    y = __umulhi(d, ws) * P + (d * nw + 2u * P);
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
@@ -150,78 +154,123 @@ template <int LOGN> struct NttLds { static constexpr int WORDS = MKT_NTT_LAYOUT 
 #ifndef MKT_NTT_XPRIV
 #define MKT_NTT_XPRIV 1
 #endif
-template <int LOGN, int LO_FROM, int LO_TO, bool LEAD = true>
-__device__ __forceinline__ void ntt_exchange(Pt (&z)[8], uint64_t *lds, int t) {
+// LEAN: the thread index is laundered through an empty asm so that the slot addresses (functions of t alone) are NOT hoisted out of the
+// caller's loop: in a register-capped kernel (three waves per SIMD: 168) the ~50 hoisted addresses are spilled and reloaded from
+// scratch at every use; recomputed they are one v_xor each
+#ifndef MKT_LEAN_FINE
+#define MKT_LEAN_FINE 0
+#endif
+// development only: timing builds with parts of the work removed (WRONG results) -- 1: no exchanges through LDS, 2: no key-row loads,
+// 4: no twiddle reads, 8: no rotation through LDS (tools/ntt_variant.sh; profiles/r05_experiments.txt)
+#ifndef MKT_ABLATE
+#define MKT_ABLATE 0
+#endif
+__device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
+// NB transforms side by side (the pair of digit polynomials of one accumulator; the low and the high half of one lifted sum) go through
+// the passes together: ONE set of twiddle reads, slot addresses and barriers for NB x the butterflies, and every wait on an exchange or a
+// twiddle read is covered by the other transform's arithmetic (what the Float64 rotation kernel's NB = 2 does: fft_device.h).  Transform b
+// stages in its own buffer, lds + b * NttLds<LOGN>::WORDS.
+template <int LOGN, int LO_FROM, int LO_TO, bool LEAD = true, bool LEAN = false, int NB = 1>
+__device__ __forceinline__ void ntt_exchange_n(Pt (&z)[NB][8], uint64_t *lds, int t) {
+    if (LEAN && MKT_LEAN_FINE) t = launder(t);
+    if (MKT_ABLATE & 1) return;
     constexpr bool priv = MKT_NTT_XPRIV && LOGN - NLR > 6 && LO_FROM <= 6 && LO_TO <= 6;
+    // the callers' LEAD rule (the exchange behind pass 0 crosses waves, the others stay in the wave) holds for 64-lane waves and N <= 4096:
+    // at N = 8192 the exchange behind pass 1 (lo 7 -> 4) would cross waves too
+    static_assert(!priv || LOGN <= 12, "wave-private exchanges: N <= 4096 (and 64-lane waves: gfx950 has no other)");
     if (!priv || LEAD) __syncthreads();
-    const int wr = ntt_pos(pt_index<NLR>(t, 0, LO_FROM));
+    // byte offsets, so that the XOR that joins a thread's base slot with point e's constant IS the address arithmetic (one v_xor per
+    // access; as element indices each access paid a shift-add on top wherever the addresses are not hoisted)
+    char *const lb = reinterpret_cast<char *>(lds);
+    const int wr = ntt_pos(pt_index<NLR>(t, 0, LO_FROM)) * 8;
 #pragma unroll
-    for (int e = 0; e < 8; e++) lds[ntt_join(wr, ntt_pos(e << LO_FROM))] = pack(z[e]);
+    for (int e = 0; e < 8; e++)
+#pragma unroll
+        for (int b = 0; b < NB; b++) *reinterpret_cast<uint64_t *>(lb + b * NttLds<LOGN>::WORDS * 8 + ntt_join(wr, ntt_pos(e << LO_FROM) * 8)) = pack(z[b][e]);
     if (!priv) __syncthreads();
-    const int rd = ntt_pos(pt_index<NLR>(t, 0, LO_TO));
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }   // compiler-level order only: the reads below stay below the writes above (a wave's LDS operations complete in order)
+    const int rd = ntt_pos(pt_index<NLR>(t, 0, LO_TO)) * 8;
 #pragma unroll
-    for (int e = 0; e < 8; e++) z[e] = unpack(lds[ntt_join(rd, ntt_pos(e << LO_TO))]);
+    for (int e = 0; e < 8; e++)
+#pragma unroll
+        for (int b = 0; b < NB; b++) z[b][e] = unpack(*reinterpret_cast<const uint64_t *>(lb + b * NttLds<LOGN>::WORDS * 8 + ntt_join(rd, ntt_pos(e << LO_TO) * 8)));
 }
+template <int LOGN, int LO_FROM, int LO_TO, bool LEAD = true, bool LEAN = false>
+__device__ __forceinline__ void ntt_exchange(Pt (&z)[8], uint64_t *lds, int t) { ntt_exchange_n<LOGN, LO_FROM, LO_TO, LEAD, LEAN, 1>(reinterpret_cast<Pt(&)[1][8]>(z), lds, t); }
 
 // In: slot e = point e*NT + t; slots 0..3 in [0, 2P), slots 4..7 any 32-bit value (fwd_in, res_small).  Out: slot e = point 8t + e (bit-reversed
 // order of the transform, as the reference's), values LAZY in [0, 4P): fine as the x of montmul and of shoup; pt_canon4
 // where the canonical residue is needed.
 // psi[k] = (-w mod p1 as 2^32 - w, the companion of w, the same mod p2), w = psi^bitrev(k)
-template <int LOGN, int PASS = 0>
-__device__ __forceinline__ void ntt_forward(Pt (&z)[8], const uint4 *__restrict__ psi, uint64_t *lds, int t) {
+template <int LOGN, int PASS = 0, bool LEAN = false, int NB = 1>
+__device__ __forceinline__ void ntt_forward_n(Pt (&z)[NB][8], const uint4 *__restrict__ psi, uint64_t *lds, int t) {
     using P = Plan<LOGN, NLR>;
     constexpr int p = PASS, lo = P::lo(p);
+    if (LEAN && (MKT_LEAN_FINE || p == 0)) t = launder(t);
 #pragma unroll
     for (int s = 0; s < P::nst(p); s++) {
         const int b = P::hib(p) - s, sb = b - lo;
         const int twbase = (1 << (LOGN - 1 - b)) + ((t >> lo) << (NLR - 1 - sb));
 #pragma unroll
         for (int g = 0; g < (1 << (NLR - 1 - sb)); g++) {
-            const uint4 w = psi[twbase + g];
+            const uint4 w = (MKT_ABLATE & 4) ? make_uint4(twbase * 0x9E3779B1u + g, twbase + 77u * g, twbase * 0x85EBCA6Bu + g, twbase + 99u * g) : psi[twbase + g];
 #pragma unroll
             for (int q = 0; q < (1 << sb); q++) {
                 const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
-                bfly_fwd<P1>(z[e].a, z[e2].a, w.x, w.y, p == 0 && s == 0);
-                bfly_fwd<P2>(z[e].b, z[e2].b, w.z, w.w, p == 0 && s == 0);
+#pragma unroll
+                for (int h = 0; h < NB; h++) {
+                    bfly_fwd<P1>(z[h][e].a, z[h][e2].a, w.x, w.y, p == 0 && s == 0);
+                    bfly_fwd<P2>(z[h][e].b, z[h][e2].b, w.z, w.w, p == 0 && s == 0);
+                }
             }
         }
     }
     if constexpr (p < P::NPASS - 1) {
-        ntt_exchange<LOGN, P::lo(p), P::lo(p + 1), (p <= 1)>(z, lds, t);      // the exchange behind pass 0 crosses waves; LEAD for the one after it
-        ntt_forward<LOGN, PASS + 1>(z, psi, lds, t);
+        ntt_exchange_n<LOGN, P::lo(p), P::lo(p + 1), (p <= 1), LEAN, NB>(z, lds, t);      // the exchange behind pass 0 crosses waves; LEAD for the one after it
+        ntt_forward_n<LOGN, PASS + 1, LEAN, NB>(z, psi, lds, t);
     }
 }
-// In: slot e = point 8t + e, values in [0, 2P).  Out: slot e = point e*NT + t, scaled by the constant sc[0] (N^-1 or N^-1 2^32;
-// sc[1] = sc[0] * psiinv[1]: the last stage has ONE twiddle, so the scale rides on its two products), values in [0, P)
-template <int LOGN, int PASS>
-__device__ __forceinline__ void ntt_inverse(Pt (&z)[8], const uint4 *__restrict__ psiinv, uint64_t *lds, int t, const uint4 (&sc)[2]) {
+template <int LOGN, int PASS = 0, bool LEAN = false>
+__device__ __forceinline__ void ntt_forward(Pt (&z)[8], const uint4 *__restrict__ psi, uint64_t *lds, int t) { ntt_forward_n<LOGN, PASS, LEAN, 1>(reinterpret_cast<Pt(&)[1][8]>(z), psi, lds, t); }
+// In: slot e = point 8t + e, values in [0, 2P].  Out: slot e = point e*NT + t, scaled by the constant sc[0] (N^-1 or N^-1 2^32;
+// sc[1] = sc[0] * psiinv[1]: the last stage has ONE twiddle, so the scale rides on its two products), values in [0, P).
+// psi: the FORWARD table (bfly_inv)
+template <int LOGN, int PASS, bool LEAN = false, int NB = 1>
+__device__ __forceinline__ void ntt_inverse_n(Pt (&z)[NB][8], const uint4 *__restrict__ psi, uint64_t *lds, int t, const uint4 (&sc)[2]) {
     using P = Plan<LOGN, NLR>;
     constexpr int p = PASS, lo = P::lo(p);
+    if (LEAN && (MKT_LEAN_FINE || p == P::NPASS - 1)) t = launder(t);
 #pragma unroll
     for (int s = P::nst(p) - 1; s >= 0; s--) {
         const int b = P::hib(p) - s, sb = b - lo;
-        const int twbase = (1 << (LOGN - 1 - b)) + ((t >> lo) << (NLR - 1 - sb));
+        const int twtop = (2 << (LOGN - 1 - b)) - 1 - ((t >> lo) << (NLR - 1 - sb));      // psiinv_rev[m + i] = -psi_rev[2m - 1 - i] (bfly_inv)
 #pragma unroll
         for (int g = 0; g < (1 << (NLR - 1 - sb)); g++) {
-            const uint4 w = psiinv[twbase + g];
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (!(p == 0 && s == 0)) w = (MKT_ABLATE & 4) ? make_uint4(twtop * 0x9E3779B1u + g, twtop + 77u * g, twtop * 0x85EBCA6Bu + g, twtop + 99u * g) : psi[twtop - g];
 #pragma unroll
             for (int q = 0; q < (1 << sb); q++) {
                 const int e = (g << (sb + 1)) | q, e2 = e | (1 << sb);
-                if (p == 0 && s == 0) {
-                    bfly_inv_scaled<P1>(z[e].a, z[e2].a, sc[0].x, sc[0].y, sc[1].x, sc[1].y);
-                    bfly_inv_scaled<P2>(z[e].b, z[e2].b, sc[0].z, sc[0].w, sc[1].z, sc[1].w);
-                } else {
-                    bfly_inv<P1>(z[e].a, z[e2].a, w.x, w.y);
-                    bfly_inv<P2>(z[e].b, z[e2].b, w.z, w.w);
+#pragma unroll
+                for (int h = 0; h < NB; h++) {
+                    if (p == 0 && s == 0) {
+                        bfly_inv_scaled<P1>(z[h][e].a, z[h][e2].a, sc[0].x, sc[0].y, sc[1].x, sc[1].y);
+                        bfly_inv_scaled<P2>(z[h][e].b, z[h][e2].b, sc[0].z, sc[0].w, sc[1].z, sc[1].w);
+                    } else {
+                        bfly_inv<P1>(z[h][e].a, z[h][e2].a, w.x, w.y);
+                        bfly_inv<P2>(z[h][e].b, z[h][e2].b, w.z, w.w);
+                    }
                 }
             }
         }
     }
     if constexpr (p > 0) {
-        ntt_exchange<LOGN, P::lo(p), P::lo(p - 1), (p == P::NPASS - 1)>(z, lds, t);   // an inverse opens behind whatever used the buffer last: LEAD
-        ntt_inverse<LOGN, PASS - 1>(z, psiinv, lds, t, sc);
+        ntt_exchange_n<LOGN, P::lo(p), P::lo(p - 1), (p == P::NPASS - 1), LEAN, NB>(z, lds, t);   // an inverse opens behind whatever used the buffer last: LEAD
+        ntt_inverse_n<LOGN, PASS - 1, LEAN, NB>(z, psi, lds, t, sc);
     }
 }
+template <int LOGN, int PASS, bool LEAN = false>
+__device__ __forceinline__ void ntt_inverse(Pt (&z)[8], const uint4 *__restrict__ psi, uint64_t *lds, int t, const uint4 (&sc)[2]) { ntt_inverse_n<LOGN, PASS, LEAN, 1>(reinterpret_cast<Pt(&)[1][8]>(z), psi, lds, t, sc); }
 
 // Inputs of ntt_forward.  Slot e < 4 is the x of a first-stage butterfly and must be below 2P; slot e >= 4 is its y, which the
 // Shoup product takes as ANY 32-bit value congruent to the point: conversions stop as early as the slot allows.
@@ -270,10 +319,8 @@ __device__ __forceinline__ uint64_t crt_signed(Pt r) {
 // constants at the tail of the table: N^-1 (+ companions) and N^-1 * 2^32 (for products of two plain operands taken with montmul),
 // each followed by its product with psiinv_rev[1]
 struct NttConsts { uint4 ninv[2], ninv_r[2]; };   // each: the constant c and c * w, w the twiddle of the inverse's last stage (ntt_inverse SCALED)
-// tables (32-bit words): psi_rev[N] x uint4 | psiinv_rev[N] x uint4 | NttConsts (4 x uint4)
-template <int LOGN> __device__ __forceinline__ const uint4 *tab_psi(const uint4 *tab) { return tab; }
-template <int LOGN> __device__ __forceinline__ const uint4 *tab_psiinv(const uint4 *tab) { return tab + (1 << LOGN); }
-template <int LOGN> __device__ __forceinline__ NttConsts tab_consts(const uint4 *tab) { NttConsts c; c.ninv[0] = tab[2 << LOGN]; c.ninv[1] = tab[(2 << LOGN) + 1]; c.ninv_r[0] = tab[(2 << LOGN) + 2]; c.ninv_r[1] = tab[(2 << LOGN) + 3]; return c; }
+// tables (32-bit words): psi_rev[N] x uint4 | NttConsts (4 x uint4).  No inverse table: bfly_inv reads the forward one mirrored
+template <int LOGN> __device__ __forceinline__ NttConsts tab_consts(const uint4 *tab) { NttConsts c; c.ninv[0] = tab[1 << LOGN]; c.ninv[1] = tab[(1 << LOGN) + 1]; c.ninv_r[0] = tab[(1 << LOGN) + 2]; c.ninv_r[1] = tab[(1 << LOGN) + 3]; return c; }
 
 // twiddles resident in LDS up to N = 2048 (one table: 16 N bytes); above, they are read through the caches
 template <int LOGN> struct TwLds { static constexpr bool on = LOGN <= 11; };
@@ -344,7 +391,7 @@ __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_inv_kernel
     constexpr int N = 1 << LOGN, NT = N >> NLR, PPW = Ppw<LOGN>::v;
     const int sub = PPW > 1 ? threadIdx.x / NT : 0, t = PPW > 1 ? threadIdx.x % NT : threadIdx.x;
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)sub * NttLds<LOGN>::WORDS;
-    const uint4 *tw[1]; const int which[1] = {1};
+    const uint4 *tw[1]; const int which[1] = {0};
     stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)PPW * NttLds<LOGN>::WORDS), threadIdx.x, PPW * NT, tw, which);
     const NttConsts k = tab_consts<LOGN>(tab);
     const size_t groups = (B + PPW - 1) / PPW;
@@ -380,8 +427,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_polymul_kernel(cons
     constexpr int N = 1 << LOGN, NT = N >> NLR, W = WordTraits<WORD>::W, H = W == 64 ? 2 : 1;
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
-    const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts k = tab_consts<LOGN>(tab);
     for (size_t b = blockIdx.x; b < B; b += gridDim.x) {
         Pt za[8];
@@ -404,7 +451,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_polymul_kernel(cons
             ntt_forward<LOGN>(zb, tw[0], lds, t);
 #pragma unroll
             for (int e = 0; e < 8; e++) zb[e] = pt_mont(zb[e], za[e]);                 // x y 2^-32: undone by N^-1 2^32 below
-            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(zb, tw[1], lds, t, k.ninv_r);
+            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(zb, tw[0], lds, t, k.ninv_r);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const uint64_t v = crt_signed(zb[e]);              // the exact integer, two's complement mod 2^64
@@ -433,8 +480,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
     constexpr int N = 1 << LOGN, NT = N >> NLR;
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
-    const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts k = tab_consts<LOGN>(tab);
     const size_t rot = blockIdx.x;
     const uint32_t *at_src = lwe + rot * (size_t)lwe_stride;
@@ -505,7 +552,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; e++) s2[e] = pt_mac(s2[e], tacc[q][pp][e], unpack(mrow[e]));   // :71 / :157
             }
-            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s2, tw[1], lds, t, k.ninv);            // :72 / :162
+            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s2, tw[0], lds, t, k.ninv);            // :72 / :162
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[pp][e] += (uint32_t)crt_signed(s2[e]);   // :73 / :163
         }
@@ -533,8 +580,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kr_kern
     constexpr int N = 1 << LOGN, NT = N >> NLR, NP = KR + 1;
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
-    const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts k = tab_consts<LOGN>(tab);
     const size_t rot = blockIdx.x;
     const uint32_t *at_src = lwe + rot * (size_t)lwe_stride;
@@ -593,7 +640,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kr_kern
         }
 #pragma unroll
         for (int pp = 0; pp < NP; pp++) {
-            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(sum[pp], tw[1], lds, t, k.ninv);                       // :72 / :162
+            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(sum[pp], tw[0], lds, t, k.ninv);                       // :72 / :162
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[pp][e] += (uint32_t)crt_signed(sum[pp][e]);                           // :73 / :163
         }
@@ -640,10 +687,16 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void ntt_fwd_split_kernel(cons
 }
 
 // the exact integers behind a (low, high) accumulator pair, combined mod 2^64: inverse transforms, N^-1, Garner lift
+#ifndef MKT_W3_WPE
+#define MKT_W3_WPE 3
+#endif
+#ifndef MKT_EXACT_WPE
+#define MKT_EXACT_WPE 2
+#endif
 template <int LOGN>
-__device__ __forceinline__ void lift_pair(Pt (&lo)[8], Pt (&hi)[8], uint64_t (&w)[8], const uint4 *psiinv, const NttConsts &k, uint64_t *lds, int t) {
-    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(lo, psiinv, lds, t, k.ninv);
-    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(hi, psiinv, lds, t, k.ninv);
+__device__ __forceinline__ void lift_pair(Pt (&lo)[8], Pt (&hi)[8], uint64_t (&w)[8], const uint4 *psi, const NttConsts &k, uint64_t *lds, int t) {
+    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(lo, psi, lds, t, k.ninv);
+    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(hi, psi, lds, t, k.ninv);
 #pragma unroll
     for (int e = 0; e < 8; e++) w[e] = crt_signed(lo[e]) + (crt_signed(hi[e]) << 32);
 }
@@ -651,7 +704,7 @@ __device__ __forceinline__ void lift_pair(Pt (&lo)[8], Pt (&hi)[8], uint64_t (&w
 // KMS phase 1 (bootstrapping.jl:389-443) with exact products: one workgroup per RLEV row rotation, accumulator (b, a) in
 // registers (slot e = coefficient e*NT + t); output: the row's two polynomials as split residue tables for phase 2
 template <int LOGN, bool BLK, bool WIDE = false>   // WIDE: l_gsw = 2, the digit products of an accumulator gathered in 64 bits (its own instantiation: its own register allocation)
-__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(2, 2))) void exact_kms_phase1_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
+__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(MKT_EXACT_WPE, MKT_EXACT_WPE))) void exact_kms_phase1_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
                                                                               const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe, int lwe_stride,
                                                                               int pre_switched, int n, int l, int logB, int blk_len, size_t ngates, int rows_per_gate,
                                                                               const int *__restrict__ slot_party, const int *__restrict__ slot_row, int logB_lev,
@@ -659,8 +712,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
     constexpr int N = 1 << LOGN, NT = N >> NLR;
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
-    const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts k = tab_consts<LOGN>(tab);
     const size_t gate = blockIdx.x % ngates;
     const int slot = (int)(blockIdx.x / ngates);
@@ -732,7 +785,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     uint64_t w[8];
-                    lift_pair<LOGN>(th[0], th[1], w, tw[1], k, lds, t);
+                    lift_pair<LOGN>(th[0], th[1], w, tw[0], k, lds, t);
                     __syncthreads();
 #pragma unroll
                     for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
@@ -806,7 +859,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int pp = 0; pp < 2; pp++) {
                     uint64_t w[8];
-                    lift_pair<LOGN>(tacc[pp][0], tacc[pp][1], w, tw[1], k, lds, t);
+                    lift_pair<LOGN>(tacc[pp][0], tacc[pp][1], w, tw[0], k, lds, t);
                     __syncthreads();
 #pragma unroll
                     for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
@@ -824,7 +877,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
         for (int pp = 0; pp < 2; pp++) {
             uint64_t w[8];
-            lift_pair<LOGN>(sum[pp][0], sum[pp][1], w, tw[1], k, lds, t);          // :436 / :653
+            lift_pair<LOGN>(sum[pp][0], sum[pp][1], w, tw[0], k, lds, t);          // :436 / :653
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[pp][e] += w[e];                        // :437 / :654
         }
@@ -845,6 +898,231 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
         }
 }
 
+// KMS phase 1 at l_gsw = 2, one key bit per step, laid out for THREE waves per SIMD (168 registers) on EVERY SIMD: ROTS = 2 rotations per
+// workgroup of four waves, side by side, sharing the staged twiddle table (2 x 8 + 16 KiB; three workgroups per CU).  Why four-wave
+// workgroups: the dispatcher deals two-wave workgroups unevenly -- six per CU land [2 4 3 3] waves per SIMD (tools/simd_place.hip) and the
+// SIMD with four sets the time -- while four-wave ones land one wave per SIMD; and why three: a gfx950 SIMD issues the multiply-class and
+// three-operand integer instructions these kernels are made of every 4.4 cycles with two waves resident and every 2.9-3.3 with three
+// (tools/int_probe.hip, profiles/r05_int_probe.txt).  The two rotations meet at every workgroup barrier, so neither may skip a step:
+// a zero mask word multiplies by X^0 - 1 = 0 and adds exactly zero (the reference skips it, :413 -- the same words).
+// The same sums as the WIDE form above, in an order that keeps fewer values alive --
+// the four digit transforms (64 registers) and the accumulator (32) stay; each (output polynomial, half) gathers its four products two
+// points at a time, is inverse-transformed and lifted at once, and X^at - 1 is applied to the low and to the high half SEPARATELY
+// ((X^at - 1)(S_lo + 2^32 S_hi) mod 2^64, the high half as 32-bit words): two more rotations through LDS per step, sixteen registers fewer.
+template <int LOGN, int ROTS>
+__global__ __launch_bounds__((ROTS << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(MKT_W3_WPE, MKT_W3_WPE))) void exact_kms_phase1_w3_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
+                                                                              const uint32_t *__restrict__ lwe, int lwe_stride, int pre_switched, int n, int logB, size_t ngates, int rows_per_gate,
+                                                                              const int *__restrict__ slot_party, const int *__restrict__ slot_row, int logB_lev,
+                                                                              uint64_t *__restrict__ lev_out) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
+    const int sub = ROTS > 1 ? threadIdx.x / NT : 0, t = ROTS > 1 ? threadIdx.x % NT : threadIdx.x;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)sub * NttLds<LOGN>::WORDS;
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)ROTS * NttLds<LOGN>::WORDS), threadIdx.x, ROTS * NT, tw, which);
+    const NttConsts k = tab_consts<LOGN>(tab);
+    const size_t nrot = ngates * (size_t)rows_per_gate;
+    size_t r = (size_t)blockIdx.x * ROTS + sub;
+    const bool live = r < nrot;                                                    // a ragged last workgroup repeats the last rotation (it must keep the barriers) and stores nothing
+    if (!live) r = nrot - 1;
+    const size_t gate = r % ngates;
+    const int slot = (int)(r / ngates);
+    const size_t rot = gate * (size_t)rows_per_gate + slot;
+    const int party = slot_party[slot], row = slot_row[slot];
+    const uint32_t *at_src = lwe + gate * (size_t)lwe_stride + (size_t)party * n;
+    const uint64_t *brk = brk0 + (size_t)party * brk_party_stride;
+    const Gadget<uint64_t> gd(2, logB);
+    uint64_t acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[c][e] = 0;
+    if (t == 0) acc[0][0] = (uint64_t)1 << (64 - (row + 1) * logB_lev);           // :403-406 trivial RLEV row
+    const int msbit = 32 - LOGN - 1;
+    for (int i = 0; i < n; i++) {
+        const uint32_t v0 = at_src[i];
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+        if (ROTS == 1 && at == 0) continue;                                        // :413 (ROTS > 1: no skip, the step adds zero)
+        Pt zz[4][8];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) zz[g][e] = res_small(gd.digit(gd.prep(g >= 2 ? acc[1][e] : acc[0][e]), g & 1));   // :415-425 decompto!
+            ntt_forward<LOGN, 0, true>(zz[g], tw[0], lds, t);
+#pragma unroll
+            for (int e = 0; e < 8; e++) zz[g][e] = wide_x(zz[g][e]);
+        }
+        const uint4 *rowb = reinterpret_cast<const uint4 *>(brk + ((size_t)i * 4 * 4) * N + 8 * t);     // [digit g][poly][half][N], two points per 16 bytes
+        auto half_poly = [&](auto ppc, auto hc) {                                  // a rolled loop would index acc[pp] at run time (-> scratch)
+            constexpr int pp = decltype(ppc)::value, h = decltype(hc)::value;
+            Pt th[8];
+#pragma unroll
+            for (int ep = 0; ep < 4; ep++) {                                       // :427-432: the same sum, two points at a time
+                Wide w0, w1;
+                w0.a = w0.b = w1.a = w1.b = 0;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint4 kv = (MKT_ABLATE & 2) ? make_uint4(zz[g][2 * ep].b >> 1, zz[g][2 * ep].a >> 1, zz[g][2 * ep + 1].b >> 1, zz[g][2 * ep + 1].a >> 1) : rowb[(size_t)(g * 4 + pp * 2 + h) * (N / 2) + ep];
+                    Pt y0, y1; y0.a = kv.x; y0.b = kv.y; y1.a = kv.z; y1.b = kv.w;
+                    wide_mac(w0, zz[g][2 * ep], y0); wide_mac(w1, zz[g][2 * ep + 1], y1);
+                }
+                th[2 * ep] = wide_reduce(w0); th[2 * ep + 1] = wide_reduce(w1);
+            }
+            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1, true>(th, tw[0], lds, t, k.ninv);
+            if (MKT_ABLATE & 8) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[pp][e] += crt_signed(th[e]) << (32 * h);
+                return;
+            }
+            __syncthreads();
+            if constexpr (h == 0) {
+                uint64_t w[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) { w[e] = crt_signed(th[e]); lds[e * NT + t] = w[e]; }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 8; e++) {                                      // :435-437: (X^at S)[i] = +-S[i - at mod N]
+                    const uint32_t src = (uint32_t)(e * NT + t - (int)at) & (2u * N - 1u);
+                    const uint64_t v = lds[src & (N - 1)];
+                    acc[pp][e] += (src >= (uint32_t)N ? (uint64_t)0 - v : v) - w[e];
+                }
+            } else {
+                uint32_t *ldw = reinterpret_cast<uint32_t *>(lds);
+                uint32_t w[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) { w[e] = (uint32_t)crt_signed(th[e]); ldw[e * NT + t] = w[e]; }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 8; e++) {                                      // the high half: the same rotation on 32-bit words, times 2^32
+                    const uint32_t src = (uint32_t)(e * NT + t - (int)at) & (2u * N - 1u);
+                    const uint32_t v = ldw[src & (N - 1)];
+                    acc[pp][e] += (uint64_t)((src >= (uint32_t)N ? 0u - v : v) - w[e]) << 32;
+                }
+            }
+        };
+        half_poly(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        half_poly(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        half_poly(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        half_poly(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    }
+    // :441 fftto!(tacc, acc): the row as split residue tables, Montgomery form
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            Pt z[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) z[e] = fwd_in(piece_of(acc[c][e], h), e);
+            ntt_forward<LOGN>(z, tw[0], lds, t);
+            uint64_t *o = lev_out + ((rot * 2 + c) * 2 + h) * (size_t)N + 8 * t;
+            if (live)
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = pack(Pt{montmul<P1, PI1>(z[e].a, RR1), montmul<P2, PI2>(z[e].b, RR2)});
+            __syncthreads();
+        }
+}
+
+// KMS phase 1 at l_gsw = 2 with PAIRED transforms (two waves per SIMD, the whole register file): the digit polynomials of one accumulator
+// (j = 0, 1) go through the forward transform side by side, the low and the high half of an output polynomial's lifted sum through the
+// inverse -- half the twiddle reads, slot addresses, barriers and exposed waits of the one-at-a-time form, and the two halves of a sum
+// arrive together, so X^at - 1 is applied once per output polynomial on the 64-bit words.  The same sums (WIDE form), the same words.
+template <int LOGN>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(2, 2))) void exact_kms_phase1_p2_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
+                                                                              const uint32_t *__restrict__ lwe, int lwe_stride, int pre_switched, int n, int logB, size_t ngates, int rows_per_gate,
+                                                                              const int *__restrict__ slot_party, const int *__restrict__ slot_row, int logB_lev,
+                                                                              uint64_t *__restrict__ lev_out) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);                        // two staging buffers, then the table
+    const int t = threadIdx.x;
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + 2 * NttLds<LOGN>::WORDS), t, NT, tw, which);
+    const NttConsts k = tab_consts<LOGN>(tab);
+    const size_t gate = blockIdx.x % ngates;
+    const int slot = (int)(blockIdx.x / ngates);
+    const size_t rot = gate * (size_t)rows_per_gate + slot;
+    const int party = slot_party[slot], row = slot_row[slot];
+    const uint32_t *at_src = lwe + gate * (size_t)lwe_stride + (size_t)party * n;
+    const uint64_t *brk = brk0 + (size_t)party * brk_party_stride;
+    const Gadget<uint64_t> gd(2, logB);
+    uint64_t acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[c][e] = 0;
+    if (t == 0) acc[0][0] = (uint64_t)1 << (64 - (row + 1) * logB_lev);           // :403-406 trivial RLEV row
+    const int msbit = 32 - LOGN - 1;
+    for (int i = 0; i < n; i++) {
+        const uint32_t v0 = at_src[i];
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+        if (at == 0) continue;                                                     // :413
+        Pt zz[4][8];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            Pt (&zp)[2][8] = *reinterpret_cast<Pt(*)[2][8]>(&zz[2 * c]);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) zp[j][e] = res_small(gd.digit(gd.prep(c ? acc[1][e] : acc[0][e]), j));   // :415-425 decompto!
+            ntt_forward_n<LOGN, 0, false, 2>(zp, tw[0], lds, t);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) zp[j][e] = wide_x(zp[j][e]);
+        }
+        const uint64_t *rowb = brk + ((size_t)i * 4 * 4) * N + 8 * t;             // [digit g][poly][half][N]
+        auto output_poly = [&](auto ppc) {                                       // written out twice: a rolled loop would index acc[pp] at run time (-> scratch)
+            constexpr int pp = decltype(ppc)::value;
+            Pt th[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                Wide wa[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) { wa[e].a = 0; wa[e].b = 0; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) wide_mac(wa[e], zz[g][e], unpack(rowb[(size_t)(g * 4 + pp * 2 + h) * N + e]));   // :427-432: the same sum
+#pragma unroll
+                for (int e = 0; e < 8; e++) th[h][e] = wide_reduce(wa[e]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ntt_inverse_n<LOGN, Plan<LOGN, NLR>::NPASS - 1, false, 2>(th, tw[0], lds, t, k.ninv);
+            uint64_t w[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) w[e] = crt_signed(th[0][e]) + (crt_signed(th[1][e]) << 32);
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; e++) {                                          // :435-437: (X^at S)[i] = +-S[i - at mod N]
+                const uint32_t src = (uint32_t)(e * NT + t - (int)at) & (2u * N - 1u);
+                const uint64_t v = lds[src & (N - 1)];
+                acc[pp][e] += (src >= (uint32_t)N ? (uint64_t)0 - v : v) - w[e];
+            }
+        };
+        output_poly(std::integral_constant<int, 0>{});
+        output_poly(std::integral_constant<int, 1>{});
+    }
+    // :441 fftto!(tacc, acc): the row as split residue tables, Montgomery form; the two halves of a polynomial side by side
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        Pt z[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) z[h][e] = fwd_in(piece_of(acc[c][e], h), e);
+        ntt_forward_n<LOGN, 0, false, 2>(z, tw[0], lds, t);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint64_t *o = lev_out + ((rot * 2 + c) * 2 + h) * (size_t)N + 8 * t;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = pack(Pt{montmul<P1, PI1>(z[h][e].a, RR1), montmul<P2, PI2>(z[h][e].b, RR2)});
+        }
+        __syncthreads();
+    }
+}
+
 // KMS phase 2 (bootstrapping.jl:448-558) with exact products; one workgroup per ciphertext, every thread only touches its
 // own coefficients (e*NT + t) and transform points (8t + e)
 struct ExactPhase2Args {
@@ -863,8 +1141,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
     constexpr int N = 1 << LOGN, NT = N >> NLR;
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
-    const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts kc = tab_consts<LOGN>(tab);
     const size_t g = blockIdx.x;
     const int k = a.k;
@@ -929,7 +1207,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
 #pragma unroll
                 for (int e = 0; e < 8; e++) tx[((size_t)q * 2 + h) * N + 8 * t + e] = pack(txq[h][e]);
             uint64_t yw[8];
-            lift_pair<LOGN>(tyq[0], tyq[1], yw, tw[1], kc, lds, t);                // :501-504
+            lift_pair<LOGN>(tyq[0], tyq[1], yw, tw[0], kc, lds, t);                // :501-504
 #pragma unroll
             for (int e = 0; e < 8; e++) tp[e] = guni.prep(yw[e]);                  // :508-509
             Pt tyu[2][8];
@@ -947,7 +1225,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
                 for (int e = 0; e < 8; e++) ty2[((size_t)q * 2 + h) * N + 8 * t + e] = pack(tyu[h][e]);
         }
         uint64_t vw[8];
-        lift_pair<LOGN>(tv[0], tv[1], vw, tw[1], kc, lds, t);                      // :538
+        lift_pair<LOGN>(tv[0], tv[1], vw, tw[0], kc, lds, t);                      // :538
         uint64_t tp[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) tp[e] = guni.prep(vw[e]);                      // :541
@@ -975,7 +1253,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
                     s[h][e] = pt_add_lazy(xv, yv);
                 }
             uint64_t w[8];
-            lift_pair<LOGN>(s[0], s[1], w, tw[1], kc, lds, t);
+            lift_pair<LOGN>(s[0], s[1], w, tw[0], kc, lds, t);
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[(size_t)q * N + e * NT + t] = w[e];
         }
@@ -999,12 +1277,12 @@ struct ExactCcsArgs {
     uint64_t *scratch;                                // [B][k+1][N] residue pairs
 };
 template <int LOGN>
-__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(2, 2))) void exact_ccs_kernel(const uint4 *__restrict__ tab, const ExactCcsArgs a) {
+__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(MKT_EXACT_WPE, MKT_EXACT_WPE))) void exact_ccs_kernel(const uint4 *__restrict__ tab, const ExactCcsArgs a) {
     constexpr int N = 1 << LOGN, NT = N >> NLR;
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
-    const uint4 *tw[2]; const int which[2] = {0, 1};
-    stage_tables<LOGN, 2>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
     const NttConsts kc = tab_consts<LOGN>(tab);
     const size_t g = blockIdx.x;
     const int k = a.k, l = a.l, n = a.n;
@@ -1056,7 +1334,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                     for (int e = 0; e < 8; e++) sc[(size_t)q * N + 8 * t + e] = pack(tu[e]);
                 }
-                ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(tv, tw[1], lds, t, kc.ninv);   // :297-300
+                ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(tv, tw[0], lds, t, kc.ninv);   // :297-300
 #pragma unroll
                 for (int e = 0; e < 8; e++) tp[e] = gd.prep((uint32_t)crt_signed(tv[e]));   // :303-310
                 for (int j = 0; j < l; j++) {                                      // :313-320 w
@@ -1079,7 +1357,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
                     const Pt x = q == 0 ? tb[e] : (q == np ? ta[e] : unpack(sc[(size_t)q * N + 8 * t + e]));
                     s[e] = pt_mont(x, unpack(mrow[e]));
                 }
-                ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s, tw[1], lds, t, kc.ninv);
+                ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s, tw[0], lds, t, kc.ninv);
 #pragma unroll
                 for (int e = 0; e < 8; e++) acc[(size_t)q * N + e * NT + t] += (uint32_t)crt_signed(s[e]);
             }
@@ -1095,6 +1373,13 @@ static hipError_t ntt_set_lds(K kern, size_t bytes) {
 
 }  // namespace
 
+#ifdef MKT_NTT_ONLY_LOGN   // development builds: instantiate one transform size only (seconds instead of minutes)
+#define MKT_NTT_DISPATCH(logN, ...)                   \
+    switch (logN) {                                   \
+    case MKT_NTT_ONLY_LOGN: { constexpr int LN = MKT_NTT_ONLY_LOGN; __VA_ARGS__; } break; \
+    default: return hipErrorInvalidValue;             \
+    }
+#else
 #define MKT_NTT_DISPATCH(logN, ...)                   \
     switch (logN) {                                   \
     case 5:  { constexpr int LN = 5;  __VA_ARGS__; } break; \
@@ -1107,6 +1392,7 @@ static hipError_t ntt_set_lds(K kern, size_t bytes) {
     case 12: { constexpr int LN = 12; __VA_ARGS__; } break; \
     default: return hipErrorInvalidValue;             \
     }
+#endif
 
 template <int LN, typename WORD, bool MONT>
 static hipError_t ntt_fwd_launch(const uint4 *tb, const void *p, uint64_t *t, size_t B, int grid, size_t lds, hipStream_t s) {
@@ -1151,7 +1437,7 @@ hipError_t launch_exact_polymul(int logN, int W, const uint64_t *tab, const void
     const int grid = (int)(B < 32768 ? B : 32768);
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
     MKT_NTT_DISPATCH(logN, {
-        const size_t lds = lds_bytes<LN>(2);
+        const size_t lds = lds_bytes<LN>(1);
         if (W == 64) { hipError_t e = ntt_set_lds(exact_polymul_kernel<LN, uint64_t>, lds); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((exact_polymul_kernel<LN, uint64_t>), dim3(grid), dim3(1 << (LN - NLR)), lds, s, tb, (const uint64_t *)a, (const uint64_t *)b, (uint64_t *)out, B); }
         else { hipError_t e = ntt_set_lds(exact_polymul_kernel<LN, uint32_t>, lds); if (e != hipSuccess) return e;
@@ -1167,7 +1453,7 @@ hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_
     last_rot_kernel = "exact_blindrotate_kernel";
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
     MKT_NTT_DISPATCH(logN, {
-        const size_t lds = lds_bytes<LN>(2);
+        const size_t lds = lds_bytes<LN>(1);
         if (blk_len == 1) {
             hipError_t e = ntt_set_lds(exact_blindrotate_kernel<LN, 1>, lds); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((exact_blindrotate_kernel<LN, 1>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, acc);
@@ -1188,7 +1474,7 @@ hipError_t launch_exact_blindrotate_kr(int logN, const uint64_t *tab, const uint
 #define MKT_EXACT_KR_LAUNCH(KRV) do { hipError_t e = ntt_set_lds(exact_blindrotate_kr_kernel<LN, KRV>, lds); if (e != hipSuccess) return e; \
         hipLaunchKernelGGL((exact_blindrotate_kr_kernel<LN, KRV>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, blk_len, acc); } while (0)
     MKT_NTT_DISPATCH(logN, {
-        const size_t lds = lds_bytes<LN>(2);
+        const size_t lds = lds_bytes<LN>(1);
         if (kr == 1) MKT_EXACT_KR_LAUNCH(1); else if (kr == 2) MKT_EXACT_KR_LAUNCH(2); else MKT_EXACT_KR_LAUNCH(3);
     });
 #undef MKT_EXACT_KR_LAUNCH
@@ -1212,14 +1498,25 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
     last_rot_kernel = "exact_kms_phase1_kernel";
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
     MKT_NTT_DISPATCH(logN, {
-        const size_t lds = lds_bytes<LN>(2);
+        const size_t lds = lds_bytes<LN>(1);
         hipError_t e = hipSuccess;
         if (a.blk_len > 1) {
             e = ntt_set_lds(exact_kms_phase1_kernel<LN, true>, lds); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, true>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
                                a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, a.blk_len, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
         } else {
-            if (a.wide && a.l_gsw == 2) {
+            if (a.wide >= 3 && a.l_gsw == 2) {
+                const size_t lds2 = lds_bytes<LN>(1, 2);
+                e = ntt_set_lds(exact_kms_phase1_p2_kernel<LN>, lds2); if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((exact_kms_phase1_p2_kernel<LN>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds2, s, tb, a.brk, a.brk_party_stride,
+                                   a.lwe, a.lwe_stride, a.pre_switched, a.n, a.logB_gsw, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+            } else if (a.wide >= 2 && a.l_gsw == 2) {
+                constexpr int ROTS = 2;
+                const size_t lds2 = lds_bytes<LN>(1, ROTS), nrot = B * (size_t)a.rtot;
+                e = ntt_set_lds(exact_kms_phase1_w3_kernel<LN, ROTS>, lds2); if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((exact_kms_phase1_w3_kernel<LN, ROTS>), dim3((unsigned)((nrot + ROTS - 1) / ROTS)), dim3(ROTS << (LN - NLR)), lds2, s, tb, a.brk, a.brk_party_stride,
+                                   a.lwe, a.lwe_stride, a.pre_switched, a.n, a.logB_gsw, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+            } else if (a.wide && a.l_gsw == 2) {
                 e = ntt_set_lds(exact_kms_phase1_kernel<LN, false, true>, lds); if (e != hipSuccess) return e;
                 hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, false, true>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
                                    a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, 1, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
@@ -1247,7 +1544,7 @@ hipError_t launch_exact_ccs(int logN, const uint64_t *tab, const ExactCcsHostArg
     a.lwe = h.lwe; a.lwe_stride = h.lwe_stride; a.pre_switched = h.pre_switched; a.n = h.n; a.k = h.k; a.l = h.l; a.logB = h.logB;
     a.brk = h.brk; a.brk_party_stride = h.brk_party_stride; a.pub_b = h.pub_b; a.crs = h.crs; a.mono = h.mono; a.acc = h.acc; a.scratch = h.scratch;
     MKT_NTT_DISPATCH(logN, {
-        const size_t lds = lds_bytes<LN>(2);
+        const size_t lds = lds_bytes<LN>(1);
         hipError_t e = ntt_set_lds(exact_ccs_kernel<LN>, lds); if (e != hipSuccess) return e;
         hipLaunchKernelGGL((exact_ccs_kernel<LN>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, a);
     });

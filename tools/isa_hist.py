@@ -5,7 +5,7 @@ import re, sys, collections
 src = open(sys.argv[1]).read()
 names = [n for n in re.findall(r'^(_Z\S+):', src, re.M) if sys.argv[2] in n]
 for tgt in names:
-    s = src.index('\n' + tgt + ':'); e = src.index('s_endpgm', s)
+    s = src.index('\n' + tgt + ':'); e = src.index('.Lfunc_end', s)
     body = src[s:e].split('\n')
     a, b = 0, len(body)
     if '--loop' in sys.argv:

@@ -30,10 +30,10 @@ __global__ void place(uint32_t *out, int spin, int live) {
 int main() {
     hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, 0);
     const int ncu = pr.multiProcessorCount;
-    for (int mode : {0, 1, 2}) for (int per_cu : {1, 2, 3, 4}) {
+    for (int mode : {0, 1, 2}) for (int per_cu : {1, 2, 3, 4, 5, 6, 8}) {
         const int waves = mode == 0 ? 2 : 4, live = mode == 2 ? 2 : waves;      // mode 2: four waves launched, two stay
         const int wgs = ncu * per_cu;
-        const size_t lds = (size_t)(160 * 1024 / 4) - 512;                     // four workgroups per CU at most
+        const size_t lds = (size_t)(160 * 1024 / (per_cu <= 4 ? 4 : 8)) - 512;   // four (eight) workgroups per CU at most
         uint32_t *d; (void)hipMalloc((void **)&d, (size_t)wgs * live * 8);
         (void)hipFuncSetAttribute((const void *)place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(place, dim3(wgs), dim3(64 * waves), lds, 0, d, 100000, live);     // 100 MHz counter: 1 ms
