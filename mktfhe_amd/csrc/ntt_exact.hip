@@ -694,11 +694,10 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void ntt_fwd_split_kernel(cons
 #define MKT_EXACT_WPE 2
 #endif
 template <int LOGN>
-__device__ __forceinline__ void lift_pair(Pt (&lo)[8], Pt (&hi)[8], uint64_t (&w)[8], const uint4 *psi, const NttConsts &k, uint64_t *lds, int t) {
-    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(lo, psi, lds, t, k.ninv);
-    ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(hi, psi, lds, t, k.ninv);
+__device__ __forceinline__ void lift_pair(Pt (&x)[2][8], uint64_t (&w)[8], const uint4 *psi, const NttConsts &k, uint64_t *lds, int t) {
+    ntt_inverse_n<LOGN, Plan<LOGN, NLR>::NPASS - 1, false, 2>(x, psi, lds, t, k.ninv);      // the two halves side by side (two staging buffers): one set of twiddle reads, addresses and barriers
 #pragma unroll
-    for (int e = 0; e < 8; e++) w[e] = crt_signed(lo[e]) + (crt_signed(hi[e]) << 32);
+    for (int e = 0; e < 8; e++) w[e] = crt_signed(x[0][e]) + (crt_signed(x[1][e]) << 32);
 }
 
 // KMS phase 1 (bootstrapping.jl:389-443) with exact products: one workgroup per RLEV row rotation, accumulator (b, a) in
@@ -713,7 +712,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
     const uint4 *tw[1]; const int which[1] = {0};
-    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + 2 * NttLds<LOGN>::WORDS), t, NT, tw, which);   // two staging buffers (lift_pair), then the table
     const NttConsts k = tab_consts<LOGN>(tab);
     const size_t gate = blockIdx.x % ngates;
     const int slot = (int)(blockIdx.x / ngates);
@@ -785,7 +784,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     uint64_t w[8];
-                    lift_pair<LOGN>(th[0], th[1], w, tw[0], k, lds, t);
+                    lift_pair<LOGN>(th, w, tw[0], k, lds, t);
                     __syncthreads();
 #pragma unroll
                     for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
@@ -859,7 +858,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int pp = 0; pp < 2; pp++) {
                     uint64_t w[8];
-                    lift_pair<LOGN>(tacc[pp][0], tacc[pp][1], w, tw[0], k, lds, t);
+                    lift_pair<LOGN>(tacc[pp], w, tw[0], k, lds, t);
                     __syncthreads();
 #pragma unroll
                     for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
@@ -877,7 +876,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
         for (int pp = 0; pp < 2; pp++) {
             uint64_t w[8];
-            lift_pair<LOGN>(sum[pp][0], sum[pp][1], w, tw[0], k, lds, t);          // :436 / :653
+            lift_pair<LOGN>(sum[pp], w, tw[0], k, lds, t);          // :436 / :653
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[pp][e] += w[e];                        // :437 / :654
         }
@@ -1081,7 +1080,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int g = 0; g < 4; g++)
 #pragma unroll
-                    for (int e = 0; e < 8; e++) wide_mac(wa[e], zz[g][e], unpack(rowb[(size_t)(g * 4 + pp * 2 + h) * N + e]));   // :427-432: the same sum
+                    for (int e = 0; e < 8; e++) wide_mac(wa[e], zz[g][e], (MKT_ABLATE & 2) ? Pt{zz[g][e].b >> 1, zz[g][e].a >> 1} : unpack(rowb[(size_t)(g * 4 + pp * 2 + h) * N + e]));   // :427-432: the same sum
 #pragma unroll
                 for (int e = 0; e < 8; e++) th[h][e] = wide_reduce(wa[e]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1090,6 +1089,11 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
             uint64_t w[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) w[e] = crt_signed(th[0][e]) + (crt_signed(th[1][e]) << 32);
+            if (MKT_ABLATE & 8) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[pp][e] += w[e];
+                return;
+            }
             __syncthreads();
 #pragma unroll
             for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
@@ -1142,7 +1146,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
     const uint4 *tw[1]; const int which[1] = {0};
-    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + 2 * NttLds<LOGN>::WORDS), t, NT, tw, which);   // two staging buffers (lift_pair), then the table
     const NttConsts kc = tab_consts<LOGN>(tab);
     const size_t g = blockIdx.x;
     const int k = a.k;
@@ -1207,7 +1211,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
 #pragma unroll
                 for (int e = 0; e < 8; e++) tx[((size_t)q * 2 + h) * N + 8 * t + e] = pack(txq[h][e]);
             uint64_t yw[8];
-            lift_pair<LOGN>(tyq[0], tyq[1], yw, tw[0], kc, lds, t);                // :501-504
+            lift_pair<LOGN>(tyq, yw, tw[0], kc, lds, t);                // :501-504
 #pragma unroll
             for (int e = 0; e < 8; e++) tp[e] = guni.prep(yw[e]);                  // :508-509
             Pt tyu[2][8];
@@ -1225,7 +1229,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
                 for (int e = 0; e < 8; e++) ty2[((size_t)q * 2 + h) * N + 8 * t + e] = pack(tyu[h][e]);
         }
         uint64_t vw[8];
-        lift_pair<LOGN>(tv[0], tv[1], vw, tw[0], kc, lds, t);                      // :538
+        lift_pair<LOGN>(tv, vw, tw[0], kc, lds, t);                      // :538
         uint64_t tp[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) tp[e] = guni.prep(vw[e]);                      // :541
@@ -1253,7 +1257,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_kms_phase2_kernel(c
                     s[h][e] = pt_add_lazy(xv, yv);
                 }
             uint64_t w[8];
-            lift_pair<LOGN>(s[0], s[1], w, tw[0], kc, lds, t);
+            lift_pair<LOGN>(s, w, tw[0], kc, lds, t);
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[(size_t)q * N + e * NT + t] = w[e];
         }
@@ -1498,7 +1502,7 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
     last_rot_kernel = "exact_kms_phase1_kernel";
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
     MKT_NTT_DISPATCH(logN, {
-        const size_t lds = lds_bytes<LN>(1);
+        const size_t lds = lds_bytes<LN>(1, 2);                                      // two staging buffers: the halves of a lifted sum are inverse-transformed side by side
         hipError_t e = hipSuccess;
         if (a.blk_len > 1) {
             e = ntt_set_lds(exact_kms_phase1_kernel<LN, true>, lds); if (e != hipSuccess) return e;
