@@ -67,19 +67,49 @@ WORKLOADS = {
     "adder8": ("KMS2party_N1024_l2", "8-bit ripple-carry adder circuits on the BASELINE configs[1] parameter set (KMS k=2, N=1024, l_gsw=2), one engine call per circuit level"),
 }
 
-# Parameter sets whose own output noise leaves less than 6 sigma of decryption margin, with the per-gate failure probability
-# that noise predicts for gates on all-party ciphertexts (tools/noise_theory.py: input phase error of a NAND = sqrt(2) x the
-# output sigma of the previous level; profiles/r03_noise_theory_vs_measured.md).  Every other set must decrypt every gate.
-# The KMS rows on the 64-bit ring are MEASURED on 16 384 gates (round 4, tools/ks_big_check.py: 22 / 7 / 5 wrong of 16 384): the
-# Float64 transform error there is heavier-tailed than the Gaussian the sigma predicts (KMS2party 5.2 sigma of margin would give
-# 1.5e-5, KMS2partyblock 5e-6) -- in the reference's arithmetic, bit for bit; the EXACT mode decrypts all 16 384.
-NOISY_SETS = {"KMS2party_N1024_l2": 1.5e-3, "KMS2party": 4.3e-4, "KMS2partyblock": 3.1e-4, "KMS8party": 1e-3,
-              "CCS2party": 4.6e-3, "CCS4party": 0.20, "CCS8party": 0.033, "CCS16party": 0.37}
+# Parameter sets whose own output noise leaves less than 6 sigma of decryption margin.  PREDICTED: the per-gate failure probability the
+# noise theory gives for gates on all-party ciphertexts (tools/noise_theory.py: input phase error of a NAND = sqrt(2) x the output sigma
+# of the previous level, Gaussian tail; profiles/r03_noise_theory_vs_measured.md).  Every other set must decrypt every gate.
+PREDICTED_FAILURE = {"KMS2party_N1024_l2": 1.5e-3, "KMS2party": 1.5e-5, "KMS2partyblock": 5e-6, "KMS8party": 1e-3,
+                     "CCS2party": 4.6e-3, "CCS4party": 0.20, "CCS8party": 0.033, "CCS16party": 0.37}
+# MEASURED in the reference's own arithmetic on 16 384 gates (round 4, tools/ks_big_check.py: 7 / 5 wrong, each wrong gate's words equal
+# to the CPU oracle's): on the 64-bit ring the Float64 transform error is heavier-tailed than the Gaussian the sigma predicts.  These
+# rates are reported beside the prediction, never in its place, and they only widen the accepted band when THIS run's wrong gates are
+# shown to be the oracle's own words (verify_wrong_gates, inside the cpu_baseline leg) -- a kernel regression cannot hide in the band.
+REFERENCE_ARITH_FAILURE = {"KMS2party": 4.3e-4, "KMS2partyblock": 3.1e-4}
 
 
-def allowed_wrong(pname, checked):
-    rate = NOISY_SETS.get(pname)
-    return 0 if rate is None else int(3 * rate * checked) + 3
+def allowed_wrong(pname, checked, verified=False):
+    """wrong decryptions a run may show: 3 x the predicted rate (+3); 3 x the rate measured in the reference's arithmetic only
+    when the wrong gates were verified word for word against the oracle"""
+    rate = PREDICTED_FAILURE.get(pname)
+    if rate is None:
+        return 0
+    if verified:
+        rate = max(rate, REFERENCE_ARITH_FAILURE.get(pname, 0.0))
+    return int(3 * rate * checked) + 3
+
+
+def decrypt_fields(pname, errs, checked):
+    return {"decrypt_ok": errs <= allowed_wrong(pname, checked), "decrypt_errors": errs, "decrypt_checked": checked,
+            "decrypt_failure_rate_measured": errs / max(checked, 1), "decrypt_failure_rate_predicted": PREDICTED_FAILURE.get(pname, 0.0),
+            "decrypt_failure_rate_reference_arithmetic": REFERENCE_ARITH_FAILURE.get(pname), "wrong_gates_match_oracle": None}
+
+
+def verify_wrong_gates(line, mk, p, crs, keys, allc, B, res, want, limit=64):
+    """the checker's part of the decryption gate (runs inside the cpu_baseline leg, F64REF only): every gate of this rank's shard that
+    decrypts wrongly is recomputed by the CPU oracle; if its words are the oracle's words, the failure is the parameter set's noise in
+    the reference's arithmetic and the band of REFERENCE_ARITH_FAILURE applies; if any differs, decrypt_ok is false whatever the count"""
+    got = mk.lwe_decrypt(res, keys if p.multikey else keys[0], p)
+    wrong = np.flatnonzero(got != want)[:limit]
+    if len(wrong) == 0:
+        return
+    from helpers import oracle_scheme
+    so = oracle_scheme(p, crs, keys)
+    same = all(np.array_equal(so.gate(0, allc[int(g)], allc[B + int(g)]), res[int(g)]) for g in wrong)
+    line["wrong_gates_match_oracle"] = bool(same)
+    line["wrong_gates_checked"] = int(len(wrong))
+    line["decrypt_ok"] = bool(same) and line["decrypt_errors"] <= allowed_wrong(line["config"]["params"], line["decrypt_checked"], verified=True)
 
 
 # no-FMA f64 vector peak: 256 CUs x 4 SIMDs x 16 lanes/clk (a wave64 v_add_f64 / v_mul_f64 issues over 4 cycles) x
@@ -540,14 +570,15 @@ def main_inproc(args):
                    "launcher": "inproc (mkt_multi_*)", "devices": devices,
                    "io": f"inputs and outputs are ONE array each on device {devices[0]}; the other shards' slices travel by peer copy inside the timed region"},
         "ranks_seen": n, "per_rank_ms_per_step": per_shard,
-        "decrypt_ok": errs <= allowed_wrong(pname, total), "decrypt_errors": errs, "decrypt_checked": total,
-        "decrypt_failure_rate_measured": errs / max(total, 1), "decrypt_failure_rate_predicted": NOISY_SETS.get(pname, 0.0),
+        **decrypt_fields(pname, errs, total),
         "kernels_ms_per_step": {"shard": 0, "blindrotate": r0 / max(args.steps, 1), "kms_phase2": q0 / max(args.steps, 1), "keyswitch": k0 / max(args.steps, 1)},
     }
     line["roofline"] = rot_roofline(mk, p, hi - lo, t, args.workload, kern) if args.arith == "f64ref" else exact_rot_roofline(mk, p, hi - lo, t, kern, args.workload)
     if not args.no_cpu_baseline:
         allc = np.concatenate([x.cpu().numpy(), y.cpu().numpy()]).view(np.uint32)
         line["cpu_baseline"], line["oracle_bitexact"] = cpu_baseline(p, crs, keys, allc, total, res, args, args.arith == "f64ref")
+        if args.arith == "f64ref":
+            verify_wrong_gates(line, mk, p, crs, keys, allc, total, res, want)
     print(json.dumps(line), flush=True)
     sch.close()
 
@@ -630,14 +661,10 @@ def main():
                        "l_gsw": p.l_gsw, "batch_per_gpu": B, "batch_total": total_batch, "op": args.op.upper(), "inputs": args.inputs, "arith": "F64REF" if args.arith == "f64ref" else "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)", "sharding": "gates across GPUs, keys replicated",
                        "launcher": "ranks (one process per GPU, torch.distributed)"},
             "ranks_seen": ranks_seen, "per_rank_ms_per_step": t["per_rank_ms"], "rendezvous_backend": backend if world > 1 else None,
-            # Wrong decryptions are the parameter set's own output noise (profiles/r03_noise_theory_vs_measured.md: predicted
-            # from the schemes' variance formulas, measured on this engine; the oracle produces the identical words --
-            # `oracle_bitexact` is the parity gate).  Sets whose margin is >= 6 sigma must decrypt EVERY gate; the noisy ones
-            # (margin / sigma in NOISY_SETS) report their measured failure rate and are held to 3x the predicted one.
-            "decrypt_ok": t["decrypt_errors_all"] <= allowed_wrong(pname, t["decrypt_checked_all"]),
-            "decrypt_errors": t["decrypt_errors_all"], "decrypt_checked": t["decrypt_checked_all"],
-            "decrypt_failure_rate_measured": t["decrypt_errors_all"] / max(t["decrypt_checked_all"], 1),
-            "decrypt_failure_rate_predicted": NOISY_SETS.get(pname, 0.0),
+            # Wrong decryptions are the parameter set's own output noise (profiles/r03_noise_theory_vs_measured.md).  Sets whose margin is
+            # >= 6 sigma must decrypt EVERY gate; the noisy ones are held to 3 x the PREDICTED rate, and to 3 x the rate measured in the
+            # reference's arithmetic only once this run's wrong gates are shown to be the oracle's words (verify_wrong_gates below)
+            **decrypt_fields(pname, t["decrypt_errors_all"], t["decrypt_checked_all"]),
             "kernels_ms_per_step": {"blindrotate": t["rot_ms"] / max(args.steps, 1), "kms_phase2": t["p2_ms"] / max(args.steps, 1),
                                     "keyswitch": t["ks_ms"] / max(args.steps, 1)},
         }
@@ -689,6 +716,8 @@ def main():
     # ---- CPU baseline leg (oracle, "port"): rank 0, at every world size (the other ranks wait at the final barrier) ----
     if rank == 0 and not args.no_cpu_baseline and args.op == "nand":
         line["cpu_baseline"], line["oracle_bitexact"] = cpu_baseline(p, crs, keys, allc, B, res, args, args.arith == "f64ref")   # EXACT words differ from the Float64 reference by construction (checked against big-integer arithmetic in tests)
+        if args.arith == "f64ref":
+            verify_wrong_gates(line, mk, p, crs, keys, allc, B, res, ~(bits[:B] & bits[B:]))
 
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -173,7 +173,12 @@ int mkt_gate_batch(mkt_ctx *ctx, int op, const uint32_t *x, const uint32_t *y, u
  * lives where x, y, out live (`mem`) */
 int mkt_gate_batch_ops(mkt_ctx *ctx, const uint8_t *ops, const uint32_t *x, const uint32_t *y, uint32_t *out, size_t B, int mem);
 /* one level of a gate circuit: gate j reads rows ix[j] and iy[j] of pool [pool_rows][k*n+1] and writes out[j]; out may be a
- * later region of the same pool provided no gate of this call reads a row this call writes */
+ * later region of the same pool provided no gate of this call reads a row this call writes.
+ * Validation: with MKT_MEM_HOST every index and gate code is checked (MKT_ERR_ARG).  With MKT_MEM_DEVICE the arrays cannot be read by
+ * the host without a synchronising copy, so valid indices (< pool_rows) and codes (bits 0-2 <= MKT_NOR, bits 5-7 clear) are the CALLER's
+ * precondition (mktfhe_amd/circuit.py builds them from a validated plan); what the engine guarantees regardless is memory safety -- an
+ * index beyond the pool is clamped to its last row, a code is read modulo its defined bits -- never an out-of-bounds access.  The same
+ * holds for mkt_gate_batch_ops and mkt_mux_batch_gather. */
 int mkt_gate_batch_gather(mkt_ctx *ctx, const uint8_t *ops, const uint32_t *pool, size_t pool_rows, const uint32_t *ix,
                           const uint32_t *iy, uint32_t *out, size_t B, int mem);
 /* MUX(s, a, b) = s ? a : b -- named by the north star; the reference has no MUX gate (gate.jl:1-57).  Two blind rotations and one
@@ -232,7 +237,9 @@ typedef struct mkt_multi mkt_multi;
  * shards on distinct devices do (exercises the device-to-device replication on a one-GPU box; costs one key copy per shard) */
 /* MKT_MULTI_STAGE_ALWAYS = device-resident arguments always travel through the shards' staging buffers (peer copies), as they do
  * for a shard on another device than the array's (that path on a one-GPU box) */
-enum { MKT_MULTI_PRIVATE_KEYS = 1, MKT_MULTI_STAGE_ALWAYS = 2 };
+/* MKT_MULTI_NO_PEER = every device-to-device copy (key replication, staged arguments) goes through a host buffer instead of
+ * hipMemcpyPeer: the path the engine falls back to by itself where a peer copy is refused, selectable so that it can be tested */
+enum { MKT_MULTI_PRIVATE_KEYS = 1, MKT_MULTI_STAGE_ALWAYS = 2, MKT_MULTI_NO_PEER = 4 };
 int mkt_multi_create(const mkt_params *params, int arith_mode, const int *devices, int nshards, int flags, mkt_multi **out);
 int mkt_multi_destroy(mkt_multi *m);
 const char *mkt_multi_last_error(const mkt_multi *m);  /* m may be NULL: last creation error */

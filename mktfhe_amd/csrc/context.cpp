@@ -601,16 +601,18 @@ int mkt_ctx_fork(mkt_ctx *c, mkt_ctx **out) {
 // dst is a fresh context of the same parameters and arithmetic on another device.  Device-to-device with hipMemcpyPeer (xGMI
 // when the devices are linked; the runtime stages through the host otherwise); if the peer copy is refused, an explicit host
 // bounce.  The key upload and its transforms run ONCE, on src's device ("optional one-time device-to-device key copy").
-static int copy_across(mkt_ctx *dst, void *d, int ddev, const void *s_, int sdev, size_t bytes) {
+static int copy_across(mkt_ctx *dst, void *d, int ddev, const void *s_, int sdev, size_t bytes, bool no_peer) {
     if (!bytes) return MKT_OK;
-    if (hipMemcpyPeer(d, ddev, s_, sdev, bytes) == hipSuccess) return MKT_OK;
-    (void)hipGetLastError();
+    if (!no_peer) {
+        if (hipMemcpyPeer(d, ddev, s_, sdev, bytes) == hipSuccess) return MKT_OK;
+        (void)hipGetLastError();
+    }
     std::vector<unsigned char> bounce(bytes);
     { DevGuard g(sdev); HIPCHK(dst, hipMemcpy(bounce.data(), s_, bytes, hipMemcpyDeviceToHost)); }
     { DevGuard g(ddev); HIPCHK(dst, hipMemcpy(d, bounce.data(), bytes, hipMemcpyHostToDevice)); }
     return MKT_OK;
 }
-int mkt_internal_clone_keys(mkt_ctx *src, mkt_ctx *dst) {
+int mkt_internal_clone_keys(mkt_ctx *src, mkt_ctx *dst, int no_peer) {
     if (!src || !dst) return MKT_ERR_ARG;
     if (std::memcmp(&src->p, &dst->p, sizeof(mkt_params)) != 0 || src->exact != dst->exact) return fail(dst, MKT_ERR_ARG, "key replication between contexts of different parameters");
     if (dst->keys_shared()) return fail(dst, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
@@ -622,20 +624,24 @@ int mkt_internal_clone_keys(mkt_ctx *src, mkt_ctx *dst) {
     int r;
     // tables a caller may have replaced on src (mkt_set_twiddles), and the monomial table that depends on them
     b.tw = a.tw;
-    if ((r = copy_across(dst, b.d_tw, dd, a.d_tw, sd, (size_t)4 * M * cb))) return r;
-    if ((r = copy_across(dst, b.d_monomial, dd, a.d_monomial, sd, (size_t)2 * N * M * cb))) return r;
-    if ((r = copy_across(dst, b.d_brk, dd, a.d_brk, sd, (size_t)np * a.brk_party_cplx * cb))) return r;
-    if ((r = copy_across(dst, b.d_ksk, dd, a.d_ksk, sd, (size_t)np * a.ksk_party_words * 4))) return r;
+    if ((r = copy_across(dst, b.d_tw, dd, a.d_tw, sd, (size_t)4 * M * cb, no_peer != 0))) return r;
+    if ((r = copy_across(dst, b.d_monomial, dd, a.d_monomial, sd, (size_t)2 * N * M * cb, no_peer != 0))) return r;
+    if ((r = copy_across(dst, b.d_brk, dd, a.d_brk, sd, (size_t)np * a.brk_party_cplx * cb, no_peer != 0))) return r;
+    if ((r = copy_across(dst, b.d_ksk, dd, a.d_ksk, sd, (size_t)np * a.ksk_party_words * 4, no_peer != 0))) return r;
     if (mkt::is_mk(p.scheme)) {
-        if ((r = copy_across(dst, b.d_pub, dd, a.d_pub, sd, (size_t)np * p.l_uni * M * cb * src->split))) return r;
-        if ((r = copy_across(dst, b.d_crs, dd, a.d_crs, sd, (size_t)p.l_uni * M * cb * src->split))) return r;
+        if ((r = copy_across(dst, b.d_pub, dd, a.d_pub, sd, (size_t)np * p.l_uni * M * cb * src->split, no_peer != 0))) return r;
+        if ((r = copy_across(dst, b.d_crs, dd, a.d_crs, sd, (size_t)p.l_uni * M * cb * src->split, no_peer != 0))) return r;
     }
     if (mkt::is_kms(p.scheme)) {
-        if ((r = copy_across(dst, b.d_rlk_d, dd, a.d_rlk_d, sd, (size_t)np * p.l_uni * M * cb * src->split))) return r;
-        if ((r = copy_across(dst, b.d_rlk_f, dd, a.d_rlk_f, sd, (size_t)np * p.l_uni * 2 * M * cb * src->split))) return r;
+        if ((r = copy_across(dst, b.d_rlk_d, dd, a.d_rlk_d, sd, (size_t)np * p.l_uni * M * cb * src->split, no_peer != 0))) return r;
+        if ((r = copy_across(dst, b.d_rlk_f, dd, a.d_rlk_f, sd, (size_t)np * p.l_uni * 2 * M * cb * src->split, no_peer != 0))) return r;
     }
     b.brk_loaded = a.brk_loaded; b.ksk_loaded = a.ksk_loaded; b.rlk_loaded = a.rlk_loaded; b.pub_loaded = a.pub_loaded; b.crs_loaded = a.crs_loaded;
     dst->tune = src->tune;
+    // hipMemcpyPeer may return before the copy has landed, and the shards evaluate on non-blocking streams that the NULL stream does
+    // not order: both devices are drained before the replica may be used (one-time cost, off the evaluation path)
+    { DevGuard g(sd); HIPCHK(dst, hipDeviceSynchronize()); }
+    { DevGuard g(dd); HIPCHK(dst, hipDeviceSynchronize()); }
     return MKT_OK;
 }
 int mkt_internal_device_of(const mkt_ctx *c) { return c ? c->device : -1; }
@@ -871,7 +877,7 @@ static int gate_impl(mkt_ctx *c, int op, const uint8_t *ops, const uint32_t *x, 
         if ((r = ensure_workspace(c, nb))) return r;
         const size_t xoff = pool ? 0 : off * len;
         HIPCHK(c, mktd::launch_gate_linear(op, ops ? (const uint8_t *)sops.dev + off : nullptr, (const uint32_t *)sx.dev + xoff, (const uint32_t *)sy.dev + xoff,
-                                           pool ? (const uint32_t *)six.dev + off : nullptr, pool ? (const uint32_t *)siy.dev + off : nullptr, c->ws_lin, (int)len, nb, c->stream));
+                                           pool ? (const uint32_t *)six.dev + off : nullptr, pool ? (const uint32_t *)siy.dev + off : nullptr, pool ? rows_xy : 0, c->ws_lin, (int)len, nb, c->stream));
         if ((r = bootstrap_chunk(c, c->ws_lin, (uint32_t *)so.dev + off * len, nb))) return r;
     }
     return so.out(out);
@@ -926,8 +932,8 @@ int mkt_mux_batch(mkt_ctx *c, const uint32_t *sel, const uint32_t *a, const uint
         const size_t nb = std::min(HALF, B - off);
         if ((r = ensure_workspace(c, 2 * nb))) return r;
         const uint32_t *ps = (const uint32_t *)ss.dev + off * len;
-        HIPCHK(c, mktd::launch_gate_linear(MKT_AND, nullptr, ps, (const uint32_t *)sa.dev + off * len, nullptr, nullptr, c->ws_lin, (int)len, nb, c->stream));
-        HIPCHK(c, mktd::launch_gate_linear(MKT_AND | MKT_OP_NOT_X, nullptr, ps, (const uint32_t *)sb.dev + off * len, nullptr, nullptr, c->ws_lin + nb * len, (int)len, nb, c->stream));
+        HIPCHK(c, mktd::launch_gate_linear(MKT_AND, nullptr, ps, (const uint32_t *)sa.dev + off * len, nullptr, nullptr, 0, c->ws_lin, (int)len, nb, c->stream));
+        HIPCHK(c, mktd::launch_gate_linear(MKT_AND | MKT_OP_NOT_X, nullptr, ps, (const uint32_t *)sb.dev + off * len, nullptr, nullptr, 0, c->ws_lin + nb * len, (int)len, nb, c->stream));
         if ((r = rotate_chunk(c, c->ws_lin, 2 * nb))) return r;
         HIPCHK(c, mktd::launch_mux_combine(c->p.W, c->ws_acc, nb, words, c->stream));
         if ((r = do_keyswitch(c, c->ws_acc, (uint32_t *)so.dev + off * len, nb))) return r;
@@ -959,7 +965,7 @@ int mkt_mux_batch_gather(mkt_ctx *c, const uint32_t *pool, size_t pool_rows, con
         if ((r = ensure_workspace(c, 2 * nb))) return r;
         const uint32_t *pp = (const uint32_t *)sp.dev, *js = (const uint32_t *)ss.dev + off;
         const uint8_t *fl = not_ab ? (const uint8_t *)sf.dev + off : nullptr;
-        HIPCHK(c, mktd::launch_mux_linear(pp, js, (const uint32_t *)sa.dev + off, (const uint32_t *)sb.dev + off, fl, c->ws_lin, (int)len, nb, c->stream));
+        HIPCHK(c, mktd::launch_mux_linear(pp, pool_rows, js, (const uint32_t *)sa.dev + off, (const uint32_t *)sb.dev + off, fl, c->ws_lin, (int)len, nb, c->stream));
         if ((r = rotate_chunk(c, c->ws_lin, 2 * nb))) return r;
         HIPCHK(c, mktd::launch_mux_combine(c->p.W, c->ws_acc, nb, words, c->stream));
         if ((r = do_keyswitch(c, c->ws_acc, (uint32_t *)so.dev + off * len, nb))) return r;

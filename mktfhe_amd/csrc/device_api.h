@@ -127,9 +127,9 @@ hipError_t launch_reorder(int logM, const cplx *in, cplx *out, size_t npolys, in
 hipError_t launch_transform_inv(int logM, int W, TwPtrs tw, const cplx *t, void *p, size_t B, hipStream_t s);
 hipError_t launch_decompose(int W, const void *p, void *digits, int N, int l, int logB, size_t B, hipStream_t s);
 // ops / ix / iy may be NULL: one op for the batch / operands in batch order (kernels.hip gate_linear_kernel)
-hipError_t launch_gate_linear(int op, const uint8_t *ops, const uint32_t *x, const uint32_t *y, const uint32_t *ix, const uint32_t *iy, uint32_t *out, int len, size_t B, hipStream_t s);
+hipError_t launch_gate_linear(int op, const uint8_t *ops, const uint32_t *x, const uint32_t *y, const uint32_t *ix, const uint32_t *iy, size_t pool_rows, uint32_t *out, int len, size_t B, hipStream_t s);   // pool_rows > 0: ix / iy are clamped into the pool (no out-of-bounds read whatever a device-side index array holds)
 hipError_t launch_negate(uint32_t *x, size_t words, hipStream_t s);
-hipError_t launch_mux_linear(const uint32_t *pool, const uint32_t *is, const uint32_t *ia, const uint32_t *ib, const uint8_t *not_ab, uint32_t *out, int len, size_t B, hipStream_t s);   // [2B][len]: AND(s, a'), then AND(NOT s, b')
+hipError_t launch_mux_linear(const uint32_t *pool, size_t pool_rows, const uint32_t *is, const uint32_t *ia, const uint32_t *ib, const uint8_t *not_ab, uint32_t *out, int len, size_t B, hipStream_t s);   // [2B][len]: AND(s, a'), then AND(NOT s, b')
 hipError_t launch_mux_combine(int W, void *acc, size_t B, size_t words, hipStream_t s);   // acc[j] += acc[B + j], + 2^(W-3) at X^0 of b: [2B][words] -> [B][words]
 hipError_t launch_modswitch(const uint32_t *lwe, uint32_t *atilde, uint32_t *btilde, int len, int logN, size_t B, hipStream_t s);
 hipError_t launch_testvector(int W, const uint32_t *lin, int lwe_stride, int logN, int kacc, void *acc, size_t B, hipStream_t s);

@@ -187,12 +187,16 @@ __global__ void reorder_kernel(const cplx *__restrict__ in, cplx *__restrict__ o
 // folded into the linear part: -x is what NOT! leaves in memory); `ix` / `iy` (optional): row of the x / y operand in a
 // ciphertext pool (a circuit level reads its operands where the earlier levels left them)
 __global__ void gate_linear_kernel(int op_all, const uint8_t *__restrict__ ops, const uint32_t *__restrict__ x, const uint32_t *__restrict__ y,
-                                   const uint32_t *__restrict__ ix, const uint32_t *__restrict__ iy, uint32_t *__restrict__ out, int len, size_t total) {
+                                   const uint32_t *__restrict__ ix, const uint32_t *__restrict__ iy, size_t pool_rows, uint32_t *__restrict__ out, int len, size_t total) {
+    // index arrays in device memory cannot be validated by the host without a copy (mktfhe.h: the caller's precondition); what the
+    // engine guarantees regardless is that no index reads outside the pool: rows are clamped to the last one
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t g = i / len; const int c = (int)(i % len);
         const bool isb = c == len - 1;
         const int code = ops ? ops[g] : op_all;
-        uint32_t a = x[(ix ? (size_t)ix[g] : g) * len + c], b = y[(iy ? (size_t)iy[g] : g) * len + c];
+        size_t ra = ix ? (size_t)ix[g] : g, rb = iy ? (size_t)iy[g] : g;
+        if (pool_rows) { ra = ra < pool_rows ? ra : pool_rows - 1; rb = rb < pool_rows ? rb : pool_rows - 1; }
+        uint32_t a = x[ra * len + c], b = y[rb * len + c];
         if (code & 8) a = 0u - a;
         if (code & 16) b = 0u - b;
         uint32_t r;
@@ -221,15 +225,17 @@ __global__ void mux_combine_kernel(WORD *__restrict__ acc, size_t B, size_t word
 
 // the two AND-linear parts of a level of MUX gates gathered from a pool: out[g] = AND(s, a'), out[B + g] = AND(NOT s, b'), a' / b' = the
 // operand or its negation (flag bits 0 / 1)
-__global__ void mux_linear_kernel(const uint32_t *__restrict__ pool, const uint32_t *__restrict__ is, const uint32_t *__restrict__ ia, const uint32_t *__restrict__ ib,
+__global__ void mux_linear_kernel(const uint32_t *__restrict__ pool, size_t pool_rows, const uint32_t *__restrict__ is, const uint32_t *__restrict__ ia, const uint32_t *__restrict__ ib,
                                   const uint8_t *__restrict__ fl, uint32_t *__restrict__ out, int len, size_t B) {
     const size_t total = B * (size_t)len;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t g = i / len; const int c = (int)(i % len);
         const uint32_t k = c == len - 1 ? (7u << 29) : 0u;                       // AND, gate.jl:10-17
         const int f = fl ? fl[g] : 0;
-        const uint32_t s = pool[(size_t)is[g] * len + c];
-        uint32_t a = pool[(size_t)ia[g] * len + c], b = pool[(size_t)ib[g] * len + c];
+        const size_t last = pool_rows - 1;                                       // rows clamped into the pool (see gate_linear_kernel)
+        const size_t rs = is[g] < pool_rows ? is[g] : last, ra = ia[g] < pool_rows ? ia[g] : last, rb = ib[g] < pool_rows ? ib[g] : last;
+        const uint32_t s = pool[rs * len + c];
+        uint32_t a = pool[ra * len + c], b = pool[rb * len + c];
         if (f & 1) a = 0u - a;
         if (f & 2) b = 0u - b;
         out[i] = k + s + a;
@@ -1486,16 +1492,16 @@ hipError_t launch_decompose(int W, const void *p, void *digits, int N, int l, in
     return hipGetLastError();
 }
 
-hipError_t launch_gate_linear(int op, const uint8_t *ops, const uint32_t *x, const uint32_t *y, const uint32_t *ix, const uint32_t *iy, uint32_t *out, int len, size_t B, hipStream_t s) {
+hipError_t launch_gate_linear(int op, const uint8_t *ops, const uint32_t *x, const uint32_t *y, const uint32_t *ix, const uint32_t *iy, size_t pool_rows, uint32_t *out, int len, size_t B, hipStream_t s) {
     const size_t total = B * (size_t)len;
     if (!total) return hipSuccess;
-    hipLaunchKernelGGL(gate_linear_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, op, ops, x, y, ix, iy, out, len, total);
+    hipLaunchKernelGGL(gate_linear_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, op, ops, x, y, ix, iy, pool_rows, out, len, total);
     return hipGetLastError();
 }
 
-hipError_t launch_mux_linear(const uint32_t *pool, const uint32_t *is, const uint32_t *ia, const uint32_t *ib, const uint8_t *fl, uint32_t *out, int len, size_t B, hipStream_t s) {
-    if (!B) return hipSuccess;
-    hipLaunchKernelGGL(mux_linear_kernel, dim3(blocks_for(B * (size_t)len, 256)), dim3(256), 0, s, pool, is, ia, ib, fl, out, len, B);
+hipError_t launch_mux_linear(const uint32_t *pool, size_t pool_rows, const uint32_t *is, const uint32_t *ia, const uint32_t *ib, const uint8_t *fl, uint32_t *out, int len, size_t B, hipStream_t s) {
+    if (!B || !pool_rows) return hipSuccess;
+    hipLaunchKernelGGL(mux_linear_kernel, dim3(blocks_for(B * (size_t)len, 256)), dim3(256), 0, s, pool, pool_rows, is, ia, ib, fl, out, len, B);
     return hipGetLastError();
 }
 

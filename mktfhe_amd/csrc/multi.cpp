@@ -32,6 +32,7 @@ struct mkt_multi {
     std::vector<mkt_ctx *> ctx;        // per shard; ctx[i] is a root context for the first shard of a device, a fork otherwise
     std::vector<int> root_of;          // per shard: index of the first shard on the same device
     bool stage_always = false;         // MKT_MULTI_STAGE_ALWAYS
+    bool no_peer = false;              // MKT_MULTI_NO_PEER: every device-to-device copy goes through a host buffer (what happens where hipMemcpyPeer is refused)
     bool sealed = false;               // keys replicated, logical shards forked
     std::string err;
     // staging buffers of the shards whose device is not the one a device-resident argument lives on: [shard][argument slot],
@@ -71,8 +72,22 @@ struct ShardArg {
     void *stage = nullptr;
     size_t bytes = 0;
     int dev = 0, remote_dev = 0;
-    bool copy_back = false;
-    int prepare(const void *base, size_t row_bytes, size_t lo, size_t hi, int mem, int shard_dev, bool in, bool out, mkt_multi::Stage &pool, bool always) {
+    bool copy_back = false, no_peer = false;
+    // device -> device: a peer copy (xGMI where the devices are linked), through a host buffer where that is refused or switched off
+    static int across(void *d, int ddev, const void *s, int sdev, size_t n, bool no_peer) {
+        if (!no_peer) {
+            if (hipMemcpyPeer(d, ddev, s, sdev, n) == hipSuccess) return hipStreamSynchronize(nullptr) == hipSuccess ? 0 : -1;
+            (void)hipGetLastError();
+        }
+        std::vector<unsigned char> bounce(n);
+        int cur = 0; (void)hipGetDevice(&cur);
+        bool ok = hipSetDevice(sdev) == hipSuccess && hipMemcpy(bounce.data(), s, n, hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && hipSetDevice(ddev) == hipSuccess && hipMemcpy(d, bounce.data(), n, hipMemcpyHostToDevice) == hipSuccess;
+        (void)hipSetDevice(cur);
+        return ok ? 0 : -1;
+    }
+    int prepare(const void *base, size_t row_bytes, size_t lo, size_t hi, int mem, int shard_dev, bool in, bool out, mkt_multi::Stage &pool, bool always, bool nopeer = false) {
+        no_peer = nopeer;
         dev = shard_dev;
         bytes = (hi - lo) * row_bytes;
         char *rows = (char *)const_cast<void *>(base) + lo * row_bytes;
@@ -87,13 +102,13 @@ struct ShardArg {
             pool.cap = bytes;
         }
         stage = pool.p;
-        if (in && (hipMemcpyPeer(stage, dev, remote, remote_dev, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)) return -1;   // the shard's own stream is non-blocking: the copy must have landed before its kernels start
+        if (in && across(stage, dev, remote, remote_dev, bytes, no_peer) != 0) return -1;   // the shard's own stream is non-blocking: the copy must have landed before its kernels start
         use = stage;
         return 0;
     }
     int finish() {
         int rc = 0;
-        if (stage && copy_back && (hipMemcpyPeer(remote, remote_dev, stage, dev, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)) rc = -1;
+        if (stage && copy_back && across(remote, remote_dev, stage, dev, bytes, no_peer) != 0) rc = -1;
         stage = nullptr;                       // the buffer stays with the shard (mkt_multi::stage)
         return rc;
     }
@@ -150,7 +165,7 @@ int sharded_call(mkt_multi *m, size_t B, int mem, const std::vector<ArgSpec> &sp
         int rc = MKT_OK;
         if (m->stage[s].size() < specs.size()) m->stage[s].resize(specs.size());     // this shard's thread only
         for (size_t i = 0; i < specs.size(); i++) {
-            if (args[i].prepare(specs[i].base, specs[i].row_bytes, lo, hi, mem, m->devices[s], specs[i].in, specs[i].out, m->stage[s][i], m->stage_always) != 0) { rc = MKT_ERR_HIP; why = "staging a remote device buffer failed"; }
+            if (args[i].prepare(specs[i].base, specs[i].row_bytes, lo, hi, mem, m->devices[s], specs[i].in, specs[i].out, m->stage[s][i], m->stage_always, m->no_peer) != 0) { rc = MKT_ERR_HIP; why = "staging a remote device buffer failed"; }
             ptrs[i] = args[i].use;
         }
         if (rc == MKT_OK) {
@@ -170,10 +185,10 @@ extern "C" {
 const char *mkt_multi_last_error(const mkt_multi *m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
 
 int mkt_multi_create(const mkt_params *params, int arith_mode, const int *devices, int nshards, int flags, mkt_multi **out) {
-    if (!params || !devices || !out || nshards < 1 || nshards > 1024 || (flags & ~(MKT_MULTI_PRIVATE_KEYS | MKT_MULTI_STAGE_ALWAYS))) return mfail(nullptr, MKT_ERR_ARG, "bad argument");
+    if (!params || !devices || !out || nshards < 1 || nshards > 1024 || (flags & ~(MKT_MULTI_PRIVATE_KEYS | MKT_MULTI_STAGE_ALWAYS | MKT_MULTI_NO_PEER))) return mfail(nullptr, MKT_ERR_ARG, "bad argument");
     *out = nullptr;
     auto *m = new mkt_multi();
-    m->p = *params; m->arith = arith_mode; m->stage_always = (flags & MKT_MULTI_STAGE_ALWAYS) != 0;
+    m->p = *params; m->arith = arith_mode; m->stage_always = (flags & MKT_MULTI_STAGE_ALWAYS) != 0; m->no_peer = (flags & MKT_MULTI_NO_PEER) != 0;
     m->devices.assign(devices, devices + nshards);
     m->ctx.assign((size_t)nshards, nullptr);
     m->root_of.assign((size_t)nshards, -1);
@@ -228,7 +243,7 @@ int mkt_multi_replicate(mkt_multi *m) {
     const int n = (int)m->ctx.size();
     for (int s = 1; s < n; s++) {
         if (m->root_of[s] != s) continue;
-        const int rc = mkt_internal_clone_keys(m->ctx[0], m->ctx[s]);
+        const int rc = mkt_internal_clone_keys(m->ctx[0], m->ctx[s], m->no_peer ? 1 : 0);
         if (rc != MKT_OK) return mfail(m, rc, std::string("replicating keys to device ") + std::to_string(m->devices[s]) + ": " + mkt_last_error(m->ctx[s]));
     }
     for (int s = 0; s < n; s++) {

@@ -28,47 +28,83 @@ def shard_slices(B, world):
 
 
 ACTIVE_BACKEND = None      # what init_process_group ended up with ("nccl" = RCCL on ROCm, or "gloo")
+_VERDICTS = None           # the agreement store stays alive for the life of the process: rank 0 serves it, the other ranks may still be reading it
 
 
-def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900):
+def _agree(store, rank, world, stage, ok, wait_s):
+    """every rank publishes whether `stage` worked for it and reads every other rank's verdict: the ranks switch backend together or
+    not at all (a rank that fell back alone would leave the others waiting in RCCL until their collective timeout)"""
+    import datetime
+    store.set(f"mkt/{stage}/{rank}", "1" if ok else "0")
+    keys = [f"mkt/{stage}/{r}" for r in range(world)]
+    store.wait(keys, datetime.timedelta(seconds=wait_s))          # raises after wait_s: a loud error instead of a 900 s hang
+    return all(store.get(k) == b"1" for k in keys)
+
+
+def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900, agree_s=180):
     """Rendezvous of the ranks (nothing on the data path: gates shard with no collective).  backend "nccl" is RCCL; it is
-    PROVED with one tiny all-reduce right away, and if creating or proving it fails on every rank -- no peer access between
-    the visible devices, an IPC mode the host driver refuses -- the ranks fall back to `fallback` (gloo over TCP, CPU
-    tensors) instead of losing the run: the barrier, the max-over-ranks and the census are all it carries."""
+    PROVED with one tiny all-reduce right away, and if creating or proving it fails on ANY rank -- no peer access between the
+    visible devices, an IPC mode the host driver refuses -- ALL ranks fall back to `fallback` (gloo over TCP, CPU tensors)
+    instead of losing the run: the barrier, the max-over-ranks and the census are all it carries.  The outcome of each stage
+    (communicator created; probe all-reduce correct) is agreed through a small TCP store of its own (MASTER_PORT + 2) before any
+    rank acts on it, and nobody enters the probe collective unless every rank holds a communicator.  What this cannot shorten is a
+    rank that never ARRIVES at a collective (creation and the probe are collectives themselves): the others then wait out `timeout_s`."""
     import datetime
     import sys
     import torch
     import torch.distributed as dist
-    global ACTIVE_BACKEND
+    global ACTIVE_BACKEND, _VERDICTS
     rank, world, local = env()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or "nccl"
         to = datetime.timedelta(seconds=timeout_s)
+        port = int(os.environ["MASTER_PORT"])
+        verdicts = None
+        if fallback:                                       # (fallback == backend: one retry of the same backend on a fresh store)
+            verdicts = _VERDICTS = dist.TCPStore(os.environ["MASTER_ADDR"], port + 2, world, rank == 0, datetime.timedelta(seconds=agree_s))
+        why = None
         try:
             kw = {}
             if backend == "nccl" and device is not None:
                 kw["device_id"] = device
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=to, **kw)
-            if backend == "nccl":
-                probe = torch.ones(1, device=device if device is not None else "cuda")
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                assert int(probe.item()) == world
         except Exception as e:      # noqa: BLE001
-            if not fallback or fallback == backend:
+            if verdicts is None:
                 raise
-            sys.stderr.write(f"mktfhe_amd.distributed: rank {rank}: backend {backend} failed ({type(e).__name__}: {str(e)[:200]}); falling back to {fallback}\n")
+            why = e
+        ok = why is None if verdicts is None else _agree(verdicts, rank, world, "created", why is None, agree_s)
+        lone = os.environ.get("MKT_DIST_TEST_FAIL_RANKS", "")     # test hook: the probe of these ranks fails AFTER its collective (a local fault)
+        if ok and (backend == "nccl" or lone):
+            try:
+                probe = torch.ones(1, device=(device if device is not None else "cuda") if backend == "nccl" else "cpu")
+                dist.all_reduce(probe)
+                if backend == "nccl":
+                    torch.cuda.synchronize()
+                assert int(probe.item()) == world
+                if str(rank) in lone.split(","):
+                    raise RuntimeError("simulated local failure on this rank only")
+            except Exception as e:  # noqa: BLE001
+                if verdicts is None:
+                    raise
+                why = e
+            if verdicts is not None:
+                ok = _agree(verdicts, rank, world, "proved", why is None, agree_s)
+        if not ok:
+            sys.stderr.write(f"mktfhe_amd.distributed: rank {rank}: backend {backend} unusable on at least one rank"
+                             f"{'' if why is None else f' (here: {type(why).__name__}: {str(why)[:200]})'}; all ranks fall back to {fallback}\n")
             try:
                 if dist.is_initialized():
                     dist.destroy_process_group()
             except Exception:       # noqa: BLE001
                 pass
-            os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)      # a fresh store: every rank takes the same step
+            os.environ["MASTER_PORT"] = str(port + 1)      # a fresh store: every rank takes the same step
             backend = fallback
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=to)
         ACTIVE_BACKEND = backend
+        if verdicts is not None:
+            dist.barrier()                                 # nobody leaves (and rank 0 may not exit) while another rank still reads the verdicts
     return rank, world, local
 
 

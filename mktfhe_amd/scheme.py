@@ -520,13 +520,13 @@ class MultiScheme:
     replicated device-to-device, every shard writing its slice of the caller's one output array.  No collective.  Same batch
     methods as Scheme; arrays are host numpy arrays or GPU tensors on ANY of the devices."""
 
-    def __init__(self, params: Params, devices, arith=ARITH_F64REF, private_keys=False, stage_always=False):
+    def __init__(self, params: Params, devices, arith=ARITH_F64REF, private_keys=False, stage_always=False, no_peer=False):
         """private_keys: shards that share a device each get their own replicated key copy (MKT_MULTI_PRIVATE_KEYS: the
         device-to-device replication path, testable on one GPU) instead of sharing that device's one key set"""
         self.params, self.devices, self.arith = params, list(devices), arith
         h = C.c_void_p()
         arr = (C.c_int * len(self.devices))(*self.devices)
-        code = _lib.lib().mkt_multi_create(C.byref(params.c()), arith, arr, len(self.devices), (1 if private_keys else 0) | (2 if stage_always else 0), C.byref(h))
+        code = _lib.lib().mkt_multi_create(C.byref(params.c()), arith, arr, len(self.devices), (1 if private_keys else 0) | (2 if stage_always else 0) | (4 if no_peer else 0), C.byref(h))
         if code < 0:
             raise MktError(code, (_lib.lib().mkt_multi_last_error(None) or b"").decode())
         self.h = h
@@ -664,10 +664,10 @@ class MultiScheme:
         return out
 
 
-def setup_multi(params: Params, devices, keys=None, a=None, arith=ARITH_F64REF, private_keys=False, stage_always=False):
+def setup_multi(params: Params, devices, keys=None, a=None, arith=ARITH_F64REF, private_keys=False, stage_always=False, no_peer=False):
     """setup (scheme.jl:151 / :190 / :244 / :292 / :343) for a MultiScheme: evaluation keys uploaded (or, for keys made with
     secrets_only=True, generated) once on devices[0], pre-transformed there and replicated to the other devices"""
-    sch = MultiScheme(params, devices, arith=arith, private_keys=private_keys, stage_always=stage_always)
+    sch = MultiScheme(params, devices, arith=arith, private_keys=private_keys, stage_always=stage_always, no_peer=no_peer)
     if params.multikey:
         sch.load_crs(a)
         klist = list(keys)

@@ -79,6 +79,34 @@ def test_rendezvous_falls_back_to_gloo_when_rccl_cannot_start():
     assert ret["backend"] == "gloo" and ret["sum"] == 2.0
 
 
+def _lone_failure_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      MKT_DIST_TEST_FAIL_RANKS="1")
+    sys.path.insert(0, ROOT)
+    from mktfhe_amd import distributed as D
+    D.init_process_group("gloo", device=None, fallback="gloo", agree_s=60)     # rank 1's probe fails locally, rank 0's succeeds
+    t = torch.ones(1)
+    torch.distributed.all_reduce(t)
+    ret[rank] = (D.ACTIVE_BACKEND, float(t.item()), os.environ["MASTER_PORT"])
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_ranks_agree_before_switching_backend_when_only_one_of_them_failed():
+    """one rank's probe of the first process group fails locally, the other's succeeds: the verdicts are exchanged first, so BOTH move to
+    the fallback group on the fresh store (a rank that switched alone would leave the other waiting in a collective until its timeout)"""
+    world, port = 2, 29700 + (os.getpid() % 90)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_lone_failure_worker, args=(r, world, port, ret)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(180)
+        assert pr.exitcode == 0
+    assert ret[0] == ret[1] == ("gloo", 2.0, str(port + 1))
+
+
 def test_shard_slices():
     from mktfhe_amd.distributed import shard_slices
     assert shard_slices(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]

@@ -105,7 +105,8 @@ def test_wrong_decryptions_of_a_large_kms_batch_are_the_reference_arithmetic(req
     (5 of 16 384 in round 4: 3e-4 per gate, where the Gaussian its sigma predicts gives 5e-6 -- the output noise of the Float64 path on
     the 64-bit ring is heavier-tailed, and it is the noise of a gate's INPUTS that decides its decryption).  Those are not engine
     defects: every wrongly decrypting gate (and a sample of the others) is the oracle's output word for word; the same pipeline in the
-    EXACT arithmetic decrypts every gate.  Bounds the Float64 rate at 3x the measured one (bench.py NOISY_SETS)."""
+    EXACT arithmetic decrypts every gate.  The count is held to 3x the rate measured in the reference's arithmetic (bench.py
+    REFERENCE_ARITH_FAILURE) -- a band that applies only because the wrong gates are first shown to be the oracle's words."""
     import torch
     sys.path.insert(0, ROOT)
     import bench as BN
@@ -116,11 +117,12 @@ def test_wrong_decryptions_of_a_large_kms_batch_are_the_reference_arithmetic(req
     out = mk.NAND(x, y, sch).cpu().numpy().view(np.uint32)
     want = ~(bits[:B] & bits[B:])
     wrong = np.flatnonzero(mk.lwe_decrypt(out, keys, p) != want)
-    assert len(wrong) <= BN.allowed_wrong(p.name, B), f"{len(wrong)} wrong decryptions of {B}"
-    pick = np.unique(np.concatenate([wrong, np.arange(0, B, B // 8)]))[:24]
+    assert len(wrong) <= 48, f"{len(wrong)} wrong decryptions of {B}"
+    pick = np.unique(np.concatenate([wrong, np.arange(0, B, B // 8)]))[:64]
     so = oracle_scheme(p, crs, keys)
     xh, yh = x.cpu().numpy().view(np.uint32), y.cpu().numpy().view(np.uint32)
-    assert np.array_equal(out[pick], so.gate_batch(0, xh[pick], yh[pick], threads=min(16, len(pick))))
+    assert np.array_equal(out[pick], so.gate_batch(0, xh[pick], yh[pick], threads=min(16, len(pick))))     # every wrong gate is the oracle's gate
+    assert len(wrong) <= BN.allowed_wrong(p.name, B, verified=True), f"{len(wrong)} wrong decryptions of {B}"
     sch.close()
     Be = 4096
     _, _, ex = BN.make_scheme(mk, p, 0, False, mk.ARITH_EXACT)

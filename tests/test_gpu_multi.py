@@ -8,10 +8,13 @@
   device, so the shards are LOGICAL shards of device 0: forked contexts over one key set (the default), or -- with
   private_keys=True -- one replicated key copy per shard, which runs the device-to-device replication path.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
-from helpers import GATE_FUNCS, O, encrypt_bits, gpu_scheme, keygen, mk, oracle_scheme
+from helpers import GATE_FUNCS, O, ROOT, encrypt_bits, gpu_scheme, keygen, mk, oracle_scheme
 
 pytestmark = pytest.mark.gpu
 
@@ -422,3 +425,61 @@ def test_baseline_multi_gpu_configs_at_full_batch_on_eight_logical_shards(requir
     assert np.array_equal(multi.gate(0, x[sub], y[sub]), out[sub])
     assert np.array_equal(multi.gate(0, x, y), out)
     multi.close()
+
+
+# ---- first contact with a multi-GPU node, rehearsed on one GPU ----
+def _bench_line(args, env_extra, timeout):
+    import json, subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--no-cpu-baseline", "--no-roofline", "--no-secondary"],
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_rendezvous_on_a_shared_gpu(require_gpu):
+    """the driver's 8-GPU command shape -- `bench.py --gpus 8` -- with all eight ranks on this box's one GPU: eight processes, eight ports'
+    worth of rendezvous, the store time-outs, the census all-reduce (ranks_seen == 8) and the per-rank step times"""
+    j = _bench_line(["--gpus", "8", "--steps", "1", "--warmup", "1", "--batch", "16", "--workload", "cggi"], dict(MKT_BENCH_SHARE_GPU="1", MKT_BENCH_BACKEND="gloo"), 1500)
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == 8 and len(j["per_rank_ms_per_step"]) == 8 and all(v > 0 for v in j["per_rank_ms_per_step"])
+    assert j["config"]["batch_total"] == 8 * 16 and j["decrypt_checked"] == 8 * 16 and j["decrypt_errors"] == 0
+    assert abs(j["value"] - 8 * 16 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+
+
+@pytest.mark.gpu
+def test_bench_inproc_launcher_eight_shards_strong_scaling(require_gpu):
+    """BASELINE configs[2]'s shape through the ONE-process launcher: `--launcher inproc --gpus 8 --scaling strong --workload kms4party --batch 64`
+    (eight logical shards of this box's one GPU, eight gates each)"""
+    j = _bench_line(["--gpus", "8", "--launcher", "inproc", "--scaling", "strong", "--workload", "kms4party", "--batch", "64", "--steps", "1", "--warmup", "0"],
+                    dict(MKT_BENCH_SHARE_GPU="1"), 1500)
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == 8 and j["scaling"] == "strong" and len(j["per_rank_ms_per_step"]) == 8
+    assert j["config"]["batch_total"] == 64 and j["config"]["batch_per_gpu"] == 8 and j["decrypt_checked"] == 64 and j["decrypt_ok"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", [mk.ARITH_F64REF, mk.ARITH_EXACT], ids=["f64ref", "exact"])
+def test_eight_shards_with_keys_replicated_through_the_host(require_gpu, arith):
+    """mkt_multi_create over eight logical shards with every device-to-device copy forced through a host buffer (MKT_MULTI_NO_PEER: the path
+    the engine takes by itself where hipMemcpyPeer is refused), each shard holding its OWN replica of the key set and device arrays
+    travelling through the shards' staging buffers: word-identical to one context, in host and in device memory, ragged split included"""
+    import torch
+    p = mk.KMS2party.scaled(n=12, N=512)
+    crs, keys = keygen(p, 61)
+    single = gpu_scheme(p, crs, keys, arith=arith)
+    multi = mk.setup_multi(p, [0] * 8, keys=keys, a=crs, arith=arith, private_keys=True, stage_always=True, no_peer=True)
+    assert multi.nshards == 8
+    rng = np.random.default_rng(62)
+    for B in (19, 8, 3):
+        bits = rng.integers(0, 2, 2 * B).astype(bool)
+        c = encrypt_bits(p, keys, bits, seed=6200 + B)
+        x, y = c[:B], c[B:]
+        want = single.gate(0, x, y)
+        assert np.array_equal(multi.gate(0, x, y), want), (B, "host")
+        xd, yd = torch.from_numpy(x.view(np.int32)).cuda(), torch.from_numpy(y.view(np.int32)).cuda()
+        assert np.array_equal(multi.gate(0, xd, yd).cpu().numpy().view(np.uint32), want), (B, "device")
+        assert np.array_equal(mk.lwe_decrypt(want, keys, p), ~(bits[:B] & bits[B:]))
+    multi.close(); single.close()
