@@ -133,7 +133,10 @@ def profiled_counters(kernel_prefix, workload, want=("FETCH_SIZE", "WRITE_SIZE")
         if int(re.match(r"r(\d+)", os.path.basename(f)).group(1)) != newest:     # earlier rounds profiled other kernels
             continue
         rows = {}
+        bid = None
         for ln in open(f):
+            if ln.startswith("# build_id:"):                 # which library these passes measured (tools/pmc_pass.sh)
+                bid = ln.split()[2]
             if not (ln.startswith(kernel_prefix + ",") or ln.startswith(kernel_prefix + ">")):   # `kernel<first template argument`
                 continue
             parts = ln.rsplit(",", 5)          # kernel, grid, counter, mean, ms, n
@@ -144,12 +147,35 @@ def profiled_counters(kernel_prefix, workload, want=("FETCH_SIZE", "WRITE_SIZE")
             if not all(w in r for w in want):
                 continue
             if near_ms is None:
-                best = (r, os.path.relpath(f, ROOT), grid)
+                best = (r, os.path.relpath(f, ROOT), bid)
             else:
                 err = abs(r["ms:" + want[0]] / near_ms - 1.0)
                 if err <= 0.30 and (best_err is None or err <= best_err + 0.02):    # newer rounds win ties
-                    best, best_err = (r, os.path.relpath(f, ROOT), grid), err
+                    best, best_err = (r, os.path.relpath(f, ROOT), bid), err
     return best
+
+
+def attach_profile(r, prof, achieved=None, peak=None):
+    """profile-derived fields of a roofline object -- only when the committed passes measured THE LIBRARY THIS PROCESS HAS LOADED (same
+    mkt_build_id: same kernel sources and flags); otherwise traffic stays null and the line says the profile is stale"""
+    if not prof:
+        return r
+    c, src, bid = prof
+    import mktfhe_amd as mk
+    r["traffic_source"] = src
+    if bid is None or bid != mk.build_id():
+        r["traffic_stale"] = True
+        r["traffic_stale_note"] = f"profile build_id {bid}, loaded library {mk.build_id()}: numbers of another build are not quoted"
+        return r
+    r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0     # gfx950: FETCH_SIZE counts half (guide, HBM section)
+    r["traffic_build_id"] = bid
+    if achieved is not None and "GRBM_GUI_ACTIVE" in c:       # sum over the 8 XCDs / 8 / duration = the clock the part held under this kernel
+        ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["ms:GRBM_GUI_ACTIVE"] * 1e-3) / 1e9
+        r["sustained_clock_ghz"] = ghz
+        r["frac_at_sustained_clock"] = achieved / (peak * ghz / 2.4)
+    if achieved is not None and "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c:
+        r["valu_active_per_wave_cycle"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
+    return r
 
 
 def effective_cpus():
@@ -330,17 +356,12 @@ def rot_roofline(mk, p, B, t, workload, kern=None, variant=None):
          "peak_note": "256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz, mul and add issued separately (no FMA: bit parity)"}
     # the kernel's first template argument is log2 M: the row of THIS transform size (a profile may also hold the secondary leg's)
     prof = profiled_counters(f"mktd::{kern}<{int(np.log2(p.N // 2))}", "kms2_n1024" if workload == "adder8" else workload, want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms, variant=variant)
-    if prof:
-        c, src, _ = prof
-        r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0     # gfx950: FETCH_SIZE counts half (guide, HBM section)
-        r["traffic_source"] = src
-        if "GRBM_GUI_ACTIVE" in c:       # sum over the 8 XCDs / 8 / duration = the clock the part held under this kernel
-            ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["ms:GRBM_GUI_ACTIVE"] * 1e-3) / 1e9
-            r["sustained_clock_ghz"] = ghz
-            r["frac_at_sustained_clock"] = achieved / (PEAK_F64_NOFMA_TFLOPS * ghz / 2.4)
-        if "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c:
-            r["valu_active_per_wave_cycle"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
-    return r
+    return attach_profile(r, prof, achieved, PEAK_F64_NOFMA_TFLOPS)
+
+
+# VALU instructions per thread and polynomial of the batched integer transforms' loops (slow class, fast class), from the ISA of this build
+NTT_LEG_INSTR = {("forward", 1024, 64): (482, 297), ("inverse", 1024, 64): (530, 391), ("forward", 1024, 32): (416, 281), ("inverse", 1024, 32): (520, 384),
+                 ("forward", 2048, 64): (515, 312), ("inverse", 2048, 64): (567, 419), ("forward", 2048, 32): (447, 295), ("inverse", 2048, 32): (555, 412)}
 
 
 def transform_roofline(mk, torch, local, dev):
@@ -382,16 +403,21 @@ def transform_roofline(mk, torch, local, dev):
                     else:
                         kern = "ntt_fwd_kernel" if direction == "forward" else "ntt_inv_kernel"
                         prefix = f"mktd::{kern}<{int(np.log2(N))}, unsigned {'long' if W == 64 else 'int'}"
-                        e = {"bound": "hbm", "kernel": kern, "arith": "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)",
-                             "bound_note": "integer issue, not HBM: VALU ~0.95 busy per SIMD (profiles/r03_ntt_pmc.txt)"}
+                        # these legs are bound by integer ISSUE, not by HBM: VALU instructions of the kernel's loop per thread and polynomial
+                        # (8 points; slow class = multiplies, v_min, three-operand and carry forms at 4.43 cycles per wave instruction and
+                        # SIMD, fast class = add / sub / logic / moves at 2.38: tools/int_probe.hip, profiles/r05_int_probe.txt), counted in the
+                        # ISA of this build (tools/kres_ntt.sh + tools/isa_hist.py --loop)
+                        slow, fast = NTT_LEG_INSTR[(direction, N, W)]
+                        cyc_poly = (slow * 4.43 + fast * 2.38) * (N // 512)              # one wave carries 512 points
+                        issue_peak = 256 * 4 * 2.4e9 / cyc_poly * per / 1e9              # GB/s of algorithmic bytes at which the VALU is full (2.4 GHz)
+                        e = {"bound": "int32-valu-issue", "kernel": kern, "arith": "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)",
+                             "issue_roofline": {"peak": issue_peak, "unit": "GB/s", "frac": achieved / issue_peak, "valu_instr_per_thread_and_polynomial": {"slow_class": slow, "fast_class": fast},
+                                                "peak_note": "1024 SIMDs x 2.4 GHz / (slow x 4.43 + fast x 2.38 cycles per 512 points) x algorithmic bytes per polynomial; the part holds 1.6-1.8 GHz under these kernels (profiles/r03_ntt_pmc.txt)"},
+                             "bound_note": "integer issue, not HBM: `frac` stays the BASELINE metric (achieved / 8 TB/s), `issue_roofline.frac` is the distance from this kernel's own bound"}
                     e.update({"direction": direction, "N": N, "ring_bits": W, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                               "traffic": None, "algorithmic_bytes_per_launch": nb * per, "bytes_per_transform": per, "transforms_per_launch": nb, "avg_launch_ms": ms / cnt})
                     prof = profiled_counters(prefix, "kms2_n1024")      # the headline workload's PMC passes include these legs
-                    if prof:
-                        c, src, _ = prof
-                        e["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-                        e["traffic_source"] = src
-                    out.append(e)
+                    out.append(attach_profile(e, prof))
                 s.close()
             del polys, tr, back
             torch.cuda.empty_cache()
@@ -466,17 +492,7 @@ def exact_rot_roofline(mk, p, B, t, kern, workload):
          "algorithmic_instr_per_launch": instr / launches_per_step, "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
          "peak_note": "256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 3.6 cycles per wave instruction (60 % multiply-class at 4.4, 40 % at 2.5: tools/valu_probe.hip)"}
     prof = profiled_counters(f"mktd::{kern}<{lg}", workload + "_exact", want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms)
-    if prof:
-        c, src, _ = prof
-        r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-        r["traffic_source"] = src
-        if "GRBM_GUI_ACTIVE" in c:
-            ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["ms:GRBM_GUI_ACTIVE"] * 1e-3) / 1e9
-            r["sustained_clock_ghz"] = ghz
-            r["frac_at_sustained_clock"] = ach / (peak * ghz / 2.4)
-        if "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c:
-            r["valu_active_per_wave_cycle"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
-    return r
+    return attach_profile(r, prof, ach, peak)
 
 
 def run_circuit(mk, torch, p, keys, sch, args, dev, flat_rate):

@@ -105,6 +105,9 @@ typedef struct mkt_client_party mkt_client_party;   /* one party's keys (client 
 /* ---- context: replaces the scheme object (scheme.jl:107-116 ...), FFTransformer (fft.jl:18-45)
  *      and getmonomial (scheme.jl:121-146), all built on device `device`. ---- */
 int mkt_abi_version(void);
+/* which source tree this library was built from: 16 hex digits of the SHA-256 over the engine's sources and build flags (csrc/Makefile).
+ * Measurement bookkeeping only: profiles record it, bench.py quotes profile-derived numbers only for the library that produced them */
+const char *mkt_build_id(void);
 int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx **out);
 int mkt_ctx_destroy(mkt_ctx *ctx);
 /* a second context over the SAME resident keys and tables (no copy; freed with the last context that holds them; both

@@ -11,6 +11,6 @@ from .scheme import (  # noqa: F401
     bootstrapping_, blindrotate_, keyswitch, NAND, AND, OR, XOR, XNOR, NOR, NOT_, MUX, MUX_composite,
     MEM_DEVICE, MEM_HOST, FMT_INT_COEFF, FMT_F64_FFT, ARITH_F64REF, ARITH_EXACT,
 )
-from ._lib import MktError, LIB_PATH  # noqa: F401
+from ._lib import MktError, LIB_PATH, build_id  # noqa: F401
 from . import keyblob  # noqa: F401,E402
 from . import circuit  # noqa: F401,E402

@@ -29,6 +29,7 @@ _vp, _i, _sz, _u64, _dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.c_doub
 _pp = C.POINTER(MktParams)
 SYMBOLS = {
     "mkt_abi_version": (_i, []),
+    "mkt_build_id": (C.c_char_p, []),
     "mkt_ctx_create": (_i, [_pp, _i, _i, C.POINTER(_vp)]),
     "mkt_ctx_destroy": (_i, [_vp]),
     "mkt_ctx_fork": (_i, [_vp, C.POINTER(_vp)]),
@@ -132,6 +133,11 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+def build_id():
+    """which source tree the loaded library was built from (csrc/Makefile BUILD_ID): what profiles are matched against"""
+    return lib().mkt_build_id().decode()
 
 
 def check(code, ctx=None):

@@ -644,6 +644,10 @@ int mkt_internal_clone_keys(mkt_ctx *src, mkt_ctx *dst, int no_peer) {
     { DevGuard g(dd); HIPCHK(dst, hipDeviceSynchronize()); }
     return MKT_OK;
 }
+#ifndef MKT_BUILD_ID
+#define MKT_BUILD_ID "unknown"
+#endif
+const char *mkt_build_id(void) { return MKT_BUILD_ID; }
 int mkt_internal_device_of(const mkt_ctx *c) { return c ? c->device : -1; }
 size_t mkt_internal_lwe_len(const mkt_ctx *c) { return c ? (size_t)c->sh.lwe_len : 0; }
 size_t mkt_internal_acc_bytes(const mkt_ctx *c) { return c ? (size_t)(1 + c->sh.kacc) * poly_bytes(c) : 0; }

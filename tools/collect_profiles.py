@@ -16,6 +16,9 @@ dirs = sorted(d for d in glob.glob(f"{src}/pmc_{wl}_*") if os.path.basename(d)[l
 if dirs:
     with open(f"{dst}/{tag}_bench_{wl}_pmc.txt", "w") as out:
         out.write(f"# rocprofv3 --kernel-trace --pmc <counters> (separate passes), python3 bench.py --steps 2 --warmup 0 --workload {wl} --no-cpu-baseline --no-secondary\n")
+        meta = dict(l.strip().split(" ", 1) for l in open(f"{src}/pmc_{wl}_meta.txt") if " " in l.strip()) if os.path.exists(f"{src}/pmc_{wl}_meta.txt") else {}
+        git = os.popen("git rev-parse --short HEAD 2>/dev/null").read().strip() + ("+dirty" if os.popen("git status --porcelain -- mktfhe_amd include 2>/dev/null").read().strip() else "")
+        out.write(f"# build_id: {meta.get('build_id', 'unknown')}  so_sha256: {meta.get('so_sha256', 'unknown')}  device: {meta.get('device', 'unknown')}  git (at collection): {git}\n")
         out.write("# FETCH_SIZE / WRITE_SIZE unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of a coalesced read stream -> x2.\n")
         out.write("# kernel, grid, counter, mean value over the full-work dispatches (within 15 % of the longest of that kernel and grid), mean duration ms, dispatches\n")
         for d in dirs:

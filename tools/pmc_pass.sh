@@ -9,6 +9,13 @@ if [ "$1" = -- ]; then shift; fi
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
 ARGS="--workload $WL --no-cpu-baseline --no-secondary ${NOROOF---no-roofline} $*"     # NOROOF= (set, empty) keeps the transform legs in the profiled command
 run() { timeout 400 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/pmc_${NAME}_$1 -- python3 $R/bench.py --steps 2 --warmup 0 $ARGS > /dev/null 2>&1; }
+# which library and device these passes measured (tools/collect_profiles.py copies it into the summary's header; bench.py quotes the summary
+# only when the library it has loaded carries the same build id)
+python3 -c "
+import sys, hashlib; sys.path.insert(0, '$R')
+import mktfhe_amd as mk, torch
+print('build_id', mk.build_id()); print('so_sha256', hashlib.sha256(open(mk.LIB_PATH, 'rb').read()).hexdigest()); print('device', torch.cuda.get_device_name(0))
+" > $O/pmc_${NAME}_meta.txt 2>/dev/null
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
 run clk "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU"
