@@ -283,11 +283,17 @@ __global__ void testvector_kernel(const uint32_t *__restrict__ lin, int lwe_stri
 // Built and measured slower, so gone: key rows requested before the group's forward transform (+0.5 %:
 // 64 more live registers), flat instead of buffer-descriptor loads (+5 %), twiddles from global memory (+21 %), three
 // waves per SIMD at M = 512 (same time, lower clock), one key bit's rows requested ahead in the block kernels (+3 % at
-// Blockparam, superseded by rot_block.hip).
+// Blockparam, superseded by rot_block.hip), the next block's key rows pulled into L2 ahead of time -- by every workgroup through
+// LDS-DMA (KMS2partyblock 33.1 -> 40.2 ms) or by one elected workgroup in 32 into a sink register (34.8 ms): profiles/r05_experiments.txt.
 // ------------------------------------------------------------------------------------------------
 // Occupancy the register allocator is told to hit EXACTLY (amdgpu_waves_per_eu(min, max)): 3 waves/SIMD pays at
 // M >= 1024 with single transforms; elsewhere LDS admits 2 and the allocator should then use all 256 VGPRs --
 // builds that stopped at ~186 or chose <= 168 for a third wave LDS cannot host ran up to 25 % slower
+// development only: timing build in which every block reads the key rows of block 0 (cache-resident; WRONG results) -- what the L2 / fabric
+// latency of the key stream costs the kernel (tools/tu_variant.sh x 1,2,3,5 "-DMKT_ROT_ABLATE_KEYS=1"; profiles/r05_experiments.txt)
+#ifndef MKT_ROT_ABLATE_KEYS
+#define MKT_ROT_ABLATE_KEYS 0
+#endif
 template <int LOGM, int NB> struct RotOcc { static constexpr int MINW = (LOGM >= 10 && NB == 1 && MKT_LOGR == 2) ? 3 : 2; };
 
 template <int LOGM, typename WORD, int LB, int LR, int NB, int LT, int BT>
@@ -382,6 +388,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
         }
         if (!any) continue;                                              // :48 / :145 / :413 / :638
 
+
         // plain kernels: the monomial row of the step is requested here (its index only depends on the mask word), not
         // right before the multiply where its Infinity-Cache latency was fully exposed (-4 %)
         constexpr bool PF_MONO = LB == 1;
@@ -423,7 +430,7 @@ void blindrotate_k1_kernel(const RotArgs a) {
 #pragma unroll
                 for (int q = 0; q < LB; q++) {
                     if (LB > 1 && ats[q] == 0) continue;
-                    const unsigned so_row = (unsigned)((((size_t)(blk * LB + q) * 2 * l + (size_t)(g0 + h2)) * 2) * M * sizeof(cplx));
+                    const unsigned so_row = (unsigned)((((size_t)((MKT_ROT_ABLATE_KEYS ? 0 : blk) * LB + q) * 2 * l + (size_t)(g0 + h2)) * 2) * M * sizeof(cplx));
 #pragma unroll
                     for (int e = 0; e < R; e++) {                        // :63-68 muladdto!(tacc, digit, row)
                         const cplx kb = table_load(rs_brk, vo_dev[e], so_row), ka = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(M * sizeof(cplx)));
@@ -954,6 +961,11 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) void kms_phase2_kernel(cons
 // then w with the digits of v_1..v_np (:317-320) -- which is why u for the current party's mask polynomial is
 // computed first and parked in registers.
 // ------------------------------------------------------------------------------------------------
+// development only: timing builds with parts of the memory traffic removed (WRONG results) -- 1: no transform-domain scratch stores / loads,
+// 2: no accumulator stores, 4: every step reads the key rows of step 0 (cache-resident) (tools/tu_variant.sh x 4 "-DMKT_CCS_ABLATE=..."; profiles/r05_experiments.txt)
+#ifndef MKT_CCS_ABLATE
+#define MKT_CCS_ABLATE 0
+#endif
 // LT, BT > 0: gadget length and base known at compile time (digit loops unrolled, shifts and masks immediates)
 template <int LOGM, typename WORD, int LT = 0, int BT = 0>
 __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2))) void ccs_blindrotate_kernel(const CcsArgs a) {
@@ -992,7 +1004,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
         }
 #pragma unroll
         for (int e = 0; e < R; e++) { tu[e].re = tu[e].im = 0.0; tvq[e].re = tvq[e].im = 0.0; }
-        const cplx *vk = q == 0 ? a.crs : a.pub_b + (size_t)(q - 1) * l * M;
+        const cplx *vk = (q == 0 || (MKT_CCS_ABLATE & 4)) ? a.crs : a.pub_b + (size_t)(q - 1) * l * M;
 #pragma unroll 1
         for (int j = 0; j < l; j++) {
             cplx z[R];
@@ -1046,7 +1058,7 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
             const uint32_t v0 = at_src[i];
             const uint32_t at = a.pre_switched ? v0 : divbits<uint32_t>(v0, msbit);
             if (at == 0) continue;                                               // :261
-            const cplx *uni = a.brk + (size_t)idx * a.brk_party_stride + (size_t)i * 3 * l * M;
+            const cplx *uni = (MKT_CCS_ABLATE & 4) ? a.brk : a.brk + (size_t)idx * a.brk_party_stride + (size_t)i * 3 * l * M;   // ablation 4: every step reads the rows of step 0 (cache-resident)
             const cplx *ud = uni, *uf = uni + (size_t)l * M;
             // One loop over the input polynomials in the order the reference's sums need: the current party's mask
             // polynomial first (its u opens tacc.a[idx], :279-284; its v is parked), then b (u opens tacc.b; w(v0),
@@ -1067,31 +1079,31 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
                         for (int e = 0; e < R; e++) tb[e] = tu[e];
                     } else {
 #pragma unroll
-                        for (int e = 0; e < R; e++) sc[(size_t)q * M + dp[e]] = tu[e];
+                        for (int e = 0; e < R; e++) if (!(MKT_CCS_ABLATE & 1)) sc[(size_t)q * M + dp[e]] = tu[e];
                     }
                     inv_words(tvq, vw);                                          // :297-300
                     if (q == np) {
 #pragma unroll
-                        for (int e = 0; e < R; e++) { vsc[e * NT + t] = vw[e][0]; vsc[M + e * NT + t] = vw[e][1]; }
+                        for (int e = 0; e < R; e++) if (!(MKT_CCS_ABLATE & 1)) { vsc[e * NT + t] = vw[e][0]; vsc[M + e * NT + t] = vw[e][1]; }
                         continue;
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < R; e++) { vw[e][0] = vsc[e * NT + t]; vw[e][1] = vsc[M + e * NT + t]; }
+                    for (int e = 0; e < R; e++) { if (MKT_CCS_ABLATE & 1) { vw[e][0] = (WORD)(t * 2654435761u + e); vw[e][1] = (WORD)(t * 40503u + e); } else { vw[e][0] = vsc[e * NT + t]; vw[e][1] = vsc[M + e * NT + t]; } }
                 }
                 wpart(vw, uf, tb, ta);
             }
             // :322-324 mul!(monomial, tacc); ifftto!; add!  -- tacc.b and tacc.a[idx] join the others in the scratch so
             // the loop below is uniform; the polynomials are independent, the two just stored go last
 #pragma unroll
-            for (int e = 0; e < R; e++) { sc[dp[e]] = tb[e]; sc[(size_t)np * M + dp[e]] = ta[e]; }
+            for (int e = 0; e < R; e++) if (!(MKT_CCS_ABLATE & 1)) { sc[dp[e]] = tb[e]; sc[(size_t)np * M + dp[e]] = ta[e]; }
             const cplx *mono = a.monomial + (size_t)(at - 1) * M;
             // the monomial row is the same for every polynomial; the next polynomial's transform-domain sum and the
             // accumulator words the result is added to are requested before the inverse transform that hides them
             auto fq = [&](int qq) { return qq < np - 1 ? qq + 1 : (qq == np - 1 ? 0 : np); };
             cplx mrow[R], xq[R];
 #pragma unroll
-            for (int e = 0; e < R; e++) { mrow[e] = mono[dp[e]]; xq[e] = sc[(size_t)fq(0) * M + dp[e]]; }
+            for (int e = 0; e < R; e++) { mrow[e] = mono[dp[e]]; xq[e] = (MKT_CCS_ABLATE & 1) ? tb[e] : sc[(size_t)fq(0) * M + dp[e]]; }
             for (int qq = 0; qq <= np; qq++) {
                 const int q = fq(qq), qn = fq(qq < np ? qq + 1 : qq);
                 cplx s[R];
@@ -1099,12 +1111,13 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
                 for (int e = 0; e < R; e++) s[e] = cmul(mrow[e], xq[e]);
                 WORD aw[R][2];
 #pragma unroll
-                for (int e = 0; e < R; e++) { xq[e] = sc[(size_t)qn * M + dp[e]]; aw[e][0] = acc[(size_t)q * N + e * NT + t]; aw[e][1] = acc[(size_t)q * N + M + e * NT + t]; }
+                for (int e = 0; e < R; e++) { xq[e] = (MKT_CCS_ABLATE & 1) ? ta[e] : sc[(size_t)qn * M + dp[e]]; aw[e][0] = acc[(size_t)q * N + e * NT + t]; aw[e][1] = acc[(size_t)q * N + M + e * NT + t]; }
                 __builtin_amdgcn_sched_barrier(0);
                 WORD w[R][2];
                 inv_words(s, w);
 #pragma unroll
                 for (int e = 0; e < R; e++) {
+                    if ((MKT_CCS_ABLATE & 2) && w[e][0] != 12345u) continue;
                     acc[(size_t)q * N + e * NT + t] = (WORD)(aw[e][0] + w[e][0]);
                     acc[(size_t)q * N + M + e * NT + t] = (WORD)(aw[e][1] + w[e][1]);
                 }
