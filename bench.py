@@ -490,7 +490,7 @@ def exact_rot_roofline(mk, p, B, t, kern, workload):
     ach = instr / launches_per_step / (avg_ms * 1e-3) / 1e12
     r = {"bound": "int32-valu-issue", "kernel": kern, "achieved": ach, "peak": peak, "unit": "T lane-instr/s", "frac": ach / peak, "traffic": None,
          "algorithmic_instr_per_launch": instr / launches_per_step, "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
-         "peak_note": "256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 3.6 cycles per wave instruction (60 % multiply-class at 4.4, 40 % at 2.5: tools/valu_probe.hip)"}
+         "peak_note": "256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 3.6 cycles per wave instruction (60 % slow class -- multiplies, v_min, three-operand and carry forms -- at 4.4, 40 % add / sub / logic at 2.4, whatever the number of resident waves: tools/int_probe.hip, profiles/r05_int_probe.txt)"}
     prof = profiled_counters(f"mktd::{kern}<{lg}", workload + "_exact", want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms)
     return attach_profile(r, prof, ach, peak)
 

@@ -939,7 +939,8 @@ __global__ __launch_bounds__((ROTS << (LOGN - NLR))) __attribute__((amdgpu_waves
     const int msbit = 32 - LOGN - 1;
     for (int i = 0; i < n; i++) {
         const uint32_t v0 = at_src[i];
-        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+        const uint32_t at_lane = pre_switched ? v0 : divbits<uint32_t>(v0, msbit);
+        const uint32_t at = (ROTS > 1 && NT < 64) ? at_lane : (uint32_t)__builtin_amdgcn_readfirstlane((int)at_lane);   // below N = 512 the two rotations of a workgroup share a wave: not wave-uniform
         if (ROTS == 1 && at == 0) continue;                                        // :413 (ROTS > 1: no skip, the step adds zero)
         Pt zz[4][8];
 #pragma unroll

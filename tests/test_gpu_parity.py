@@ -1080,6 +1080,38 @@ def test_exact_mode_kms_gates(require_gpu, p):
     sx.close()
 
 
+# The EXACT KMS phase 1 at l_gsw = 2 has four kernels (exact_wide 0: one product chain per term; 1: products gathered in 64 bits; 2: the same
+# on three waves per SIMD, two rotations per four-wave workgroup -- an odd rotation count leaves half a workgroup idle; 3: paired
+# transforms, the default): every one must give the big-integer restatement's words, at two ring sizes and ragged batches.
+@pytest.mark.parametrize("wide", [0, 1, 2, 3])
+@pytest.mark.parametrize("p", [mk.KMS2party_N1024_l2.scaled(n=10), mk.KMS2party_N1024_l2.scaled(n=8, N=256), mk.KMS2party_N1024_l2.scaled(n=12, N=512)], ids=lambda p: f"N{p.N}-n{p.n}")     # (N = 2048 with this gadget exceeds the two-prime modulus: refused)
+def test_exact_kms_phase1_kernels_are_word_identical(require_gpu, p, wide):
+    import ref_exact as RX
+    crs, keys = keygen(p, 83)
+    so = oracle_scheme(p, crs, keys)
+    sx = mk.Scheme(p, arith=mk.ARITH_EXACT)
+    sx.load_crs(crs)
+    for i, kk in enumerate(keys):
+        sx.load_party(i, kk)
+    sx.set_option("exact_wide", wide)
+    rng = np.random.default_rng(84)
+    for B in (3, 2):                                                  # 3 gates x 3 RLEV rows = 9 rotations: odd
+        bits = rng.integers(0, 2, 2 * B).astype(bool)
+        c = encrypt_bits(p, keys, bits, seed=8400 + B)
+        x, y = c[:B], c[B:]
+        out = sx.gate(0, x, y)
+        assert np.array_equal(out, np.stack([RX.kms_gate(p, so, keys, crs, 0, x[j], y[j]) for j in range(B)])), (wide, B)
+        assert np.array_equal(mk.lwe_decrypt(out, keys, p), ~(bits[:B] & bits[B:]))
+    lin = np.stack([O.gate_linear(0, x[j], y[j]) for j in range(B)])
+    at, bt = sx.modswitch(lin)
+    at[0, :3] = [0, 2 * p.N, 0]                                       # zero mask words: the reference skips them, kernel 2 multiplies by X^0 - 1 = 0
+    acc0 = np.stack([so.testvector(bt[j]) for j in range(B)])
+    acc_x = sx.blindrotate_(at, acc0.astype(np.uint64).copy())
+    for j in range(B):
+        assert np.array_equal(acc_x[j], RX.kms_blindrotate(p, keys, crs, at[j], acc0[j])), (wide, j)
+    sx.close()
+
+
 @pytest.mark.parametrize("p", [mk.CCS2party.scaled(n=8, N=256), mk.CCS2party.scaled(n=6), mk.CCS4party.scaled(n=4, N=512), mk.CCS8party.scaled(n=3, N=256, k=3),
                                mk.CCS16party.scaled(n=2, N=256, k=4)], ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
 def test_exact_mode_ccs_gates(require_gpu, p):

@@ -1,5 +1,5 @@
 # usage: bash tools/ntt_variant.sh <sfx> "<-D flags>"  -- libmktfhe_hip_<sfx>.so = the default build with ntt_exact.hip recompiled with extra flags
-# (development A/B builds of the EXACT kernels; the default build must be current; run them with tools/ab_bench.sh LIBS="base <sfx>" ARGS="--arith exact")
+# (development A/B builds of the EXACT kernels; the default build must be current; run them with tools/sweep.sh --libs "base <sfx>" -- --arith exact)
 SFX=$1; EXTRA="$2"
 cd $(dirname $0)/../mktfhe_amd/csrc
 mkdir -p /tmp/mkt_tuv
