@@ -28,7 +28,7 @@ def shard_slices(B, world):
 
 
 ACTIVE_BACKEND = None      # what init_process_group ended up with ("nccl" = RCCL on ROCm, or "gloo")
-_VERDICTS = None           # the agreement store stays alive for the life of the process: rank 0 serves it, the other ranks may still be reading it
+_VERDICTS = None           # the agreement store stays alive for the life of the process
 
 
 def _agree(store, rank, world, stage, ok, wait_s):
@@ -46,8 +46,8 @@ def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900
     PROVED with one tiny all-reduce right away, and if creating or proving it fails on ANY rank -- no peer access between the
     visible devices, an IPC mode the host driver refuses -- ALL ranks fall back to `fallback` (gloo over TCP, CPU tensors)
     instead of losing the run: the barrier, the max-over-ranks and the census are all it carries.  The outcome of each stage
-    (communicator created; probe all-reduce correct) is agreed through a small TCP store of its own (MASTER_PORT + 2) before any
-    rank acts on it, and nobody enters the probe collective unless every rank holds a communicator.  What this cannot shorten is a
+    (communicator created; probe all-reduce correct) is agreed through a small file store of its own (/tmp, named after the launcher's pid)
+    before any rank acts on it, and nobody enters the probe collective unless every rank holds a communicator.  What this cannot shorten is a
     rank that never ARRIVES at a collective (creation and the probe are collectives themselves): the others then wait out `timeout_s`."""
     import datetime
     import sys
@@ -63,7 +63,14 @@ def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900
         port = int(os.environ["MASTER_PORT"])
         verdicts = None
         if fallback:                                       # (fallback == backend: one retry of the same backend on a fresh store)
-            verdicts = _VERDICTS = dist.TCPStore(os.environ["MASTER_ADDR"], port + 2, world, rank == 0, datetime.timedelta(seconds=agree_s))
+            # the agreement store is a FILE in /tmp (one node: the contract of this launcher), named after the launcher's pid -- the same for
+            # every rank, new for every launch -- so the rendezvous needs no port beyond MASTER_PORT (and MASTER_PORT + 1 for a fallback group)
+            import tempfile
+            path = os.path.join(tempfile.gettempdir(), f"mkt_verdicts_{os.getppid()}_{port}")
+            try:
+                verdicts = _VERDICTS = dist.FileStore(path, world)
+            except Exception as e:      # noqa: BLE001  (no agreement store: the ranks act on their own outcome, as before round 5)
+                sys.stderr.write(f"mktfhe_amd.distributed: rank {rank}: no agreement store ({type(e).__name__}: {str(e)[:120]})\n")
         why = None
         try:
             kw = {}
@@ -104,7 +111,12 @@ def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=to)
         ACTIVE_BACKEND = backend
         if verdicts is not None:
-            dist.barrier()                                 # nobody leaves (and rank 0 may not exit) while another rank still reads the verdicts
+            dist.barrier()                                 # every rank has read every verdict
+            if rank == 0:
+                try:
+                    os.remove(path)                        # a later launch that recycles this pid and port must not find old verdicts
+                except OSError:
+                    pass
     return rank, world, local
 
 
