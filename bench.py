@@ -492,10 +492,10 @@ def exact_rot_roofline(mk, p, B, t, kern, workload):
          "algorithmic_instr_per_launch": instr / launches_per_step, "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
          "peak_note": "256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 3.6 cycles per wave instruction (60 % slow class -- multiplies, v_min, three-operand and carry forms -- at 4.4, 40 % add / sub / logic at 2.4, whatever the number of resident waves: tools/int_probe.hip, profiles/r05_int_probe.txt)"}
     prof = profiled_counters(f"mktd::{kern}<{lg}", workload + "_exact", want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms)
-    if prof is None and kern == "exact_kms_phase1_kernel":       # the engine reports the family name; at l_gsw = 2 the launched kernel is the paired-transform member
-        prof = profiled_counters(f"mktd::exact_kms_phase1_p2_kernel<{lg}", workload + "_exact", want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms)
+    if prof is None and kern == "exact_kms_phase1_kernel":       # the engine reports the family name; at l_gsw = 2 the launched kernel is the paired-transform member with key rows requested ahead
+        prof = profiled_counters(f"mktd::exact_kms_phase1_p2pf_kernel<{lg}", workload + "_exact", want=("FETCH_SIZE", "WRITE_SIZE"), near_ms=avg_ms)
         if prof is not None:
-            r["kernel"] = "exact_kms_phase1_p2_kernel"
+            r["kernel"] = "exact_kms_phase1_p2pf_kernel"
     return attach_profile(r, prof, ach, peak)
 
 

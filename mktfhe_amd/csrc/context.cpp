@@ -39,7 +39,7 @@ struct Tune {
     int rot_map = 1;        // workgroup id -> (ciphertext, slot) mapping of the k = 1 rotation kernels (kernel_common.h rot_decode): 1 = the RLEV rows of one
                             // (ciphertext, party) on one XCD at one time -- 25 % less fabric traffic at KMS k = 2 (FETCH_SIZE 15.3 -> 11.4 GB per launch,
                             // L2 misses -27 %), time -0.3 ... -2.5 % (profiles/r04j_bench_kms2_n1024_map{0,1}_pmc.txt)
-    int exact_wide = 3;     // EXACT KMS phase 1 at l_gsw = 2: 0 one product chain per term, 1 wide (64-bit) digit-product accumulation, 2 wide on three waves per SIMD (four-wave workgroups), 3 wide with paired transforms (default)
+    int exact_wide = 4;     // EXACT KMS phase 1 at l_gsw = 2: 0 one product chain per term, 1 wide (64-bit) digit-product accumulation, 2 wide on three waves per SIMD (four-wave workgroups), 3 wide with paired transforms, 4 the same with the first sum's key rows requested ahead (default)
     void from_env() {
         rot_variant = env_int("MKT_ROT_VARIANT", rot_variant); rot_stagger = env_int("MKT_ROT_STAGGER", rot_stagger);
         rot_split = env_int("MKT_ROT_SPLIT", rot_split); rot_wide = env_int("MKT_ROT_WIDE", rot_wide);

@@ -1128,6 +1128,132 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
     }
 }
 
+// The same kernel with the key rows of the FIRST (polynomial, half) requested ahead (exact_wide = 4): its 16 row pieces per thread are asked
+// for before the second forward pair instead of at use, where the wait was an exposed L2 / fabric round trip (key rows: 13 % of the step,
+// profiles/r05_experiments.txt item 4).  The other three sums load at use: asked ahead too (under the previous sum's multiply-adds, around
+// the inverse pair) the kernel spills 60-100 registers and runs 7-22 % SLOWER.
+template <int LOGN>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(2, 2))) void exact_kms_phase1_p2pf_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
+                                                                              const uint32_t *__restrict__ lwe, int lwe_stride, int pre_switched, int n, int logB, size_t ngates, int rows_per_gate,
+                                                                              const int *__restrict__ slot_party, const int *__restrict__ slot_row, int logB_lev,
+                                                                              uint64_t *__restrict__ lev_out) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);                        // two staging buffers, then the table
+    const int t = threadIdx.x;
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + 2 * NttLds<LOGN>::WORDS), t, NT, tw, which);
+    const NttConsts k = tab_consts<LOGN>(tab);
+    const size_t gate = blockIdx.x % ngates;
+    const int slot = (int)(blockIdx.x / ngates);
+    const size_t rot = gate * (size_t)rows_per_gate + slot;
+    const int party = slot_party[slot], row = slot_row[slot];
+    const uint32_t *at_src = lwe + gate * (size_t)lwe_stride + (size_t)party * n;
+    const uint64_t *brk = brk0 + (size_t)party * brk_party_stride;
+    const Gadget<uint64_t> gd(2, logB);
+    uint64_t acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[c][e] = 0;
+    if (t == 0) acc[0][0] = (uint64_t)1 << (64 - (row + 1) * logB_lev);           // :403-406 trivial RLEV row
+    const int msbit = 32 - LOGN - 1;
+    for (int i = 0; i < n; i++) {
+        const uint32_t v0 = at_src[i];
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+        if (at == 0) continue;                                                     // :413
+        const uint4 *rowb = reinterpret_cast<const uint4 *>(brk + ((size_t)i * 4 * 4) * N + 8 * t);   // [digit g][poly][half][N], two points per 16 bytes
+        // piece (g, ep) of (polynomial pp, half h): K[g * 4 + ep]
+        auto ask = [&](uint4 (&K)[16], int pp, int h) {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int ep = 0; ep < 4; ep++) K[g * 4 + ep] = rowb[(size_t)(g * 4 + pp * 2 + h) * (N / 2) + ep];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        Pt zz[4][8];
+        uint4 Ka[16], Kb[16];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            Pt (&zp)[2][8] = *reinterpret_cast<Pt(*)[2][8]>(&zz[2 * c]);
+            if (c == 1) ask(Ka, 0, 0);                                            // (0, low): under the second forward pair
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) zp[j][e] = res_small(gd.digit(gd.prep(c ? acc[1][e] : acc[0][e]), j));   // :415-425 decompto!
+            ntt_forward_n<LOGN, 0, false, 2>(zp, tw[0], lds, t);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) zp[j][e] = wide_x(zp[j][e]);
+        }
+        // the sum of one (polynomial, half) from the pieces in K (:427-432), two points at a time
+        auto gather = [&](Pt (&th)[8], const uint4 (&K)[16]) {
+#pragma unroll
+            for (int ep = 0; ep < 4; ep++) {
+                Wide w0, w1;
+                w0.a = w0.b = w1.a = w1.b = 0;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint4 kv = K[g * 4 + ep];
+                    Pt y0, y1; y0.a = kv.x; y0.b = kv.y; y1.a = kv.z; y1.b = kv.w;
+                    wide_mac(w0, zz[g][2 * ep], y0); wide_mac(w1, zz[g][2 * ep + 1], y1);
+                }
+                th[2 * ep] = wide_reduce(w0); th[2 * ep + 1] = wide_reduce(w1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto lift_rotate = [&](Pt (&th)[2][8], auto ppc) {                        // inverse pair, lift, X^at - 1 (:435-437)
+            constexpr int pp = decltype(ppc)::value;
+            ntt_inverse_n<LOGN, Plan<LOGN, NLR>::NPASS - 1, false, 2>(th, tw[0], lds, t, k.ninv);
+            uint64_t w[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) w[e] = crt_signed(th[0][e]) + (crt_signed(th[1][e]) << 32);
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t src = (uint32_t)(e * NT + t - (int)at) & (2u * N - 1u);
+                const uint64_t v = lds[src & (N - 1)];
+                acc[pp][e] += (src >= (uint32_t)N ? (uint64_t)0 - v : v) - w[e];
+            }
+        };
+        {
+            Pt th[2][8];
+            gather(th[0], Ka);
+            ask(Kb, 0, 1);
+            gather(th[1], Kb);
+            lift_rotate(th, std::integral_constant<int, 0>{});
+        }
+        {
+            Pt th[2][8];
+            ask(Ka, 1, 0);
+            gather(th[0], Ka);
+            ask(Kb, 1, 1);
+            gather(th[1], Kb);
+            lift_rotate(th, std::integral_constant<int, 1>{});
+        }
+    }
+    // :441 fftto!(tacc, acc): the row as split residue tables, Montgomery form; the two halves of a polynomial side by side
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        Pt z[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) z[h][e] = fwd_in(piece_of(acc[c][e], h), e);
+        ntt_forward_n<LOGN, 0, false, 2>(z, tw[0], lds, t);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint64_t *o = lev_out + ((rot * 2 + c) * 2 + h) * (size_t)N + 8 * t;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = pack(Pt{montmul<P1, PI1>(z[h][e].a, RR1), montmul<P2, PI2>(z[h][e].b, RR2)});
+        }
+        __syncthreads();
+    }
+}
+
 // KMS phase 2 (bootstrapping.jl:448-558) with exact products; one workgroup per ciphertext, every thread only touches its
 // own coefficients (e*NT + t) and transform points (8t + e)
 struct ExactPhase2Args {
@@ -1510,7 +1636,12 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
             hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, true>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
                                a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, a.blk_len, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
         } else {
-            if (a.wide >= 3 && a.l_gsw == 2) {
+            if (a.wide >= 4 && a.l_gsw == 2) {
+                const size_t lds2 = lds_bytes<LN>(1, 2);
+                e = ntt_set_lds(exact_kms_phase1_p2pf_kernel<LN>, lds2); if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((exact_kms_phase1_p2pf_kernel<LN>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds2, s, tb, a.brk, a.brk_party_stride,
+                                   a.lwe, a.lwe_stride, a.pre_switched, a.n, a.logB_gsw, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+            } else if (a.wide >= 3 && a.l_gsw == 2) {
                 const size_t lds2 = lds_bytes<LN>(1, 2);
                 e = ntt_set_lds(exact_kms_phase1_p2_kernel<LN>, lds2); if (e != hipSuccess) return e;
                 hipLaunchKernelGGL((exact_kms_phase1_p2_kernel<LN>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds2, s, tb, a.brk, a.brk_party_stride,

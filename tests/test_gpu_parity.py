@@ -1080,10 +1080,11 @@ def test_exact_mode_kms_gates(require_gpu, p):
     sx.close()
 
 
-# The EXACT KMS phase 1 at l_gsw = 2 has four kernels (exact_wide 0: one product chain per term; 1: products gathered in 64 bits; 2: the same
+# The EXACT KMS phase 1 at l_gsw = 2 has five kernels (exact_wide 0: one product chain per term; 1: products gathered in 64 bits; 2: the same
 # on three waves per SIMD, two rotations per four-wave workgroup -- an odd rotation count leaves half a workgroup idle; 3: paired
-# transforms, the default): every one must give the big-integer restatement's words, at two ring sizes and ragged batches.
-@pytest.mark.parametrize("wide", [0, 1, 2, 3])
+# transforms; 4: paired transforms with the first sum's key rows requested ahead, the default): every one must give the big-integer
+# restatement's words, at three ring sizes and ragged batches.
+@pytest.mark.parametrize("wide", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("p", [mk.KMS2party_N1024_l2.scaled(n=10), mk.KMS2party_N1024_l2.scaled(n=8, N=256), mk.KMS2party_N1024_l2.scaled(n=12, N=512)], ids=lambda p: f"N{p.N}-n{p.n}")     # (N = 2048 with this gadget exceeds the two-prime modulus: refused)
 def test_exact_kms_phase1_kernels_are_word_identical(require_gpu, p, wide):
     import ref_exact as RX
