@@ -32,7 +32,7 @@ if [ $PART = 5 ]; then      # bench lines only, AFTER the PMC summaries of this 
   for w in ccs2party ccs8party ccs8_n2048; do line --steps 2 --warmup 1 --workload $w --no-roofline > $O/bench_$w.json; done
   line --steps 2 --warmup 1 --workload lmss --batch 16384 --no-roofline --no-cpu-baseline > $O/bench_lmss_16384.json
   line --steps 2 --warmup 1 --workload lmss_k2 --batch 16384 --no-roofline --no-cpu-baseline > $O/bench_lmss_k2_16384.json
-  line --steps 2 --warmup 1 --workload kms2partyblock --batch 16384 --no-roofline --no-cpu-baseline > $O/bench_kms2partyblock_16384.json
+  line --steps 2 --warmup 1 --workload kms2partyblock --batch 16384 --no-roofline > $O/bench_kms2partyblock_16384.json
   line --steps 2 --warmup 1 --workload kms4party --batch 8192 --no-roofline --no-cpu-baseline > $O/bench_kms4party_8192.json                 # config (3): one GPU's share of 65 536 gates
   for w in kms2party kms2partyblock cggi lmss ccs2party; do line --steps 3 --warmup 1 --workload $w --arith exact --no-roofline --no-cpu-baseline --no-secondary > $O/bench_${w}_exact.json; done
 fi
