@@ -12,7 +12,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--arith", nargs="+", default=["f64ref", "exact"])
 ap.add_argument("--N", type=int, nargs="+", default=[1024, 2048])
 ap.add_argument("--W", type=int, nargs="+", default=[64, 32])
-ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--warm", type=int, default=30, help="untimed launches first: the part needs tens of milliseconds of back-to-back work to reach the clock it then holds (5 timed launches after 2 warm-ups read 15-25 %% low)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 knobs = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith(("MKT_FFT_", "MKT_NTT_")))
@@ -29,7 +30,9 @@ for W in a.W:
             s = mk.Scheme(p, device=0, arith=mk.ARITH_EXACT if ar == "exact" else mk.ARITH_F64REF)
             out = []
             for fn in ((lambda: s.transform_fwd(pv, out=tr)), (lambda: s.transform_inv(tr, out=back))):
-                fn(); fn(); torch.cuda.synchronize()
+                for _ in range(a.warm):
+                    fn()
+                torch.cuda.synchronize()
                 s.enable_timing(True)
                 for _ in range(a.reps):
                     fn()
