@@ -364,6 +364,11 @@ NTT_LEG_INSTR = {("forward", 1024, 64): (482, 297), ("inverse", 1024, 64): (530,
                  ("forward", 2048, 64): (515, 312), ("inverse", 2048, 64): (567, 419), ("forward", 2048, 32): (447, 295), ("inverse", 2048, 32): (555, 412)}
 
 
+# shader clock held INSIDE the batched integer transforms after >= 1.5 s of back-to-back launches (tools/ntt_clock_probe.hip, another device of
+# the pool, labelled as such in the line: in_kernel_clock_source)
+NTT_IN_KERNEL_GHZ = {1024: 2.0, 2048: 2.166}
+
+
 def transform_roofline(mk, torch, local, dev):
     """BASELINE.json metric 2: batched forward (fft.jl:57-63) and inverse (fft.jl:74-81) transforms streamed HBM -> HBM at
     N = 1024 and 2048, >= 4 GiB per launch (>> 256 MiB Infinity Cache), on both rings: algorithmic bytes per transform
@@ -422,7 +427,8 @@ def transform_roofline(mk, torch, local, dev):
                         issue_peak = 256 * 4 * 2.4e9 / cyc_poly * per / 1e9              # GB/s of algorithmic bytes at which the VALU is full (2.4 GHz)
                         e = {"bound": "int32-valu-issue", "kernel": kern, "arith": "EXACT (integer NTT, residues mod 131063*2^13+1 and 131066*2^13+1)",
                              "issue_roofline": {"peak": issue_peak, "unit": "GB/s", "frac": achieved / issue_peak, "valu_instr_per_thread_and_polynomial": {"slow_class": slow, "fast_class": fast},
-                                                "peak_note": "1024 SIMDs x 2.4 GHz / (slow x 4.43 + fast x 2.38 cycles per 512 points) x algorithmic bytes per polynomial; the part holds 1.6-1.8 GHz under these kernels (profiles/r03_ntt_pmc.txt)"},
+                                                "frac_at_in_kernel_clock": achieved / (issue_peak * NTT_IN_KERNEL_GHZ[N] / 2.4), "in_kernel_clock_ghz": NTT_IN_KERNEL_GHZ[N], "in_kernel_clock_source": "profiles/r05_ntt_clock_probe.txt",
+                                                "peak_note": "1024 SIMDs x 2.4 GHz / (slow x 4.43 + fast x 2.38 cycles per 512 points) x algorithmic bytes per polynomial; under these kernels the part holds 2.0 GHz (N = 1024) / 2.17 GHz (N = 2048), measured in the kernel as d s_memtime / d s_memrealtime (tools/ntt_clock_probe.hip): frac_at_in_kernel_clock prices the issue peak at that clock"},
                              "bound_note": "integer issue, not HBM: `frac` stays the BASELINE metric (achieved / 8 TB/s), `issue_roofline.frac` is the distance from this kernel's own bound"}
                     e.update({"direction": direction, "N": N, "ring_bits": W, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                               "frac_first_launches": cold / 8000.0, "launches_timed": cnt, "launches_before": warm,

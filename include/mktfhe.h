@@ -67,7 +67,7 @@ enum {
                              Transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch,
                              mkt_decompose_batch, mkt_modswitch_batch, mkt_not_batch) for every scheme; the gate path
                              (mkt_load_*, mkt_keygen_device, mkt_gate, mkt_bootstrap, mkt_blindrotate, mkt_keyswitch) for
-                             MKT_CGGI / MKT_LMSS (RLWE length 1 .. 3, any block length, 32-bit ring), MKT_CCS (32-bit ring) and MKT_KMS /
+                             MKT_CGGI / MKT_LMSS (any RLWE length and block length, 32-bit ring), MKT_CCS (32-bit ring) and MKT_KMS /
                              MKT_KMS_BLOCK (64-bit ring: every 64-bit table kept as the transforms of its two centered
                              32-bit pieces), provided the context's gadgets keep every product sum below P / 2 (checked at the
                              first key upload: MKT_ERR_UNSUPPORTED otherwise).  The ciphertexts are valid -- on the

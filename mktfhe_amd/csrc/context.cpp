@@ -40,6 +40,7 @@ struct Tune {
                             // (ciphertext, party) on one XCD at one time -- 25 % less fabric traffic at KMS k = 2 (FETCH_SIZE 15.3 -> 11.4 GB per launch,
                             // L2 misses -27 %), time -0.3 ... -2.5 % (profiles/r04j_bench_kms2_n1024_map{0,1}_pmc.txt)
     int exact_wide = 4;     // EXACT KMS phase 1 at l_gsw = 2: 0 one product chain per term, 1 wide (64-bit) digit-product accumulation, 2 wide on three waves per SIMD (four-wave workgroups), 3 wide with paired transforms, 4 the same with the first sum's key rows requested ahead (default)
+    int exact_kany = 0;     // EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel (sums in memory) also where the register kernels serve (k <= 3); tests
     void from_env() {
         rot_variant = env_int("MKT_ROT_VARIANT", rot_variant); rot_stagger = env_int("MKT_ROT_STAGGER", rot_stagger);
         rot_split = env_int("MKT_ROT_SPLIT", rot_split); rot_wide = env_int("MKT_ROT_WIDE", rot_wide);
@@ -230,7 +231,7 @@ int ensure_workspace(mkt_ctx *c, size_t gates) {
     } else if (p.scheme == MKT_CCS) {
         HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * 3 * poly_bytes(c)));    // v scratch (ring words): parked v + two hand-off slots
         HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)(p.k + 1) * c->M * sizeof(cplx)));
-    } else if (p.k > 3) {                                                          // CGGI / LMSS beyond RLWE length 3: tacc and tacc2 of blindrotate_kany_kernel
+    } else if (p.k > 3 || (c->exact && c->tune.exact_kany)) {                      // CGGI / LMSS beyond RLWE length 3: tacc and tacc2 of blindrotate_kany_kernel / exact_blindrotate_kany_kernel (same byte count)
         HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)2 * (p.k + 1) * c->M * sizeof(cplx)));
     }
     c->ws_gates = gates;
@@ -309,6 +310,13 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         q.lin_for_tv = lin_for_tv; q.acc = reinterpret_cast<uint64_t *>(acc); q.scratch = reinterpret_cast<uint64_t *>(scratch); q.phase1_only = 0; q.wide = c->tune.exact_wide;
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_exact_kms(c->logN, c->d_ntt, q, B, c->stream));
+        return MKT_OK;
+    }
+    if (c->exact && (p.k > 3 || c->tune.exact_kany)) {   // CGGI / LMSS, any RLWE length: sums in memory
+        Timer tm(c, 1);
+        HIPCHK(c, mktd::launch_exact_blindrotate_kany(c->logN, c->d_ntt, reinterpret_cast<const uint64_t *>(c->ks->d_brk), reinterpret_cast<const uint64_t *>(c->ks->d_monomial),
+                                                      lwe, stride, pre, p.n, p.k, p.l_gsw, p.logB_gsw, mkt::is_block(p.scheme) ? p.blk_len : 1, (uint32_t *)acc,
+                                                      reinterpret_cast<uint64_t *>(scratch), B, c->stream));
         return MKT_OK;
     }
     if (c->exact && (p.k > 1 || (mkt::is_block(p.scheme) && p.blk_len != 3))) {   // CGGI / LMSS with RLWE length 2, 3 or another block length: the general kernel
@@ -472,14 +480,14 @@ bool exact_gate_ok(const mkt_ctx *c) {
     if (p.scheme == MKT_CCS && p.W == 32)    // tacc.b gathers u_0 and the w of all np + 1 polynomials, then the monomial doubles it
         return 2.0 * (p.k + 2.0) * p.l_uni * std::ldexp(1.0, p.logB_uni - 1) * n31 < half_P;
     const bool lmss = p.scheme == MKT_LMSS;
-    if (!((p.scheme == MKT_CGGI || lmss) && p.k >= 1 && p.k <= 3 && p.W == 32)) return false;     // RLWE length 1 .. 3 (exact_blindrotate_kr_kernel beyond the k = 1, block-length-3 shapes)
+    if (!((p.scheme == MKT_CGGI || lmss) && p.k >= 1 && p.W == 32)) return false;     // any RLWE length (exact_blindrotate_kr_kernel beyond the k = 1, block-length-3 shapes; exact_blindrotate_kany_kernel beyond k = 3)
     // the kernels multiply the product sum by the monomial X^a - 1 in the transform domain BEFORE the one lift (ntt_exact.hip
     // exact_blindrotate_kernel: s2 = tacc * mono), so the lifted integer is up to twice the sum -- for CGGI as for a block;
     // (k + 1) l digit polynomials per key bit
     const double bound = 2.0 * (lmss ? p.blk_len : 1.0) * (p.k + 1.0) * p.l_gsw * std::ldexp(1.0, p.logB_gsw - 1) * n31;
     return bound < half_P;
 }
-#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (RLWE length 1 .. 3, 32-bit ring), for CCS (32-bit ring) and for KMS / KMS_block (64-bit ring, tables split in 32-bit halves), gadgets within the two-prime modulus; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
+#define MKT_EXACT_GATE(c) do { if ((c) && (c)->exact && !exact_gate_ok(c)) return fail((c), MKT_ERR_UNSUPPORTED, "MKT_ARITH_EXACT evaluates gates for CGGI and LMSS (32-bit ring), for CCS (32-bit ring) and for KMS / KMS_block (64-bit ring, tables split in 32-bit halves), gadgets within the two-prime modulus; other schemes offer the transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch)"); } while (0)
 #define MKT_F64_OR_EXACT_KMS(c) do { if ((c) && (c)->exact && !(mkt::is_mk((c)->p.scheme) && exact_gate_ok(c))) return fail((c), MKT_ERR_UNSUPPORTED, "on an MKT_ARITH_EXACT context this entry point serves the multi-key gate paths only"); } while (0)
 #define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; not offered by an MKT_ARITH_EXACT context"); } while (0)
 
@@ -671,6 +679,7 @@ int mkt_set_option(mkt_ctx *c, const char *name, int value) {
     else if (k == "ccs_pipe") t.ccs_pipe = value;
     else if (k == "exact_wide") t.exact_wide = value;
     else if (k == "rot_map") t.rot_map = value;
+    else if (k == "exact_kany") { if (t.exact_kany != value) c->ws_gates = 0; t.exact_kany = value; }   // the workspace gains / loses the kernel's scratch at the next call
     else return fail(c, MKT_ERR_ARG, "mkt_set_option: unknown option '" + k + "'");
     return MKT_OK;
 }

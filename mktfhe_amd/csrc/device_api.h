@@ -155,6 +155,9 @@ hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_
 // the same for any RLWE length kr = 1 .. 3 and any block length (digit transforms recomputed per key bit of a block); brk [n][(kr+1) l][kr+1][N]
 hipError_t launch_exact_blindrotate_kr(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
                                        int pre_switched, int n, int kr, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s);
+// any RLWE length (run-time kr): the transform-domain sums in scratch [B][2][kr+1][N] packed residue pairs
+hipError_t launch_exact_blindrotate_kany(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
+                                         int pre_switched, int n, int kr, int l, int logB, int blk_len, uint32_t *acc, uint64_t *scratch, size_t B, hipStream_t s);
 // the 64-bit ring with exact products (KMS): resident 64-bit tables as (low, high) residue polynomials per logical polynomial
 hipError_t launch_ntt_fwd_split(int logN, const uint64_t *tab, const void *p, uint64_t *out, size_t B, hipStream_t s);
 struct ExactKmsArgs {

@@ -652,6 +652,78 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kr_kern
 }
 
 // ------------------------------------------------------------------------------------------------
+// Any RLWE length beyond 3 (scheme.jl:6-36 leaves k free; the Float64 mode's counterpart is blindrotate_kany_kernel): np = k + 1 is a
+// run-time value, so the transform-domain sums of one key bit (tacc, :62-68 / :146-154) and of the block (:71 / :157) live in a
+// per-rotation scratch region [2][np][N] of packed residue pairs and the accumulator stays in its ring-word buffer.  Every thread
+// reads and writes only its own elements of all three (words e*NT + t, transform points 8t + e), so no barrier beyond the
+// transforms' own is needed.  Same products, same single lift per output polynomial and block as exact_blindrotate_kr_kernel:
+// word-identical to it where both run (tests force this kernel at k <= 3).
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kany_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk,
+                                                                                   const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe,
+                                                                                   int lwe_stride, int pre_switched, int n, int np, int l, int logB, int blk_len,
+                                                                                   uint32_t *__restrict__ acc_io, uint64_t *__restrict__ scratch) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
+    const int t = threadIdx.x;
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + NttLds<LOGN>::WORDS), t, NT, tw, which);
+    const NttConsts k = tab_consts<LOGN>(tab);
+    const size_t rot = blockIdx.x;
+    const uint32_t *at_src = lwe + rot * (size_t)lwe_stride;
+    uint32_t *accg = acc_io + rot * (size_t)np * N;
+    uint64_t *tg = scratch + rot * (size_t)2 * np * N + 8 * t, *sg = tg + (size_t)np * N;     // this thread's points of tacc / of the block sum
+    const Gadget<uint32_t> gd(l, logB);
+    const int msbit = 32 - LOGN - 1;
+    for (int blk = 0; blk < n / blk_len; blk++) {
+        bool first_bit = true;                                                     // the block sum starts at this key bit's product (:157 from zero)
+        for (int q = 0; q < blk_len; q++) {
+            const int i = blk * blk_len + q;
+            const uint32_t v0 = at_src[i];
+            const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+            if (at == 0) continue;                                                 // :48 / :145
+            for (int c = 0; c < np; c++)
+                for (int j = 0; j < l; j++) {
+                    const uint64_t *row = brk + (((size_t)i * np * l + (size_t)(c * l + j)) * np) * N + 8 * t;   // [row c l + j][poly][N]
+                    Pt z[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(gd.prep(accg[(size_t)c * N + e * NT + t]), j));   // :50-51 / :131-132 decompto!
+                    ntt_forward<LOGN>(z, tw[0], lds, t);
+                    const bool first_row = c == 0 && j == 0;
+                    for (int pp = 0; pp < np; pp++) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            Pt cur; cur.a = 0; cur.b = 0;
+                            if (!first_row) cur = unpack(tg[(size_t)pp * N + e]);
+                            tg[(size_t)pp * N + e] = pack(pt_mac(cur, z[e], unpack(row[(size_t)pp * N + e])));   // :63-68 / :146-154, exactly
+                        }
+                    }
+                }
+            const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
+            for (int pp = 0; pp < np; pp++) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    Pt cur; cur.a = 0; cur.b = 0;
+                    if (!first_bit) cur = unpack(sg[(size_t)pp * N + e]);
+                    sg[(size_t)pp * N + e] = pack(pt_mac(cur, unpack(tg[(size_t)pp * N + e]), unpack(mrow[e])));   // :71 / :157
+                }
+            }
+            first_bit = false;
+        }
+        if (first_bit) continue;                                                   // an all-zero block adds 0
+        for (int pp = 0; pp < np; pp++) {
+            Pt s[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) s[e] = unpack(sg[(size_t)pp * N + e]);
+            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s, tw[0], lds, t, k.ninv);                             // :72 / :162
+#pragma unroll
+            for (int e = 0; e < 8; e++) accg[(size_t)pp * N + e * NT + t] += (uint32_t)crt_signed(s[e]);         // :73 / :163
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The 64-bit ring (KMS) with exact products.  A product  digit polynomial x 64-bit polynomial  exceeds P, so every resident
 // 64-bit table is kept as TWO residue polynomials -- the transforms of its low and of its high 32-bit halves (centered
 // pieces in [-2^31, 2^31), piece_of) -- every sum of such products as a (low, high) pair of transform-domain accumulators,
@@ -1609,6 +1681,20 @@ hipError_t launch_exact_blindrotate_kr(int logN, const uint64_t *tab, const uint
         if (kr == 1) MKT_EXACT_KR_LAUNCH(1); else if (kr == 2) MKT_EXACT_KR_LAUNCH(2); else MKT_EXACT_KR_LAUNCH(3);
     });
 #undef MKT_EXACT_KR_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_exact_blindrotate_kany(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
+                                         int pre_switched, int n, int kr, int l, int logB, int blk_len, uint32_t *acc, uint64_t *scratch, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    if (kr < 1 || blk_len < 1 || n % blk_len || !scratch) return hipErrorInvalidValue;
+    last_rot_kernel = "exact_blindrotate_kany_kernel";
+    const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
+    MKT_NTT_DISPATCH(logN, {
+        const size_t lds = lds_bytes<LN>(1);
+        hipError_t e = ntt_set_lds(exact_blindrotate_kany_kernel<LN>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((exact_blindrotate_kany_kernel<LN>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, kr + 1, l, logB, blk_len, acc, scratch);
+    });
     return hipGetLastError();
 }
 

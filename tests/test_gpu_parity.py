@@ -334,9 +334,9 @@ def test_errors(require_gpu):
         s.gate(0, x, x)
     with pytest.raises(ValueError):       # wrong length (reference: @assert)
         s.gate(0, x[:, :-1], x[:, :-1])
-    # EXACT: a gadget whose product sums would not fit the two-prime modulus (P / 2 = 2^58.9998), or an RLWE length it has no kernel
-    # for, is refused instead of computing something else
-    for pk in (mk.KMS2party.scaled(n=8, N=2048, l_gsw=2, logB_gsw=20), mk.CGGIparam.scaled(n=8, N=256, k=4)):
+    # EXACT: a gadget whose product sums would not fit the two-prime modulus (P / 2 = 2^58.9998) is refused instead of computing
+    # something else (64-bit ring; 32-bit ring, where the bound grows with the RLWE length)
+    for pk in (mk.KMS2party.scaled(n=8, N=2048, l_gsw=2, logB_gsw=20), mk.CGGIparam.scaled(n=8, N=2048, k=4, l_gsw=2, logB_gsw=16)):
         ex = mk.Scheme(pk, arith=mk.ARITH_EXACT)
         xk = np.zeros((2, pk.lwe_len), dtype=np.uint32)
         with pytest.raises(mk.MktError, match="MKT_ARITH_EXACT evaluates gates for CGGI"):
@@ -1156,7 +1156,10 @@ def test_exact_mode_ccs_gates(require_gpu, p):
                                # RLWE length 2 / 3 and other block lengths: exact_blindrotate_kr_kernel (BASELINE configs[4] = LMSS, k = 2, in the integer arithmetic)
                                mk.Blockparam_k2.scaled(n=9, blk_d=3), mk.Blockparam_k2.scaled(n=12, N=256, blk_d=4), mk.CGGIparam.scaled(n=8, N=256, k=2),
                                mk.CGGIparam.scaled(n=6, N=512, k=3, l_gsw=2, logB_gsw=10), mk.Blockparam.scaled(n=8, N=256, blk_d=4, blk_len=2),
-                               mk.Blockparam.scaled(n=8, N=128, blk_d=2, blk_len=4, k=2)],
+                               mk.Blockparam.scaled(n=8, N=128, blk_d=2, blk_len=4, k=2),
+                               # RLWE length beyond 3 (scheme.jl:6-36 leaves k free): exact_blindrotate_kany_kernel, sums in memory
+                               mk.CGGIparam.scaled(n=6, N=256, k=4), mk.Blockparam.scaled(n=8, N=128, blk_d=4, blk_len=2, k=5),
+                               mk.Blockparam.scaled(n=9, N=512, blk_d=3, k=4)],
                          ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-l{p.l_gsw}-k{p.k}-b{p.blk_len}")
 def test_exact_mode_cggi_gates(require_gpu, p):
     """MKT_ARITH_EXACT gate path (CGGI and LMSS, 32-bit ring): blind rotation with integer-NTT products.  Accumulators and
@@ -1179,6 +1182,11 @@ def test_exact_mode_cggi_gates(require_gpu, p):
     for j in range(B):
         rot = RX.blindrotate_lmss if p.blk_len > 1 else RX.blindrotate
         assert np.array_equal(acc_x[j].astype(np.uint64).reshape(-1), rot(p, keys[0].brk, at[j], acc0[j])), f"exact blindrotate {j}"
+    # the run-time-RLWE-length kernel (the only one beyond k = 3) forced where the register kernels serve: the same words
+    assert ("kany" in sx.last_kernel_name()) == (p.k > 3)
+    sx.set_option("exact_kany", 1)
+    assert np.array_equal(sx.blindrotate_(at, acc0.astype(np.uint32).copy()), acc_x) and "kany" in sx.last_kernel_name()
+    sx.set_option("exact_kany", 0)
     for op in (0, 3, 5):
         out = sx.gate(op, x, y)
         assert np.array_equal(out, np.stack([RX.gate(p, so, keys[0].brk, op, x[j], y[j]) for j in range(B)])), f"exact gate {op}"
