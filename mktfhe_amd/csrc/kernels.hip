@@ -1702,6 +1702,10 @@ hipError_t launch_blindrotate_k1(int logM, int W, const RotArgs &a, size_t nrot,
         // 257..512 rotations: one 4-wave workgroup of two rotations per CU instead of two 2-wave workgroups, which share a SIMD pair
         // (tools/simd_place.hip): Blockparam 384 / 512 gates 4.51 -> 3.90 ms; up to 256 and from 513 to 1023 one rotation per workgroup is ahead
         if (a.blk_group == 0 && W == 32 && logM == 9 && nrot > 256 && nrot <= 512 && blockg_supported(logM, 2)) G = 2;
+        // 64-bit ring at M = 1024 (KMS_block, params.jl:87-125): two rotations per workgroup halve the key elements a thread holds, which
+        // leaves room to re-request each for the next digit right after its last use (rot_block.hip); ahead up to about one KMS2partyblock
+        // batch of 1024 gates (512 / 1024 gates: 16.6 / 32.3 ms against 17.2 / 33.3), behind from 2048 (63.4 against 62.5 ms)
+        if (a.blk_group == 0 && W == 64 && logM == 10 && nrot >= 1536 && nrot <= 4096 && blockg_supported(logM, 2)) G = 2;
         if (G > 1 && blockg_supported(logM, G) && a.blk_len >= 2 && a.blk_len <= 4) {
             const size_t nslots = (size_t)a.rows_per_gate;
             const hipError_t e = W == 64 ? launch_rot_blockg_u64(logM, G, 2, a, nslots, s) : launch_rot_blockg_u32(logM, G, 2, a, nslots, s);

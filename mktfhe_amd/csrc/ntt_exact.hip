@@ -510,6 +510,17 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
             for (int pp = 0; pp < 2; pp++)
 #pragma unroll
                 for (int e = 0; e < 8; e++) { tacc[q][pp][e].a = 0; tacc[q][pp][e].b = 0; }
+        // the monomial row of the (first non-zero) key bit, requested a whole step ahead of its use (at use it was one exposed L2 round
+        // trip per step); MKT_EXACT_MONO_AHEAD=0: at use (A/B builds)
+#ifndef MKT_EXACT_MONO_AHEAD
+#define MKT_EXACT_MONO_AHEAD 1
+#endif
+        uint64_t mr0[8];
+        if constexpr (LB == 1 && MKT_EXACT_MONO_AHEAD) {
+            const uint64_t *mrow = mono + (size_t)(ats[0] - 1) * N + 8 * t;
+#pragma unroll
+            for (int e = 0; e < 8; e++) mr0[e] = mrow[e];
+        }
         for (int c = 0; c < 2; c++) {
             uint32_t tp[8];
 #pragma unroll
@@ -550,7 +561,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
                 if (ats[q] == 0) continue;
                 const uint64_t *mrow = mono + (size_t)(ats[q] - 1) * N + 8 * t;
 #pragma unroll
-                for (int e = 0; e < 8; e++) s2[e] = pt_mac(s2[e], tacc[q][pp][e], unpack(mrow[e]));   // :71 / :157
+                for (int e = 0; e < 8; e++) s2[e] = pt_mac(s2[e], tacc[q][pp][e], unpack((LB == 1 && MKT_EXACT_MONO_AHEAD) ? mr0[e] : mrow[e]));   // :71 / :157
             }
             ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s2, tw[0], lds, t, k.ninv);            // :72 / :162
 #pragma unroll

@@ -42,6 +42,13 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
     // 32-bit ring 168 -> 36 B, Blockparam 6.18 -> 5.65 ms per 1024 gates and -- TWO independent workgroups per compute unit -- 75.8 ms per
     // 16 384 gates against 79.2 ms for G = 4, whose one eight-wave workgroup idles all four SIMDs at every barrier)
     constexpr bool LEAN = NP > 2 || G == 2;   // (on the shipped Blockparam kernel, G = 4: 5.27 - 5.35 ms either way)
+    // Key elements are re-requested for the NEXT digit as soon as their last multiply-add of this digit is done (per key bit; in the lean
+    // stages per key bit and stored position), not after the whole stage: the wait for them was 20 % of a wave's time at G = 2
+    // (SQ_WAIT_INST_ANY - SQ_WAIT_INST_LDS, profiles/r05_experiments.txt item 12).  -DMKT_BLK_EARLYK=0: the round-4 order (A/B builds).
+#ifndef MKT_BLK_EARLYK
+#define MKT_BLK_EARLYK 1
+#endif
+    constexpr bool EARLYQ = !LEAN && MKT_BLK_EARLYK, EARLYK = LEAN && MKT_BLK_EARLYK;
     constexpr int ORDER = NP > 2 ? MKT_DEVORDER_KR : MKT_DEVORDER;   // context.cpp: the RLWE-length-k contexts keep their tables in order 2
     static_assert(MKT_DEVORDER == 1 && MKT_DEVORDER_KR == 2, "device point orders of the resident tables");
     static_assert(NP >= 2 && NP <= 4, "accumulator polynomials");
@@ -131,6 +138,11 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
                 for (int p = 0; p < PTS; p++) K[q][c][p] = table_load(rs_brk, vo[p], so_row + (unsigned)(c * M * sizeof(cplx)));
         }
     };
+    auto load_keys_qp = [&](int kb, int g, int q, int p) {   // one key bit, one stored position
+        const unsigned so_row = (unsigned)((((size_t)(kb * LB + q) * NP * l + (size_t)g) * NP) * M * sizeof(cplx));
+#pragma unroll
+        for (int c = 0; c < NP; c++) K[q][c][p] = table_load(rs_brk, vo[p], so_row + (unsigned)(c * M * sizeof(cplx)));
+    };
     int kblk = -1;                                // block whose first digit's key elements are in flight / in K
 
     for (int blk = 0; blk < nblk; blk++) {
@@ -209,7 +221,7 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
             if (LAST && G == 4 && !LEAN) load_mono();                  // in flight during the multiply-adds where the registers allow
             if constexpr (!LEAN) {
 #pragma unroll
-                for (int q = 0; q < LB; q++)
+                for (int q = 0; q < LB; q++) {
 #pragma unroll
                     for (int c = 0; c < NP; c++)
 #pragma unroll
@@ -217,9 +229,34 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
 #pragma unroll
                             for (int r = 0; r < G; r++)                  // :146-154 muladdto!(tacc[q], digit, row); a key bit with atilde = 0 is dropped below
                                 tacc[r][q][c][p] = cadd(tacc[r][q][c][p], cmul(zr[r][p], K[q][c][p]));
+                    if constexpr (EARLYQ && !LAST) {                     // the key bit's elements are free: the next digit's are requested now
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int p = 0; p < PTS; p++) load_keys_qp(blk, g + 1, q, p);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             } else {
                 // three polynomials: 36 accumulators + 9 key elements leave no room to hold all G digit points -- one rotation at a
                 // time, its points read from LDS as they are used (the parity buffers keep them until the step after next)
+                if constexpr (EARLYK && !LAST) {
+                    // (position, key bit)-major with the G digit points of the position in registers: each group of NP key elements is
+                    // re-requested for the next digit as soon as its G * NP multiply-adds are done
+#pragma unroll
+                    for (int p = 0; p < PTS; p++) {
+                        cplx zg[G];
+#pragma unroll
+                        for (int r = 0; r < G; r++) zg[r] = xb[r * M + tid + p * T];
+#pragma unroll
+                        for (int q = 0; q < LB; q++) {
+#pragma unroll
+                            for (int r = 0; r < G; r++)
+#pragma unroll
+                                for (int c = 0; c < NP; c++) tacc[r][q][c][p] = cadd(tacc[r][q][c][p], cmul(zg[r], K[q][c][p]));
+                            __builtin_amdgcn_sched_barrier(0); load_keys_qp(blk, g + 1, q, p); __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < G; r++) {
 #pragma unroll
@@ -231,9 +268,10 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
                             for (int c = 0; c < NP; c++) tacc[r][q][c][p] = cadd(tacc[r][q][c][p], cmul(zz, K[q][c][p]));
                     }
                 }
+                }
                 if (LAST) __syncthreads();                               // the products are published over these buffers
             }
-            if (!LAST) { __builtin_amdgcn_sched_barrier(0); load_keys(blk, g + 1); __builtin_amdgcn_sched_barrier(0); }
+            if (!LAST && !EARLYK && !EARLYQ) { __builtin_amdgcn_sched_barrier(0); load_keys(blk, g + 1); __builtin_amdgcn_sched_barrier(0); }
             if (LAST && G != 4 && !LEAN) { __builtin_amdgcn_sched_barrier(0); load_mono(); }
         };
         using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using CL = std::integral_constant<int, NP - 1>;

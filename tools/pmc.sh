@@ -1,4 +1,4 @@
-# usage (GPU box, repo root): [KERN=substr] [GROUPS="sq1 sq2 clk"] bash tools/pmc.sh <tag> -- <python program and args, e.g. bench.py --workload lmss --steps 2 --warmup 0 ...>
+# usage (GPU box, repo root): [KERN=substr] [PMC_GROUPS="sq1 sq2 clk"] bash tools/pmc.sh <tag> -- <python program and args, e.g. bench.py --workload lmss --steps 2 --warmup 0 ...>
 # Separate rocprofv3 --pmc passes (one counter group per run, only with --kernel-trace: the rule of MI355X_MICROARCH.md) of ONE python
 # command, then per-kernel means with the ratios that get read off them.  Groups: sq1 (wave cycles, waits, active), sq2 (LDS, instruction
 # counts), tcp (L1 <-> L2 requests), icache (instruction cache), clk (GRBM clock, L2 hit rate), fetch, write (fabric bytes, KiB).
@@ -14,7 +14,7 @@ declare -A G=(
  [icache]="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES"
  [clk]="GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU"
  [fetch]="FETCH_SIZE" [write]="WRITE_SIZE")
-for g in ${GROUPS:-sq1 sq2 clk}; do
+for g in ${PMC_GROUPS:-sq1 sq2 clk}; do
   rm -rf $O/pmc_$g
   ( cd $R && timeout 600 rocprofv3 --kernel-trace --pmc ${G[$g]} --output-format csv -d $O/pmc_$g -- python3 "$@" > $O/pmc_$g.log 2>&1 )
 done
