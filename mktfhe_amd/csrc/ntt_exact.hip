@@ -539,6 +539,33 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(tp[e], j));
                 ntt_forward<LOGN>(z, tw[0], lds, t);
+#ifndef MKT_EXACT_BLK_PIPE
+#define MKT_EXACT_BLK_PIPE 1
+#endif
+                if constexpr (LB > 1 && MKT_EXACT_BLK_PIPE) {
+                    // a block's other key bits: the rows of key bit q + 1 are requested before the multiply-adds of key bit q (two row
+                    // buffers in turn) -- at use, each was an exposed round trip per digit and key bit
+                    uint64_t kn[2][8];
+#pragma unroll
+                    for (int q = 0; q < LB; q++) {
+                        uint64_t kc[2][8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) { kc[0][e] = q == 0 ? kr0[0][e] : kn[0][e]; kc[1][e] = q == 0 ? kr0[1][e] : kn[1][e]; }
+                        if (q + 1 < LB) {
+                            const uint64_t *row = brk + (((size_t)(blk * LB + q + 1) * 2 * l + (size_t)(c * l + j)) * 2) * N + 8 * t;
+#pragma unroll
+                            for (int e = 0; e < 8; e++) { kn[0][e] = row[e]; kn[1][e] = row[N + e]; }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (ats[q] == 0) continue;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {                    // :63-68 / :146-154, exactly
+                            tacc[q][0][e] = pt_mac(tacc[q][0][e], z[e], unpack(kc[0][e]));
+                            tacc[q][1][e] = pt_mac(tacc[q][1][e], z[e], unpack(kc[1][e]));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < LB; q++) {
                     if (ats[q] == 0) continue;
@@ -548,6 +575,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(
                         tacc[q][0][e] = pt_mac(tacc[q][0][e], z[e], unpack(q == 0 ? kr0[0][e] : row[e]));
                         tacc[q][1][e] = pt_mac(tacc[q][1][e], z[e], unpack(q == 0 ? kr0[1][e] : row[N + e]));
                     }
+                }
                 }
             }
         }
