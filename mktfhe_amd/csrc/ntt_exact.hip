@@ -1555,14 +1555,18 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
                 zero(tu); zero(tv);
                 const uint64_t *vk = q == 0 ? a.crs : a.pub_b + (size_t)(q - 1) * l * N;
                 for (int j = 0; j < l; j++) {                                      // :279-294 u and v
+                    uint64_t kd[8], kv[8];                                         // key rows requested before the transform that hides them (at use: an exposed round trip per digit)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { kd[e] = ud[(size_t)j * N + 8 * t + e]; kv[e] = vk[(size_t)j * N + 8 * t + e]; }
+                    __builtin_amdgcn_sched_barrier(0);
                     Pt z[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(tp[e], j));
                     ntt_forward<LOGN>(z, tw[0], lds, t);
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        tu[e] = pt_mac(tu[e], z[e], unpack(ud[(size_t)j * N + 8 * t + e]));   // accumulators are lazy, [0, 2P)
-                        const Pt y = unpack(vk[(size_t)j * N + 8 * t + e]);
+                        tu[e] = pt_mac(tu[e], z[e], unpack(kd[e]));                // accumulators are lazy, [0, 2P)
+                        const Pt y = unpack(kv[e]);
                         tv[e] = q == 0 ? pt_msub(tv[e], z[e], y) : pt_mac(tv[e], z[e], y);     // mulsubto! with crs, muladdto! with b_i
                     }
                 }
@@ -1580,28 +1584,38 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int e = 0; e < 8; e++) tp[e] = gd.prep((uint32_t)crt_signed(tv[e]));   // :303-310
                 for (int j = 0; j < l; j++) {                                      // :313-320 w
+                    uint64_t fb[8], fa[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { fb[e] = uf[(size_t)(2 * j) * N + 8 * t + e]; fa[e] = uf[(size_t)(2 * j + 1) * N + 8 * t + e]; }
+                    __builtin_amdgcn_sched_barrier(0);
                     Pt z[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(tp[e], j));
                     ntt_forward<LOGN>(z, tw[0], lds, t);
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        tb[e] = pt_mac(tb[e], z[e], unpack(uf[(size_t)(2 * j) * N + 8 * t + e]));
-                        ta[e] = pt_mac(ta[e], z[e], unpack(uf[(size_t)(2 * j + 1) * N + 8 * t + e]));
+                        tb[e] = pt_mac(tb[e], z[e], unpack(fb[e]));
+                        ta[e] = pt_mac(ta[e], z[e], unpack(fa[e]));
                     }
                 }
             }
             const uint64_t *mrow = a.mono + (size_t)(at - 1) * N + 8 * t;
+            uint64_t mr[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) mr[e] = mrow[e];
             for (int q = 0; q <= np; q++) {                                        // :322-324 mul!(monomial, tacc); ifftto!; add!
                 Pt s[8];
+                uint32_t aw[8];                                                    // the words the lift is added to: requested before the inverse transform
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const Pt x = q == 0 ? tb[e] : (q == np ? ta[e] : unpack(sc[(size_t)q * N + 8 * t + e]));
-                    s[e] = pt_mont(x, unpack(mrow[e]));
+                    s[e] = pt_mont(x, unpack(mr[e]));
+                    aw[e] = acc[(size_t)q * N + e * NT + t];
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1>(s, tw[0], lds, t, kc.ninv);
 #pragma unroll
-                for (int e = 0; e < 8; e++) acc[(size_t)q * N + e * NT + t] += (uint32_t)crt_signed(s[e]);
+                for (int e = 0; e < 8; e++) acc[(size_t)q * N + e * NT + t] = aw[e] + (uint32_t)crt_signed(s[e]);
             }
         }
     }
