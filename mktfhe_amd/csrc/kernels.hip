@@ -1042,11 +1042,20 @@ __global__ __launch_bounds__((Plan<LOGM, LOGR>::NT)) __attribute__((amdgpu_waves
             for (int e = 0; e < R; e++) { tb[e] = cadd(tb[e], cmul(z[e], fbr[e])); ta[e] = cadd(ta[e], cmul(z[e], far[e])); }
         }
     };
+#ifndef MKT_CCS_RI_AHEAD
+#define MKT_CCS_RI_AHEAD 1
+#endif
     auto inv_words = [&](cplx (&z)[R], WORD (&w)[R][2]) {                        // fft.jl:74-81
+        cplx ri[R];                                                              // untwist factors requested before the transform (at use: an exposed round trip per inverse)
+        if (MKT_CCS_RI_AHEAD) {
+#pragma unroll
+            for (int e = 0; e < R; e++) ri[e] = a.tw.rootsinv[e * NT + t];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         fft_inverse<LOGM, LOGR, 1, true, MO1>(reinterpret_cast<cplx(&)[1][R]>(z), psi_l, lds, t, xs.lx);
 #pragma unroll
         for (int e = 0; e < R; e++) {
-            const cplx v = cmul(z[e], a.tw.rootsinv[e * NT + t]);
+            const cplx v = cmul(z[e], MKT_CCS_RI_AHEAD ? ri[e] : a.tw.rootsinv[e * NT + t]);
             w[e][0] = native<WORD>(v.re); w[e][1] = native<WORD>(-v.im);
         }
     };
