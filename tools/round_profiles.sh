@@ -34,7 +34,7 @@ if [ $PART = 5 ]; then      # bench lines only, AFTER the PMC summaries of this 
   line --steps 2 --warmup 1 --workload lmss_k2 --batch 16384 --no-roofline --no-cpu-baseline > $O/bench_lmss_k2_16384.json
   line --steps 2 --warmup 1 --workload kms2partyblock --batch 16384 --no-roofline > $O/bench_kms2partyblock_16384.json
   line --steps 2 --warmup 1 --workload kms4party --batch 8192 --no-roofline --no-cpu-baseline > $O/bench_kms4party_8192.json                 # config (3): one GPU's share of 65 536 gates
-  for w in kms2party kms2partyblock cggi lmss ccs2party; do line --steps 6 --warmup 3 --workload $w --arith exact --no-roofline --no-cpu-baseline --no-secondary > $O/bench_${w}_exact.json; done
+  for w in kms2party kms2partyblock cggi lmss lmss_k2 ccs2party; do line --steps 6 --warmup 3 --workload $w --arith exact --no-roofline --no-cpu-baseline --no-secondary > $O/bench_${w}_exact.json; done
 fi
 if [ $PART = 2 ]; then
   for w in kms2party cggi cggi_l2 lmss kms2partyblock kms4party; do
@@ -50,6 +50,6 @@ if [ $PART = 3 ]; then
   line --steps 2 --warmup 1 --workload lmss --batch 16384 --no-roofline --no-cpu-baseline > $O/bench_lmss_16384.json
   line --steps 2 --warmup 1 --workload lmss_k2 --batch 16384 --no-roofline --no-cpu-baseline > $O/bench_lmss_k2_16384.json
   bash tools/pmc_pass.sh $TAG lmss_k2 lmss_k2_16384 -- --batch 16384 > /dev/null
-  for w in kms2party kms2partyblock cggi lmss ccs2party; do line --steps 6 --warmup 3 --workload $w --arith exact --no-roofline --no-cpu-baseline --no-secondary > $O/bench_${w}_exact.json; done
+  for w in kms2party kms2partyblock cggi lmss lmss_k2 ccs2party; do line --steps 6 --warmup 3 --workload $w --arith exact --no-roofline --no-cpu-baseline --no-secondary > $O/bench_${w}_exact.json; done
 fi
 ls $O | tr '\n' ' '
