@@ -1014,6 +1014,101 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
         }
 }
 
+// KMS_block phase 1 (bootstrapping.jl:599-659) with ONE set of digit transforms per block.  The block adds
+//     sum_q mono[at_q] (*) ( sum_g z_g (*) K_{q,g} )        (:639-648; q the block's key bits, g the 2l digit polynomials)
+// in exact integers mod P, so the same value is   sum_g sum_q (mono[at_q] (*) z_g) (*) K_{q,g}:  each digit transform is multiplied by
+// the key bit's monomial row first (one product per key bit and digit) and then into the key bit's four rows, straight into the block's
+// four accumulators -- 2l forward transforms per block instead of blk_len x 2l (exact_kms_phase1_kernel<.., BLK> transforms the digits
+// again for every key bit: its per-key-bit accumulators leave no room to keep them), no per-key-bit accumulators, the same register
+// footprint.  Word-identical to that kernel (the Float64 mode cannot re-associate: every rounding is pinned there).
+template <int LOGN>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(MKT_EXACT_WPE, MKT_EXACT_WPE))) void exact_kms_block_phase1_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
+                                                                              const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe, int lwe_stride,
+                                                                              int pre_switched, int n, int l, int logB, int blk_len, size_t ngates, int rows_per_gate,
+                                                                              const int *__restrict__ slot_party, const int *__restrict__ slot_row, int logB_lev,
+                                                                              uint64_t *__restrict__ lev_out) {
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
+    const int t = threadIdx.x;
+    const uint4 *tw[1]; const int which[1] = {0};
+    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + 2 * NttLds<LOGN>::WORDS), t, NT, tw, which);   // two staging buffers (lift_pair), then the table
+    const NttConsts k = tab_consts<LOGN>(tab);
+    const size_t gate = blockIdx.x % ngates;
+    const int slot = (int)(blockIdx.x / ngates);
+    const size_t rot = gate * (size_t)rows_per_gate + slot;
+    const int party = slot_party[slot], row = slot_row[slot];
+    const uint32_t *at_src = lwe + gate * (size_t)lwe_stride + (size_t)party * n;
+    const uint64_t *brk = brk0 + (size_t)party * brk_party_stride;
+    const Gadget<uint64_t> gd(l, logB);
+    uint64_t acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[c][e] = 0;
+    if (t == 0) acc[0][0] = (uint64_t)1 << (64 - (row + 1) * logB_lev);           // :609-612 trivial RLEV row
+    const int msbit = 32 - LOGN - 1;
+    for (int blk = 0; blk < n / blk_len; blk++) {
+        bool any = false;
+        for (int q = 0; q < blk_len; q++) {
+            const uint32_t v0 = at_src[blk * blk_len + q];
+            any |= (pre_switched ? v0 : divbits<uint32_t>(v0, msbit)) != 0;
+        }
+        if (!__builtin_amdgcn_readfirstlane((int)any)) continue;                   // :638 for every key bit of the block
+        Pt sum[2][2][8];                                                           // [output polynomial][half]
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) { sum[pp][h][e].a = 0; sum[pp][h][e].b = 0; }
+        for (int c = 0; c < 2; c++)
+            for (int j = 0; j < l; j++) {
+                Pt z[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(gd.prep(c ? acc[1][e] : acc[0][e]), j));   // :625-633 decompto!
+                ntt_forward<LOGN>(z, tw[0], lds, t);
+                for (int q = 0; q < blk_len; q++) {
+                    const int i = blk * blk_len + q;
+                    const uint32_t v0 = at_src[i];
+                    const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+                    if (at == 0) continue;                                         // :638 per key bit
+                    const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
+                    const uint64_t *rowp = brk + (((size_t)i * 2 * l + (size_t)(c * l + j)) * 4) * N + 8 * t;   // [poly][half][N]
+                    Pt zm[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) zm[e] = pt_mont(z[e], unpack(mrow[e]));   // mono (*) z: canonical, the x of the multiply-adds below
+#pragma unroll
+                    for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+#pragma unroll
+                            for (int e = 0; e < 8; e++) sum[pp][h][e] = pt_mac(sum[pp][h][e], zm[e], unpack(rowp[(size_t)(pp * 2 + h) * N + e]));   // :639-648, re-associated
+                }
+            }
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) {
+            uint64_t w[8];
+            lift_pair<LOGN>(sum[pp], w, tw[0], k, lds, t);                         // :653
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[pp][e] += w[e];                        // :654
+        }
+    }
+    // :657 fftto!(tacc, acc): the row as split residue tables, Montgomery form
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            Pt z[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) z[e] = fwd_in(piece_of(acc[c][e], h), e);
+            ntt_forward<LOGN>(z, tw[0], lds, t);
+            uint64_t *o = lev_out + ((rot * 2 + c) * 2 + h) * (size_t)N + 8 * t;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = pack(Pt{montmul<P1, PI1>(z[e].a, RR1), montmul<P2, PI2>(z[e].b, RR2)});
+            __syncthreads();
+        }
+}
+
 // KMS phase 1 at l_gsw = 2, one key bit per step, laid out for THREE waves per SIMD (168 registers) on EVERY SIMD: ROTS = 2 rotations per
 // workgroup of four waves, side by side, sharing the staged twiddle table (2 x 8 + 16 KiB; three workgroups per CU).  Why four-wave
 // workgroups: the dispatcher deals two-wave workgroups unevenly -- six per CU land [2 4 3 3] waves per SIMD (tools/simd_place.hip) and the
@@ -1780,7 +1875,12 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
     MKT_NTT_DISPATCH(logN, {
         const size_t lds = lds_bytes<LN>(1, 2);                                      // two staging buffers: the halves of a lifted sum are inverse-transformed side by side
         hipError_t e = hipSuccess;
-        if (a.blk_len > 1) {
+        if (a.blk_len > 1 && a.wide != 0) {                                       // exact_wide = 0: the per-key-bit kernel below (tests force both)
+            last_rot_kernel = "exact_kms_block_phase1_kernel";
+            e = ntt_set_lds(exact_kms_block_phase1_kernel<LN>, lds); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((exact_kms_block_phase1_kernel<LN>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
+                               a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, a.blk_len, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
+        } else if (a.blk_len > 1) {
             e = ntt_set_lds(exact_kms_phase1_kernel<LN, true>, lds); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, true>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
                                a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, a.blk_len, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);

@@ -1070,6 +1070,13 @@ def test_exact_mode_kms_gates(require_gpu, p):
     acc_x = sx.blindrotate_(at, acc0.astype(np.uint64).copy())
     for j in range(B):
         assert np.array_equal(acc_x[j], RX.kms_blindrotate(p, keys, crs, at[j], acc0[j])), f"exact KMS blind rotation {j}"
+    if p.blk_len > 1:
+        # KMS_block has two phase-1 kernels: one set of digit transforms per block, each multiplied by a key bit's monomial row before the
+        # key rows (exact integers re-associate), and one that transforms the digits again for every key bit (exact_wide = 0) -- the same words
+        assert sx.last_kernel_name() == "exact_kms_block_phase1_kernel"
+        sx.set_option("exact_wide", 0)
+        assert np.array_equal(sx.blindrotate_(at, acc0.astype(np.uint64).copy()), acc_x) and sx.last_kernel_name() == "exact_kms_phase1_kernel"
+        sx.set_option("exact_wide", 4)
     for op in (0, 3):
         out = sx.gate(op, x, y)
         assert np.array_equal(out, np.stack([RX.kms_gate(p, so, keys, crs, op, x[j], y[j]) for j in range(B)])), f"exact KMS gate {op}"
