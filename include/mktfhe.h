@@ -129,8 +129,7 @@ int mkt_synchronize(mkt_ctx *ctx);
  * "rot_variant", "rot_stagger", "rot_split", "rot_wide" (latency variant: 0 auto, 1 never, 2 always), "rot_blkg" (block
  * schemes, rotations per workgroup: 0 auto, 1, 2, 4), "rot_map" (workgroup -> (ciphertext, slot) dealing: 0 plain, 1 XCD-aware),
  * "ccs_stagger", "ccs_pipe" (-1 auto, 0 never, 1 always), "exact_wide" (MKT_ARITH_EXACT KMS phase 1 at l_gsw = 2: kernels 0 .. 4),
- * "exact_kany" (MKT_ARITH_EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel also at k <= 3, 2 = the any-shape
- * register kernel also where a specialised one exists).  Results never
+ * "exact_kany" (MKT_ARITH_EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel also at k <= 3).  Results never
  * depend on them.  The environment (MKT_ROT_*, MKT_CCS_*) seeds them once, at mkt_ctx_create; no batch call reads it. */
 int mkt_set_option(mkt_ctx *ctx, const char *name, int value);
 /* base name of the blind-rotation kernel the last batch call of this context launched ("" before the first) */

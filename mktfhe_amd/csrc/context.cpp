@@ -40,12 +40,12 @@ struct Tune {
                             // (ciphertext, party) on one XCD at one time -- 25 % less fabric traffic at KMS k = 2 (FETCH_SIZE 15.3 -> 11.4 GB per launch,
                             // L2 misses -27 %), time -0.3 ... -2.5 % (profiles/r04j_bench_kms2_n1024_map{0,1}_pmc.txt)
     int exact_wide = 4;     // EXACT KMS phase 1 at l_gsw = 2: 0 one product chain per term, 1 wide (64-bit) digit-product accumulation, 2 wide on three waves per SIMD (four-wave workgroups), 3 wide with paired transforms, 4 the same with the first sum's key rows requested ahead (default)
-    int exact_kany = 0;     // EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel (sums in memory) also where the register kernels serve (k <= 3); 2 = the any-shape register kernel also at (k = 2, block length 3); tests
+    int exact_kany = 0;     // EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel (sums in memory) also where the register kernels serve (k <= 3); tests
     void from_env() {
         rot_variant = env_int("MKT_ROT_VARIANT", rot_variant); rot_stagger = env_int("MKT_ROT_STAGGER", rot_stagger);
         rot_split = env_int("MKT_ROT_SPLIT", rot_split); rot_wide = env_int("MKT_ROT_WIDE", rot_wide);
         rot_blkg = env_int("MKT_ROT_BLKG", rot_blkg); ccs_stagger = env_int("MKT_CCS_STAGGER", ccs_stagger);
-        ccs_pipe = env_int("MKT_CCS_PIPE", ccs_pipe); exact_wide = env_int("MKT_EXACT_WIDE", exact_wide); rot_map = env_int("MKT_ROT_MAP", rot_map);
+        ccs_pipe = env_int("MKT_CCS_PIPE", ccs_pipe); exact_wide = env_int("MKT_EXACT_WIDE", exact_wide); rot_map = env_int("MKT_ROT_MAP", rot_map); exact_kany = env_int("MKT_EXACT_KANY", exact_kany);
     }
 };
 }  // namespace
@@ -322,7 +322,7 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
     if (c->exact && (p.k > 1 || (mkt::is_block(p.scheme) && p.blk_len != 3))) {   // CGGI / LMSS with RLWE length 2, 3 or another block length: the general kernel
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_exact_blindrotate_kr(c->logN, c->d_ntt, reinterpret_cast<const uint64_t *>(c->ks->d_brk), reinterpret_cast<const uint64_t *>(c->ks->d_monomial),
-                                                    lwe, stride, pre, p.n, p.k, p.l_gsw, p.logB_gsw, mkt::is_block(p.scheme) ? p.blk_len : 1, (uint32_t *)acc, B, c->stream, c->tune.exact_kany == 2));
+                                                    lwe, stride, pre, p.n, p.k, p.l_gsw, p.logB_gsw, mkt::is_block(p.scheme) ? p.blk_len : 1, (uint32_t *)acc, B, c->stream));
         return MKT_OK;
     }
     if (c->exact) {          // CGGI / LMSS, RLWE length 1, 32-bit ring (exact_gate_ok): every product exact mod 2^32

@@ -154,7 +154,7 @@ hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_
                                     int pre_switched, int n, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s);
 // the same for any RLWE length kr = 1 .. 3 and any block length (digit transforms recomputed per key bit of a block); brk [n][(kr+1) l][kr+1][N]
 hipError_t launch_exact_blindrotate_kr(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
-                                       int pre_switched, int n, int kr, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s, int force_general = 0);   // force_general: the any-shape kernel also at (kr = 2, block length 3), which has a register-resident one
+                                       int pre_switched, int n, int kr, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s);
 // any RLWE length (run-time kr): the transform-domain sums in scratch [B][2][kr+1][N] packed residue pairs
 hipError_t launch_exact_blindrotate_kany(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
                                          int pre_switched, int n, int kr, int l, int logB, int blk_len, uint32_t *acc, uint64_t *scratch, size_t B, hipStream_t s);

@@ -473,14 +473,11 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_polymul_kernel(cons
 // One workgroup of N / 8 threads per rotation; the accumulator lives in registers (slot e = coefficient e*NT + t).  Key
 // and monomial tables are in the transform's natural order, Montgomery form.
 // ------------------------------------------------------------------------------------------------
-#ifndef MKT_EXACT_NP3_WPE
-#define MKT_EXACT_NP3_WPE 2
-#endif
-template <int LOGN, int LB, int NP = 2>
-__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(NP > 2 ? MKT_EXACT_NP3_WPE : 1))) void exact_blindrotate_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk,
+template <int LOGN, int LB>
+__global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk,
                                                                               const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe,
                                                                               int lwe_stride, int pre_switched, int n, int l, int logB, uint32_t *__restrict__ acc_io) {
-    constexpr int N = 1 << LOGN, NT = N >> NLR;      // NP = RLWE length + 1 accumulator polynomials (b, a_0 ..): 2, or 3 for block length 3 at RLWE length 2 (BASELINE configs[4])
+    constexpr int N = 1 << LOGN, NT = N >> NLR;
     uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);
     const int t = threadIdx.x;
     const uint4 *tw[1]; const int which[1] = {0};
@@ -488,11 +485,11 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
     const NttConsts k = tab_consts<LOGN>(tab);
     const size_t rot = blockIdx.x;
     const uint32_t *at_src = lwe + rot * (size_t)lwe_stride;
-    uint32_t *accg = acc_io + rot * NP * (size_t)N;
+    uint32_t *accg = acc_io + rot * 2 * (size_t)N;
     const Gadget<uint32_t> gd(l, logB);
-    uint32_t acc[NP][8];
+    uint32_t acc[2][8];
 #pragma unroll
-    for (int c = 0; c < NP; c++)
+    for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[c][e] = accg[c * N + e * NT + t];
     const int msbit = 32 - LOGN - 1;
@@ -506,11 +503,11 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
             any |= ats[q] != 0;
         }
         if (!any) continue;                                              // :48 / :145 (an all-zero block adds 0)
-        Pt tacc[LB][NP][8];
+        Pt tacc[LB][2][8];
 #pragma unroll
         for (int q = 0; q < LB; q++)
 #pragma unroll
-            for (int pp = 0; pp < NP; pp++)
+            for (int pp = 0; pp < 2; pp++)
 #pragma unroll
                 for (int e = 0; e < 8; e++) { tacc[q][pp][e].a = 0; tacc[q][pp][e].b = 0; }
         // the monomial row of the (first non-zero) key bit, requested a whole step ahead of its use (at use it was one exposed L2 round
@@ -524,21 +521,18 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
             for (int e = 0; e < 8; e++) mr0[e] = mrow[e];
         }
-#pragma unroll
-        for (int c = 0; c < NP; c++) {
+        for (int c = 0; c < 2; c++) {
             uint32_t tp[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) tp[e] = gd.prep(acc[c][e]);                      // :50-51 / :131-132 decompto!
+            for (int e = 0; e < 8; e++) tp[e] = gd.prep(c ? acc[1][e] : acc[0][e]);      // :50-51 / :131-132 decompto!
             for (int j = 0; j < l; j++) {
                 // the rows of the block's first key bit are requested ahead of the digit's transform (at use, each was one exposed L2
                 // round trip per digit); a block's other key bits load theirs at use -- 96 accumulator registers leave no room
-                uint64_t kr0[NP][8];
+                uint64_t kr0[2][8];
                 {
-                    const uint64_t *row0 = brk + (((size_t)(blk * LB) * NP * l + (size_t)(c * l + j)) * NP) * N + 8 * t;
+                    const uint64_t *row0 = brk + (((size_t)(blk * LB) * 2 * l + (size_t)(c * l + j)) * 2) * N + 8 * t;
 #pragma unroll
-                    for (int pp = 0; pp < NP; pp++)
-#pragma unroll
-                        for (int e = 0; e < 8; e++) kr0[pp][e] = row0[(size_t)pp * N + e];
+                    for (int e = 0; e < 8; e++) { kr0[0][e] = row0[e]; kr0[1][e] = row0[N + e]; }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 Pt z[8];
@@ -548,7 +542,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #ifndef MKT_EXACT_BLK_PIPE
 #define MKT_EXACT_BLK_PIPE 1
 #endif
-                if constexpr (LB > 1 && NP == 2 && MKT_EXACT_BLK_PIPE) {
+                if constexpr (LB > 1 && MKT_EXACT_BLK_PIPE) {
                     // a block's other key bits: the rows of key bit q + 1 are requested before the multiply-adds of key bit q (two row
                     // buffers in turn) -- at use, each was an exposed round trip per digit and key bit
                     uint64_t kn[2][8];
@@ -575,18 +569,18 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int q = 0; q < LB; q++) {
                     if (ats[q] == 0) continue;
-                    const uint64_t *row = brk + (((size_t)(blk * LB + q) * NP * l + (size_t)(c * l + j)) * NP) * N + 8 * t;
+                    const uint64_t *row = brk + (((size_t)(blk * LB + q) * 2 * l + (size_t)(c * l + j)) * 2) * N + 8 * t;
 #pragma unroll
-                    for (int pp = 0; pp < NP; pp++)
-#pragma unroll
-                        for (int e = 0; e < 8; e++)                      // :63-68 / :146-154, exactly
-                            tacc[q][pp][e] = pt_mac(tacc[q][pp][e], z[e], unpack(q == 0 ? kr0[pp][e] : row[(size_t)pp * N + e]));
+                    for (int e = 0; e < 8; e++) {                        // :63-68 / :146-154, exactly
+                        tacc[q][0][e] = pt_mac(tacc[q][0][e], z[e], unpack(q == 0 ? kr0[0][e] : row[e]));
+                        tacc[q][1][e] = pt_mac(tacc[q][1][e], z[e], unpack(q == 0 ? kr0[1][e] : row[N + e]));
+                    }
                 }
                 }
             }
         }
 #pragma unroll
-        for (int pp = 0; pp < NP; pp++) {
+        for (int pp = 0; pp < 2; pp++) {
             Pt s2[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) { s2[e].a = 0; s2[e].b = 0; }
@@ -603,7 +597,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
         }
     }
 #pragma unroll
-    for (int c = 0; c < NP; c++)
+    for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int e = 0; e < 8; e++) accg[c * N + e * NT + t] = acc[c][e];
 }
@@ -650,6 +644,34 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kr_kern
         for (int pp = 0; pp < NP; pp++)
 #pragma unroll
             for (int e = 0; e < 8; e++) { sum[pp][e].a = 0; sum[pp][e].b = 0; }
+        if (blk_len > 1) {
+            // a block of several key bits: ONE set of digit transforms; sum_q mono_q (*) (sum_g z_g (*) K_qg) = sum_g sum_q (mono_q (*) z_g) (*) K_qg
+            // in exact integers mod P -- each transform is multiplied by the key bit's monomial row, then into the key bit's rows, straight
+            // into the block's sums (no per-key-bit accumulators, no second transform of the same digits)
+#pragma unroll
+            for (int c = 0; c < NP; c++)
+                for (int j = 0; j < l; j++) {
+                    Pt z[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) z[e] = res_small(gd.digit(gd.prep(acc[c][e]), j));   // :131-132 decompto!
+                    ntt_forward<LOGN>(z, tw[0], lds, t);
+                    for (int q = 0; q < blk_len; q++) {
+                        const int i = blk * blk_len + q;
+                        const uint32_t v0 = at_src[i];
+                        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
+                        if (at == 0) continue;                                     // :145
+                        const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
+                        const uint64_t *row = brk + (((size_t)i * NP * l + (size_t)(c * l + j)) * NP) * N + 8 * t;   // [row c l + j][poly][N]
+                        Pt zm[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) zm[e] = pt_mont(z[e], unpack(mrow[e]));
+#pragma unroll
+                        for (int pp = 0; pp < NP; pp++)
+#pragma unroll
+                            for (int e = 0; e < 8; e++) sum[pp][e] = pt_mac(sum[pp][e], zm[e], unpack(row[(size_t)pp * N + e]));   // :146-157, re-associated
+                    }
+                }
+        } else
         for (int q = 0; q < blk_len; q++) {
             const int i = blk * blk_len + q;
             const uint32_t v0 = at_src[i];
@@ -1823,7 +1845,7 @@ hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_
 }
 
 hipError_t launch_exact_blindrotate_kr(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
-                                       int pre_switched, int n, int kr, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s, int force_general) {
+                                       int pre_switched, int n, int kr, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
     if (kr < 1 || kr > 3 || blk_len < 1 || n % blk_len) return hipErrorInvalidValue;
     last_rot_kernel = "exact_blindrotate_kr_kernel";
@@ -1832,11 +1854,7 @@ hipError_t launch_exact_blindrotate_kr(int logN, const uint64_t *tab, const uint
         hipLaunchKernelGGL((exact_blindrotate_kr_kernel<LN, KRV>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, blk_len, acc); } while (0)
     MKT_NTT_DISPATCH(logN, {
         const size_t lds = lds_bytes<LN>(1);
-        if (kr == 2 && blk_len == 3 && !force_general) {     // BASELINE configs[4]'s shape: one decomposition per block, the three key bits' sums in registers (a third of the digit transforms)
-            last_rot_kernel = "exact_blindrotate_kernel";
-            hipError_t e = ntt_set_lds(exact_blindrotate_kernel<LN, 3, 3>, lds); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((exact_blindrotate_kernel<LN, 3, 3>), dim3((unsigned)B), dim3(1 << (LN - NLR)), lds, s, tb, brk, mono, lwe, lwe_stride, pre_switched, n, l, logB, acc);
-        } else if (kr == 1) MKT_EXACT_KR_LAUNCH(1); else if (kr == 2) MKT_EXACT_KR_LAUNCH(2); else MKT_EXACT_KR_LAUNCH(3);
+        if (kr == 1) MKT_EXACT_KR_LAUNCH(1); else if (kr == 2) MKT_EXACT_KR_LAUNCH(2); else MKT_EXACT_KR_LAUNCH(3);
     });
 #undef MKT_EXACT_KR_LAUNCH
     return hipGetLastError();

@@ -1193,9 +1193,6 @@ def test_exact_mode_cggi_gates(require_gpu, p):
     assert ("kany" in sx.last_kernel_name()) == (p.k > 3)
     sx.set_option("exact_kany", 1)
     assert np.array_equal(sx.blindrotate_(at, acc0.astype(np.uint32).copy()), acc_x) and "kany" in sx.last_kernel_name()
-    sx.set_option("exact_kany", 2)           # the any-shape register kernel where a specialised one exists (k = 2, block length 3: three key bits' sums in registers)
-    assert np.array_equal(sx.blindrotate_(at, acc0.astype(np.uint32).copy()), acc_x)
-    assert ("_kr_" in sx.last_kernel_name()) == (p.k in (2, 3) or (p.k == 1 and p.blk_len not in (0, 1, 3)))
     sx.set_option("exact_kany", 0)
     for op in (0, 3, 5):
         out = sx.gate(op, x, y)
