@@ -494,8 +494,9 @@ def exact_rot_roofline(mk, p, B, t, kern, workload):
         per_poly = 2 * lu * fwd + 2 * inv + 4 * lu * mac * N + 8 * N
         instr = sum((idx + 2) * per_poly for idx in range(p.k)) * p.n * B
         rows = 1
-    elif p.W == 64:      # split tables: 2l forward, (low, high) x (b, a) = 4 inverses, 2 x 2 x 2l MACs per key bit
-        per_blk = 2 * l * fwd * (LB if LB > 1 else 1) + 4 * inv + LB * (8 * l * mac * N) + 16 * N
+    elif p.W == 64:      # split tables: 2l forward and (low, high) x (b, a) = 4 inverses per block, 2 x 2 x 2l MACs per key bit, 4 monomial products per key bit of a block
+        # (what the ALGORITHM needs: until round 5 the KMS_block kernel transformed the digits once per key bit and this line counted that too)
+        per_blk = 2 * l * fwd + 4 * inv + LB * (8 * l * mac * N) + (LB * 4 * mac * N if LB > 1 else 0) + 16 * N
         instr = per_blk * (p.n // LB) * rows * B
     else:                # 32-bit ring, RLWE length kr: (kr+1) l forward and kr+1 inverses per block, (kr+1)^2 l MACs per key bit, monomial product in the transform domain
         kr = p.k
