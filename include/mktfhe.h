@@ -129,11 +129,19 @@ int mkt_synchronize(mkt_ctx *ctx);
  * "rot_variant", "rot_stagger", "rot_split", "rot_wide" (latency variant: 0 auto, 1 never, 2 always), "rot_blkg" (block
  * schemes, rotations per workgroup: 0 auto, 1, 2, 4), "rot_map" (workgroup -> (ciphertext, slot) dealing: 0 plain, 1 XCD-aware),
  * "ccs_stagger", "ccs_pipe" (-1 auto, 0 never, 1 always), "exact_wide" (MKT_ARITH_EXACT KMS phase 1 at l_gsw = 2: kernels 0 .. 4),
- * "exact_kany" (MKT_ARITH_EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel also at k <= 3).  Results never
+ * "exact_kany" (MKT_ARITH_EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel also at k <= 3),
+ * "exact_impl" (MKT_ARITH_EXACT blind rotation of CGGI with RLWE length 1 and of KMS phase 1, and mkt_exact_polymul_batch:
+ * 0 = the integer NTT over two 30-bit primes, 1 = Float64 FMA transforms over 16-bit key limbs wherever the proven rounding bound
+ * certifies the loaded keys, -1 (default) = 1 for the gate paths; both give the same words).  Results never
  * depend on them.  The environment (MKT_ROT_*, MKT_CCS_*) seeds them once, at mkt_ctx_create; no batch call reads it. */
 int mkt_set_option(mkt_ctx *ctx, const char *name, int value);
 /* base name of the blind-rotation kernel the last batch call of this context launched ("" before the first) */
 const char *mkt_last_kernel_name(const mkt_ctx *ctx);
+/* diagnostics of the Float64-pipe implementation of MKT_ARITH_EXACT: "fx_available" (1: the loaded keys are certified and exact_impl
+ * admits it), "fx_bound" (proven bound on |computed - exact| of a rounded product sum for the loaded keys; must stay below 1/2),
+ * "fx_kmax" (largest transform-domain magnitude of the loaded key limbs), "fx_last_resid" (largest rounding distance met by the last
+ * mkt_exact_polymul_batch under exact_impl = 1) */
+int mkt_get_metric(mkt_ctx *ctx, const char *name, double *out);
 
 /* twiddle tables (fft.jl:31-41): which = 0 Psi, 1 Psiinv, 2 roots, 3 rootsinv; M complex each.
  * mkt_set_twiddles lets a caller install the reference's own ffter tables verbatim. */

@@ -39,6 +39,7 @@ SYMBOLS = {
     "mkt_synchronize": (_i, [_vp]),
     "mkt_set_option": (_i, [_vp, C.c_char_p, _i]),
     "mkt_last_kernel_name": (C.c_char_p, [_vp]),
+    "mkt_get_metric": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "mkt_get_twiddles": (_i, [_vp, _i, _vp]),
     "mkt_set_twiddles": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mkt_make_twiddles": (_i, [_i, _i, _vp]),

@@ -41,7 +41,10 @@ struct Tune {
                             // L2 misses -27 %), time -0.3 ... -2.5 % (profiles/r04j_bench_kms2_n1024_map{0,1}_pmc.txt)
     int exact_wide = 4;     // EXACT KMS phase 1 at l_gsw = 2: 0 one product chain per term, 1 wide (64-bit) digit-product accumulation, 2 wide on three waves per SIMD (four-wave workgroups), 3 wide with paired transforms, 4 the same with the first sum's key rows requested ahead (default)
     int exact_kany = 0;     // EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel (sums in memory) also where the register kernels serve (k <= 3); tests
+    int exact_impl = -1;    // EXACT blind rotation of CGGI (RLWE length 1) and KMS phase 1: 0 = integer NTT over two 30-bit primes (ntt_exact.hip), 1 / -1 = the Float64 pipe
+                            // (fx_exact.hip: FMA transforms over 16-bit key limbs) wherever its error bound certifies the loaded keys (fx_usable), the integer NTT elsewhere
     void from_env() {
+        exact_impl = env_int("MKT_EXACT_IMPL", exact_impl);
         rot_variant = env_int("MKT_ROT_VARIANT", rot_variant); rot_stagger = env_int("MKT_ROT_STAGGER", rot_stagger);
         rot_split = env_int("MKT_ROT_SPLIT", rot_split); rot_wide = env_int("MKT_ROT_WIDE", rot_wide);
         rot_blkg = env_int("MKT_ROT_BLKG", rot_blkg); ccs_stagger = env_int("MKT_CCS_STAGGER", ccs_stagger);
@@ -81,11 +84,16 @@ struct KeySet {
     int rtot = 1;
     int *d_slot_party = nullptr, *d_slot_row = nullptr;
     uint64_t *d_ntt = nullptr;   // MKT_ARITH_EXACT: psi_rev (negated) | N^-1, N^-1 w | N^-1 2^32, N^-1 2^32 w, with Shoup companions
+    // MKT_ARITH_EXACT on the Float64 pipe (fx_exact.hip), where the shape has the kernel: the engine's own tables and the bootstrapping key as limb transforms
+    cplx *d_fx_tab = nullptr;    // fx_om | fx_tw | fx_nat, M each
+    cplx *d_fx_brk = nullptr;  size_t fx_brk_party_cplx = 0;   // [party][n][2l][2][W/16][M], scaled by 1 / M
+    unsigned long long *d_fx_stat = nullptr;   // [0] largest |key transform value|^2 over the loaded keys, [1] largest rounding distance of the last fx polymul (bit patterns)
+    double fx_kmax = 0.0;        // sqrt of [0], read back after every key load
     ~KeySet() {
         int prev = -1;
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != device) (void)hipSetDevice(device);
-        void *ptrs[] = {d_tw, d_monomial, d_brk, d_ksk, d_rlk_d, d_rlk_f, d_pub, d_crs, d_slot_party, d_slot_row, d_ntt};
+        void *ptrs[] = {d_tw, d_monomial, d_brk, d_ksk, d_rlk_d, d_rlk_f, d_pub, d_crs, d_slot_party, d_slot_row, d_ntt, d_fx_tab, d_fx_brk, d_fx_stat};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     }
@@ -109,13 +117,18 @@ struct mkt_ctx {
     uint32_t *ws_lin = nullptr;
     void *ws_acc = nullptr;
     cplx *ws_lev = nullptr, *ws_scratch = nullptr;
+    void *ws_fxacc = nullptr;    // fx_exact.hip, KMS: the phase-1 rows as ring words [gates][rtot][2][N] before they become split residue tables
     uint32_t *ws_ksd = nullptr; size_t ws_ksd_words = 0;   // key switch: prepared digit words + partial sums per slab (grows with the largest batch seen)
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;
     Tune tune;
     const char *last_rot_kernel = "";   // name of the blind-rotation kernel the last call launched (mkt_last_kernel_name)
+    double fx_last_resid = 0.0;         // fx polymul: largest |q - round(q)| of the last call
 
+    const cplx *fx_om() const { return ks->d_fx_tab; }
+    const cplx *fx_tw() const { return ks->d_fx_tab + M; }
+    const cplx *fx_nat() const { return ks->d_fx_tab + 2 * (size_t)M; }
     mktd::TwPtrs twp() const { return mktd::TwPtrs{ks->d_tw, ks->d_tw + M, ks->d_tw + 2 * (size_t)M, ks->d_tw + 3 * (size_t)M}; }
     bool keys_shared() const { return ks.use_count() > 1; }
 };
@@ -154,7 +167,10 @@ void clear_spans(mkt_ctx *c) {
 size_t poly_bytes(const mkt_ctx *c) { return (size_t)c->p.N * c->sh.word; }
 
 // transform `npolys` coefficient-form polynomials (host) into TransPolys at `dst` (device)
-int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt, bool small = false) {   // small: coefficients far below 2^32 in magnitude (monomials): never split
+int fx_after_key_load(mkt_ctx *c);
+bool fx_usable(const mkt_ctx *c);
+mktd::FxRotArgs fx_rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre);
+int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt, bool small = false, cplx *fx_dst = nullptr) {   // small: coefficients far below 2^32 in magnitude (monomials): never split; fx_dst: also as limb transforms (fx_exact.hip)
     if (c->exact && fmt != MKT_FMT_INT_COEFF) return fail(c, MKT_ERR_UNSUPPORTED, "an MKT_ARITH_EXACT context takes keys in integer form (MKT_FMT_INT_COEFF)");
     if (fmt == MKT_FMT_F64_FFT) {   // the reference's Trans* values: copy, then natural -> device point order
         cplx *tmpc = nullptr;
@@ -174,9 +190,11 @@ int upload_polys(mkt_ctx *c, const void *host, size_t npolys, cplx *dst, int fmt
     if (e == hipSuccess) e = !c->exact ? mktd::launch_transform_fwd(c->logM, c->p.W, c->twp(), tmp, dst, npolys, c->dev_order, c->stream)
                            : (c->split == 2 && !small) ? mktd::launch_ntt_fwd_split(c->logN, c->d_ntt, tmp, reinterpret_cast<uint64_t *>(dst), npolys, c->stream)   // 2 residue polynomials per input
                            : mktd::launch_ntt_fwd(c->logN, c->p.W, c->d_ntt, tmp, reinterpret_cast<uint64_t *>(dst), npolys, 1, c->stream);   // N residues = the bytes of M complex
+    if (e == hipSuccess && fx_dst) e = mktd::launch_fx_key_fwd(c->logM, c->p.W, c->fx_om(), c->fx_tw(), tmp, fx_dst, npolys, c->ks->d_fx_stat, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) return hipfail(c, e, "key pre-transform");
+    if (fx_dst) return fx_after_key_load(c);
     return MKT_OK;
 }
 
@@ -221,13 +239,15 @@ int ensure_workspace(mkt_ctx *c, size_t gates) {
     if (c->ws_acc) (void)hipFree(c->ws_acc);
     if (c->ws_lev) (void)hipFree(c->ws_lev);
     if (c->ws_scratch) (void)hipFree(c->ws_scratch);
-    c->ws_lin = nullptr; c->ws_acc = nullptr; c->ws_lev = nullptr; c->ws_scratch = nullptr; c->ws_gates = 0;
+    if (c->ws_fxacc) (void)hipFree(c->ws_fxacc);
+    c->ws_lin = nullptr; c->ws_acc = nullptr; c->ws_lev = nullptr; c->ws_scratch = nullptr; c->ws_fxacc = nullptr; c->ws_gates = 0;
     const mkt_params &p = c->p;
     HIPCHK(c, hipMalloc((void **)&c->ws_lin, gates * (size_t)c->sh.lwe_len * 4));
     HIPCHK(c, hipMalloc(&c->ws_acc, gates * (size_t)(1 + c->sh.kacc) * poly_bytes(c)));
     if (mkt::is_kms(p.scheme)) {
         HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * (size_t)c->ks->rtot * 2 * c->M * sizeof(cplx) * c->split));
         HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)2 * (p.k + 1) * c->M * sizeof(cplx) * c->split));
+        if (c->ks->d_fx_brk) HIPCHK(c, hipMalloc(&c->ws_fxacc, gates * (size_t)c->ks->rtot * 2 * poly_bytes(c)));
     } else if (p.scheme == MKT_CCS) {
         HIPCHK(c, hipMalloc((void **)&c->ws_lev, gates * 3 * poly_bytes(c)));    // v scratch (ring words): parked v + two hand-off slots
         HIPCHK(c, hipMalloc((void **)&c->ws_scratch, gates * (size_t)(p.k + 1) * c->M * sizeof(cplx)));
@@ -309,7 +329,16 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         q.pub_b = reinterpret_cast<const uint64_t *>(c->ks->d_pub); q.crs = reinterpret_cast<const uint64_t *>(c->ks->d_crs);
         q.lin_for_tv = lin_for_tv; q.acc = reinterpret_cast<uint64_t *>(acc); q.scratch = reinterpret_cast<uint64_t *>(scratch); q.phase1_only = 0; q.wide = c->tune.exact_wide;
         Timer tm(c, 1);
+        if (p.scheme == MKT_KMS && fx_usable(c) && c->ws_fxacc) {   // phase 1 on the Float64 pipe: rows as ring words, then as split residue tables for the integer phase 2
+            mktd::FxRotArgs f = fx_rot_args(c, lwe, stride, pre);
+            f.init_mode = 1; f.acc_io = c->ws_fxacc; f.ngates = B;
+            const size_t nrot = B * (size_t)c->ks->rtot;
+            HIPCHK(c, mktd::launch_fx_blindrotate(c->logM, p.W, f, nrot, c->stream));
+            HIPCHK(c, mktd::launch_ntt_fwd_split(c->logN, c->d_ntt, c->ws_fxacc, q.levkey, nrot * 2, c->stream));
+            q.phase2_only = 1;
+        }
         HIPCHK(c, mktd::launch_exact_kms(c->logN, c->d_ntt, q, B, c->stream));
+        if (q.phase2_only) mktd::last_rot_kernel = "fx_blindrotate_kernel";
         return MKT_OK;
     }
     if (c->exact && (p.k > 3 || c->tune.exact_kany == 1)) {   // CGGI / LMSS, any RLWE length: sums in memory
@@ -323,6 +352,13 @@ int do_blindrotate(mkt_ctx *c, const uint32_t *lwe, int stride, int pre, const u
         Timer tm(c, 1);
         HIPCHK(c, mktd::launch_exact_blindrotate_kr(c->logN, c->d_ntt, reinterpret_cast<const uint64_t *>(c->ks->d_brk), reinterpret_cast<const uint64_t *>(c->ks->d_monomial),
                                                     lwe, stride, pre, p.n, p.k, p.l_gsw, p.logB_gsw, mkt::is_block(p.scheme) ? p.blk_len : 1, (uint32_t *)acc, B, c->stream));
+        return MKT_OK;
+    }
+    if (c->exact && p.scheme == MKT_CGGI && fx_usable(c)) {   // CGGI on the Float64 pipe (fx_exact.hip)
+        mktd::FxRotArgs f = fx_rot_args(c, lwe, stride, pre);
+        f.init_mode = 0; f.acc_io = acc; f.ngates = B;
+        Timer tm(c, 1);
+        HIPCHK(c, mktd::launch_fx_blindrotate(c->logM, p.W, f, B, c->stream));
         return MKT_OK;
     }
     if (c->exact) {          // CGGI / LMSS, RLWE length 1, 32-bit ring (exact_gate_ok): every product exact mod 2^32
@@ -491,6 +527,48 @@ bool exact_gate_ok(const mkt_ctx *c) {
 #define MKT_F64_OR_EXACT_KMS(c) do { if ((c) && (c)->exact && !(mkt::is_mk((c)->p.scheme) && exact_gate_ok(c))) return fail((c), MKT_ERR_UNSUPPORTED, "on an MKT_ARITH_EXACT context this entry point serves the multi-key gate paths only"); } while (0)
 #define MKT_F64_ONLY(c) do { if ((c) && (c)->exact) return fail((c), MKT_ERR_UNSUPPORTED, "this entry point is the Float64-reference gate path; not offered by an MKT_ARITH_EXACT context"); } while (0)
 
+// ---- MKT_ARITH_EXACT on the Float64 pipe (fx_exact.hip) ----
+// Which shapes keep a second copy of the bootstrapping key as limb transforms: CGGI with RLWE length 1 and KMS (phase 1), gadget lengths the kernel holds in registers.
+bool fx_shape(const mkt_ctx *c) {
+    const mkt_params &p = c->p;
+    return c->exact && ((p.scheme == MKT_CGGI && p.k == 1) || p.scheme == MKT_KMS) && mktd::fx_supported(c->logM, p.W, p.l_gsw);
+}
+// Proven bound on |computed coefficient - exact integer| of one rounded sum  sum_g d_g (*) limb_g  (DESIGN.md section 2), u = 2^-53:
+//   transform-domain errors reach a coefficient through the 1-norm:  (gamma_f + gamma_k + gamma_m) sum_g |d_g|_2 |limb_g|_2
+//   the inverse's own roundings are relative to the 2-norm of what it transforms:  gamma_i sum_g |d_g|_2 max_r |K_g[r]|
+// with |d_g|_2 <= sqrt(N) 2^(logB-1), |limb_g|_2 <= sqrt(N) 2^15, max_r |K[r]| MEASURED over the loaded key (kmax; a random key sits near
+// 4 sqrt(N) 2^15 / sqrt(3), an adversarial one at N 2^15 fails the bound and the integer NTT serves), per-stage constants 5.5 u (6-operation
+// butterfly incl. the rounded twiddle), 1.5 u (product-free stages), 3 u (twist / untwist), (2 + 4 l) u for the multiply-add chain.
+double fx_bound(const mkt_ctx *c, double kmax) {
+    const mkt_params &p = c->p;
+    const double u = std::ldexp(1.0, -53), g2 = 2.0 * p.l_gsw;
+    const double gt = (3.0 + 5.5 * (c->logM - 2) + 1.5 * 2) * u, gm = (2.0 + 2.0 * g2) * u;
+    const double dn = std::sqrt((double)p.N) * std::ldexp(1.0, p.logB_gsw - 1), kn = std::sqrt((double)p.N) * 32768.0;
+    return (gt + (gt + u) + gm) * g2 * dn * kn + gt * g2 * dn * kmax * (1.0 + 1e-6);
+}
+bool fx_usable(const mkt_ctx *c) {
+    if (!c->ks->d_fx_brk || c->tune.exact_impl == 0 || c->ks->fx_kmax <= 0.0) return false;
+    const mkt_params &p = c->p;
+    if (2.0 * p.l_gsw * p.N * std::ldexp(1.0, p.logB_gsw - 1) * 32768.0 >= std::ldexp(1.0, 50)) return false;   // the rounding trick holds integers below 2^51
+    return fx_bound(c, c->ks->fx_kmax) < 0.45;
+}
+int fx_after_key_load(mkt_ctx *c) {   // the key's largest transform magnitude, for fx_bound
+    unsigned long long bits = 0;
+    HIPCHK(c, hipMemcpy(&bits, c->ks->d_fx_stat, 8, hipMemcpyDeviceToHost));
+    double v; std::memcpy(&v, &bits, 8);
+    c->ks->fx_kmax = std::sqrt(v);
+    return MKT_OK;
+}
+mktd::FxRotArgs fx_rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre) {
+    const mkt_params &p = c->p;
+    mktd::FxRotArgs q{};
+    q.om = c->fx_om(); q.twist = c->fx_tw(); q.nat = c->fx_nat(); q.brk = c->ks->d_fx_brk; q.brk_party_stride = c->ks->fx_brk_party_cplx;
+    q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.logN = c->logN; q.l = p.l_gsw; q.logB = p.logB_gsw;
+    q.rows_per_gate = c->ks->rtot; q.slot_party = c->ks->d_slot_party; q.slot_row = c->ks->d_slot_row; q.logB_lev = p.logB_lev;
+    q.stagger = c->tune.rot_stagger; q.map_mode = c->tune.rot_map;
+    return q;
+}
+
 }  // namespace
 
 extern "C" {
@@ -562,6 +640,20 @@ int mkt_ctx_create(const mkt_params *params, int arith_mode, int device, mkt_ctx
     CK(hipMalloc((void **)&c->ks->d_slot_row, sr.size() * sizeof(int)));
     CK(hipMemcpy(c->ks->d_slot_party, sp.data(), sp.size() * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(c->ks->d_slot_row, sr.data(), sr.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (fx_shape(c) && c->tune.exact_impl != 0) {   // second copy of the bootstrapping key as limb transforms + the engine's own tables
+        const size_t per = (size_t)p.n * 2 * p.l_gsw * 2 * (p.W / 16) * M;
+        if (per * sizeof(cplx) <= 0x7fffffffull) {
+            c->ks->fx_brk_party_cplx = per;
+            CK(hipMalloc((void **)&c->ks->d_fx_tab, (size_t)3 * M * sizeof(cplx)));
+            CK(hipMalloc((void **)&c->ks->d_fx_brk, (size_t)np * per * sizeof(cplx)));
+            CK(hipMalloc((void **)&c->ks->d_fx_stat, 16));
+            CK(hipMemset(c->ks->d_fx_stat, 0, 16));
+            const size_t tb = (size_t)M * sizeof(cplx);
+            CK(hipMemcpy(c->ks->d_fx_tab, c->ks->tw.fx_om.data(), tb, hipMemcpyHostToDevice));
+            CK(hipMemcpy(c->ks->d_fx_tab + M, c->ks->tw.fx_tw.data(), tb, hipMemcpyHostToDevice));
+            CK(hipMemcpy(c->ks->d_fx_tab + 2 * (size_t)M, c->ks->tw.fx_nat.data(), tb, hipMemcpyHostToDevice));
+        }
+    }
 #undef CK
     int r = upload_twiddles(c);
     if (!r && c->exact) r = upload_ntt_tables(c);
@@ -577,7 +669,7 @@ int mkt_ctx_destroy(mkt_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);   // before the workspace goes: work queued on the fork's own stream may still use it
     clear_spans(c);
-    void *ptrs[] = {c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch, c->ws_ksd};
+    void *ptrs[] = {c->ws_lin, c->ws_acc, c->ws_lev, c->ws_scratch, c->ws_ksd, c->ws_fxacc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;                      // drops this context's reference to the key set; the last one frees it
@@ -644,6 +736,11 @@ int mkt_internal_clone_keys(mkt_ctx *src, mkt_ctx *dst, int no_peer) {
         if ((r = copy_across(dst, b.d_rlk_d, dd, a.d_rlk_d, sd, (size_t)np * p.l_uni * M * cb * src->split, no_peer != 0))) return r;
         if ((r = copy_across(dst, b.d_rlk_f, dd, a.d_rlk_f, sd, (size_t)np * p.l_uni * 2 * M * cb * src->split, no_peer != 0))) return r;
     }
+    if (a.d_fx_brk && b.d_fx_brk) {
+        if ((r = copy_across(dst, b.d_fx_brk, dd, a.d_fx_brk, sd, (size_t)np * a.fx_brk_party_cplx * cb, no_peer != 0))) return r;
+        if ((r = copy_across(dst, b.d_fx_stat, dd, a.d_fx_stat, sd, 16, no_peer != 0))) return r;
+        b.fx_kmax = a.fx_kmax;
+    }
     b.brk_loaded = a.brk_loaded; b.ksk_loaded = a.ksk_loaded; b.rlk_loaded = a.rlk_loaded; b.pub_loaded = a.pub_loaded; b.crs_loaded = a.crs_loaded;
     dst->tune = src->tune;
     // hipMemcpyPeer may return before the copy has landed, and the shards evaluate on non-blocking streams that the NULL stream does
@@ -678,6 +775,7 @@ int mkt_set_option(mkt_ctx *c, const char *name, int value) {
     else if (k == "ccs_stagger") t.ccs_stagger = value;
     else if (k == "ccs_pipe") t.ccs_pipe = value;
     else if (k == "exact_wide") t.exact_wide = value;
+    else if (k == "exact_impl") t.exact_impl = value;
     else if (k == "rot_map") t.rot_map = value;
     else if (k == "exact_kany") { if (t.exact_kany != value) c->ws_gates = 0; t.exact_kany = value; }   // the workspace gains / loses the kernel's scratch at the next call
     else return fail(c, MKT_ERR_ARG, "mkt_set_option: unknown option '" + k + "'");
@@ -685,6 +783,19 @@ int mkt_set_option(mkt_ctx *c, const char *name, int value) {
 }
 
 const char *mkt_last_kernel_name(const mkt_ctx *c) { return c ? c->last_rot_kernel : ""; }
+
+// diagnostics of the Float64-pipe EXACT implementation (fx_exact.hip): "fx_available" (1 if the loaded keys are certified and exact_impl admits it),
+// "fx_bound" (proven bound on |computed - exact| of a rounded sum for the loaded keys), "fx_kmax" (largest |key transform value|), "fx_last_resid"
+int mkt_get_metric(mkt_ctx *c, const char *name, double *out) {
+    if (!c || !name || !out) return fail(c, MKT_ERR_ARG, "null argument");
+    const std::string k(name);
+    if (k == "fx_available") *out = fx_usable(c) ? 1.0 : 0.0;
+    else if (k == "fx_bound") *out = c->ks->d_fx_brk ? fx_bound(c, c->ks->fx_kmax) : -1.0;
+    else if (k == "fx_kmax") *out = c->ks->fx_kmax;
+    else if (k == "fx_last_resid") *out = c->fx_last_resid;
+    else return fail(c, MKT_ERR_ARG, "mkt_get_metric: unknown metric '" + k + "'");
+    return MKT_OK;
+}
 
 int mkt_synchronize(mkt_ctx *c) {
     if (!c) return MKT_ERR_ARG;
@@ -741,7 +852,8 @@ int mkt_load_brk(mkt_ctx *c, int party, const void *data, int fmt) {
     MKT_EXACT_GATE(c);
     if (c->keys_shared()) return fail(c, MKT_ERR_STATE, "the key set is shared with forked contexts and immutable");
     DevGuard dg(c->device);
-    int r = upload_polys(c, data, (size_t)c->p.n * c->sh.brk_polys, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, fmt);
+    int r = upload_polys(c, data, (size_t)c->p.n * c->sh.brk_polys, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, fmt, false,
+                         c->ks->d_fx_brk ? c->ks->d_fx_brk + (size_t)party * c->ks->fx_brk_party_cplx : nullptr);
     if (!r) c->ks->brk_loaded[party] = 1;
     return r;
 }
@@ -830,6 +942,7 @@ static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, 
     if (e == hipSuccess) e = (c->exact && c->split == 2) ? mktd::launch_ntt_fwd_split(c->logN, c->d_ntt, d_out, reinterpret_cast<uint64_t *>(c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx), brk_polys_total, c->stream)
                            : c->exact ? mktd::launch_ntt_fwd(c->logN, p.W, c->d_ntt, d_out, reinterpret_cast<uint64_t *>(c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx), brk_polys_total, 1, c->stream)
                                : mktd::launch_transform_fwd(c->logM, p.W, c->twp(), d_out, c->ks->d_brk + (size_t)party * c->ks->brk_party_cplx, brk_polys_total, c->dev_order, c->stream);
+    if (e == hipSuccess && c->ks->d_fx_brk) e = mktd::launch_fx_key_fwd(c->logM, p.W, c->fx_om(), c->fx_tw(), d_out, c->ks->d_fx_brk + (size_t)party * c->ks->fx_brk_party_cplx, brk_polys_total, c->ks->d_fx_stat, c->stream);
     uint32_t *ksk = c->ks->d_ksk + (size_t)party * c->ks->ksk_party_words;
     if (e == hipSuccess) e = hipMemsetAsync(ksk, 0, c->ks->ksk_party_words * sizeof(uint32_t), c->stream);
     a.zoff = mkt::is_kms(p.scheme) ? 1 : 0;      // the key switch targets the uni key of the KMS schemes
@@ -839,6 +952,7 @@ static int keygen_device_impl(mkt_ctx *c, int party, const mkt_client_party *K, 
     explicit_bzero(&a, sizeof a);            // the host copy of the party's stream key (the kernel-argument copy: see the TRUST note in mktfhe.h)
     if (e != hipSuccess) return hipfail(c, e, "device keygen");
     c->ks->brk_loaded[party] = 1; c->ks->ksk_loaded[party] = 1;
+    if (c->ks->d_fx_brk) { int r = fx_after_key_load(c); if (r) return r; }
     if (ksk_out) return mkt_get_ksk(c, party, ksk_out);
     return MKT_OK;
 }
@@ -1063,6 +1177,18 @@ int mkt_kms_phase1_batch(mkt_ctx *c, const uint32_t *atilde, double *levkey, siz
         q.lwe = (const uint32_t *)sa.dev; q.lwe_stride = (int)alen; q.pre_switched = 1; q.n = p.n; q.k = p.k; q.l_gsw = p.l_gsw; q.logB_gsw = p.logB_gsw;
         q.l_lev = p.l_lev; q.logB_lev = p.logB_lev; q.l_uni = p.l_uni; q.logB_uni = p.logB_uni; q.rtot = c->ks->rtot; q.lwe_len = c->sh.lwe_len; q.blk_len = p.scheme == MKT_KMS_BLOCK ? p.blk_len : 1;
         q.slot_party = c->ks->d_slot_party; q.slot_row = c->ks->d_slot_row; q.levkey = (uint64_t *)sl.dev; q.phase1_only = 1; q.wide = c->tune.exact_wide;
+        if (p.scheme == MKT_KMS && fx_usable(c)) {
+            if ((r = ensure_workspace(c, B < CHUNK_GATES ? B : CHUNK_GATES))) return r;
+            for (size_t off = 0; off < B; off += CHUNK_GATES) {
+                const size_t nb = B - off < CHUNK_GATES ? B - off : CHUNK_GATES, nrot = nb * (size_t)c->ks->rtot;
+                mktd::FxRotArgs f = fx_rot_args(c, (const uint32_t *)sa.dev + off * alen, (int)alen, 1);
+                f.init_mode = 1; f.acc_io = c->ws_fxacc; f.ngates = nb;
+                Timer tm(c, 1);
+                HIPCHK(c, mktd::launch_fx_blindrotate(c->logM, p.W, f, nrot, c->stream));
+                HIPCHK(c, mktd::launch_ntt_fwd_split(c->logN, c->d_ntt, c->ws_fxacc, (uint64_t *)sl.dev + off * (lb / 8), nrot * 2, c->stream));
+            }
+            return sl.out(levkey);
+        }
         { Timer tm(c, 1); HIPCHK(c, mktd::launch_exact_kms(c->logN, c->d_ntt, q, B, c->stream)); }
         return sl.out(levkey);
     }
@@ -1125,6 +1251,16 @@ int mkt_exact_polymul_batch(mkt_ctx *c, const void *a, const void *b, void *out,
     Staged sa{c}, sb{c}, so{c};
     int r;
     if ((r = sa.in(a, B * poly_bytes(c), mem, true)) || (r = sb.in(b, B * poly_bytes(c), mem, true)) || (r = so.in(out, B * poly_bytes(c), mem, false))) return r;
+    if (c->ks->d_fx_tab && c->tune.exact_impl == 1) {   // the Float64-pipe product (fx_exact.hip), certified per call by its measured rounding distance
+        HIPCHK(c, hipMemsetAsync(c->ks->d_fx_stat + 1, 0, 8, c->stream));
+        { Timer tm(c, 3); HIPCHK(c, mktd::launch_fx_polymul(c->logM, c->p.W, c->fx_om(), c->fx_tw(), c->fx_nat(), sa.dev, sb.dev, so.dev, B, c->ks->d_fx_stat + 1, c->stream)); }
+        unsigned long long bits = 0;
+        HIPCHK(c, hipMemcpyAsync(&bits, c->ks->d_fx_stat + 1, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(&c->fx_last_resid, &bits, 8);
+        if (!(c->fx_last_resid < 0.25)) return fail(c, MKT_ERR_UNSUPPORTED, "mkt_exact_polymul_batch (Float64 pipe): a rounding distance of 1/4 or more -- operands beyond what 16-bit limbs certify; use exact_impl = 0");
+        return so.out(out);
+    }
     { Timer tm(c, 3); HIPCHK(c, mktd::launch_exact_polymul(c->logN, c->p.W, c->d_ntt, sa.dev, sb.dev, so.dev, B, c->stream)); }
     return so.out(out);
 }

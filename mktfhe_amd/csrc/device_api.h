@@ -172,6 +172,7 @@ struct ExactKmsArgs {
     const uint32_t *lin_for_tv;                     // bootstrapping.jl:11-23 from the linear combination, or NULL (acc holds the test vector)
     uint64_t *acc, *scratch;                        // [B][1+k][N] ; [B][4(k+1)][N]
     int phase1_only;
+    int phase2_only;                                // phase 1 was run elsewhere (fx_exact.hip) and levkey is filled
     int wide;                                       // phase 1, l_gsw = 2: the digit products of an accumulator gathered in 64 bits, one reduction (speed only)
 };
 hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a, size_t B, hipStream_t s);
@@ -185,5 +186,25 @@ struct ExactCcsHostArgs {
 };
 hipError_t launch_exact_ccs(int logN, const uint64_t *tab, const ExactCcsHostArgs &a, size_t B, hipStream_t s);
 hipError_t launch_exact_polymul(int logN, int W, const uint64_t *tab, const void *a, const void *b, void *out, size_t B, hipStream_t s);
+
+// MKT_ARITH_EXACT on the Float64 pipe (fx_exact.hip): exact products from FMA complex transforms over 16-bit key limbs.
+// Tables (host_internal.h Twiddles::fx_*): om = cyclic forward twiddles by block, twist = rho^j, nat = inverse twiddles by position.
+struct FxRotArgs {
+    const cplx *om, *twist, *nat;
+    const cplx *brk;          // party 0 base; [n][2l][2 polys][W/16 limbs][M], device point order, scaled by 1 / M
+    size_t brk_party_stride;  // in cplx
+    const uint32_t *lwe; int lwe_stride, pre_switched;
+    int n, logN, l, logB;
+    int rows_per_gate; size_t ngates;
+    const int *slot_party, *slot_row;
+    int init_mode;            // 0: load acc from acc_io; 1: trivial RLEV row (bootstrapping.jl:403-406)
+    int logB_lev;
+    void *acc_io;             // [rot][2][N] ring words, in place
+    int stagger; unsigned block0; int map_mode;
+};
+bool fx_supported(int logM, int W, int l);
+hipError_t launch_fx_key_fwd(int logM, int W, const cplx *om, const cplx *twist, const void *p, cplx *out, size_t npolys, unsigned long long *kmax, hipStream_t s);   // out [npolys][W/16][M]; kmax: largest |transform value|^2 (bit pattern, atomicMax) or NULL
+hipError_t launch_fx_polymul(int logM, int W, const cplx *om, const cplx *twist, const cplx *nat, const void *a, const void *b, void *out, size_t B, unsigned long long *resid, hipStream_t s);
+hipError_t launch_fx_blindrotate(int logM, int W, const FxRotArgs &a, size_t nrot, hipStream_t s);
 
 }  // namespace mktd

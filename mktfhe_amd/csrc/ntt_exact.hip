@@ -1893,7 +1893,8 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
     MKT_NTT_DISPATCH(logN, {
         const size_t lds = lds_bytes<LN>(1, 2);                                      // two staging buffers: the halves of a lifted sum are inverse-transformed side by side
         hipError_t e = hipSuccess;
-        if (a.blk_len > 1 && a.wide != 0) {                                       // exact_wide = 0: the per-key-bit kernel below (tests force both)
+        if (a.phase2_only) {                                                       // phase 1 ran on the Float64 pipe (fx_exact.hip) and levkey holds its rows
+        } else if (a.blk_len > 1 && a.wide != 0) {                                // exact_wide = 0: the per-key-bit kernel below (tests force both)
             last_rot_kernel = "exact_kms_block_phase1_kernel";
             e = ntt_set_lds(exact_kms_block_phase1_kernel<LN>, lds); if (e != hipSuccess) return e;
             hipLaunchKernelGGL((exact_kms_block_phase1_kernel<LN>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,

@@ -157,6 +157,22 @@ void make_twiddles(int N, Twiddles &tw) {
     tw.psi[1] = -0.0; tw.psiinv[1] = 0.0; tw.roots[1] = 0.0; tw.rootsinv[1] = -0.0;
     bit_reverse(tw.psi, M);      // fft.jl:36
     bit_reverse(tw.psiinv, M);   // fft.jl:37
+
+    // fx_exact.hip: cos / sin of pi t / N, with the 1e-77 residue of cos(RN256(pi) / 2) cleared (these tables owe the reference nothing)
+    auto cs = [&](int t, double &c, double &s) { c = std::fabs(C[t]) < 1e-60 ? 0.0 : C[t]; s = S[t]; };
+    tw.fx_om.assign(2 * M, 0.0); tw.fx_tw.assign(2 * M, 0.0); tw.fx_nat.assign(2 * M, 0.0);
+    tw.fx_om[0] = 1.0; tw.fx_nat[0] = 1.0;
+    for (int s = 0, m = 1; m < M; s++, m <<= 1)
+        for (int i = 0; i < m; i++) {
+            int r = 0;
+            for (int b = 0; b < s; b++) r |= ((i >> b) & 1) << (s - 1 - b);
+            double c, sn;
+            cs(r * (N / m), c, sn);
+            tw.fx_om[2 * (m + i)] = c; tw.fx_om[2 * (m + i) + 1] = -sn;
+            cs(i * (N / m), c, sn);
+            tw.fx_nat[2 * (m + i)] = c; tw.fx_nat[2 * (m + i) + 1] = sn;
+        }
+    for (int j = 0; j < M; j++) { double c, sn; cs(j, c, sn); tw.fx_tw[2 * j] = c; tw.fx_tw[2 * j + 1] = -sn; }
 }
 
 }  // namespace mkt

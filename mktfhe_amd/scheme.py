@@ -310,6 +310,12 @@ class Scheme:
         the parity tests force every kernel variant through this"""
         self._ck(_lib.lib().mkt_set_option(self.h, name.encode(), int(value)))
 
+    def get_metric(self, name):
+        """diagnostics of the Float64-pipe EXACT implementation (mkt_get_metric): "fx_available", "fx_bound", "fx_kmax", "fx_last_resid" """
+        v = C.c_double(0.0)
+        self._ck(_lib.lib().mkt_get_metric(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     def last_kernel_name(self):
         """base name of the blind-rotation kernel the last batch call launched"""
         return (_lib.lib().mkt_last_kernel_name(self.h) or b"").decode()
