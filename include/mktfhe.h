@@ -128,7 +128,7 @@ int mkt_synchronize(mkt_ctx *ctx);
 /* kernel-selection switches (where a step has more than one kernel, parity tests force each; A/B tools): name one of
  * "rot_variant", "rot_stagger", "rot_split", "rot_wide" (latency variant: 0 auto, 1 never, 2 always), "rot_blkg" (block
  * schemes, rotations per workgroup: 0 auto, 1, 2, 4), "rot_map" (workgroup -> (ciphertext, slot) dealing: 0 plain, 1 XCD-aware),
- * "ccs_stagger", "ccs_pipe" (-1 auto, 0 never, 1 always), "exact_wide" (MKT_ARITH_EXACT KMS phase 1 at l_gsw = 2: kernels 0 .. 4),
+ * "ccs_stagger", "ccs_pipe" (-1 auto, 0 never, 1 always), "exact_wide" (MKT_ARITH_EXACT on the integer NTT, KMS phase 1 at l_gsw = 2 / KMS_block: 1 the default kernel, 0 the one-at-a-time form),
  * "exact_kany" (MKT_ARITH_EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel also at k <= 3),
  * "exact_impl" (MKT_ARITH_EXACT blind rotation of CGGI with RLWE length 1 and of KMS phase 1, and mkt_exact_polymul_batch:
  * 0 = the integer NTT over two 30-bit primes, 1 = Float64 FMA transforms over 16-bit key limbs wherever the proven rounding bound

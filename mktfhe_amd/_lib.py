@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmktfhe_hip.so")
+# MKT_LIB_PATH: an alternative build of the same library (development A/B runs: tools/variant.sh, tools/sweep.sh) -- never a fallback
+LIB_PATH = os.environ.get("MKT_LIB_PATH") or os.path.join(_HERE, "lib", "libmktfhe_hip.so")
 
 
 class MktParams(C.Structure):

@@ -39,7 +39,7 @@ struct Tune {
     int rot_map = 1;        // workgroup id -> (ciphertext, slot) mapping of the k = 1 rotation kernels (kernel_common.h rot_decode): 1 = the RLEV rows of one
                             // (ciphertext, party) on one XCD at one time -- 25 % less fabric traffic at KMS k = 2 (FETCH_SIZE 15.3 -> 11.4 GB per launch,
                             // L2 misses -27 %), time -0.3 ... -2.5 % (profiles/r04j_bench_kms2_n1024_map{0,1}_pmc.txt)
-    int exact_wide = 4;     // EXACT KMS phase 1 at l_gsw = 2: 0 one product chain per term, 1 wide (64-bit) digit-product accumulation, 2 wide on three waves per SIMD (four-wave workgroups), 3 wide with paired transforms, 4 the same with the first sum's key rows requested ahead (default)
+    int exact_wide = 1;     // EXACT (integer NTT) KMS phase 1 at l_gsw = 2 and KMS_block phase 1: 1 = the paired-transform kernel / one set of digit transforms per block (default), 0 = the one-at-a-time kernel (reference loop order; tests force both)
     int exact_kany = 0;     // EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel (sums in memory) also where the register kernels serve (k <= 3); tests
     int exact_impl = -1;    // EXACT blind rotation of CGGI (RLWE length 1) and KMS phase 1: 0 = integer NTT over two 30-bit primes (ntt_exact.hip), 1 / -1 = the Float64 pipe
                             // (fx_exact.hip: FMA transforms over 16-bit key limbs) wherever its error bound certifies the loaded keys (fx_usable), the integer NTT elsewhere
@@ -550,6 +550,9 @@ bool fx_usable(const mkt_ctx *c) {
     if (!c->ks->d_fx_brk || c->tune.exact_impl == 0 || c->ks->fx_kmax <= 0.0) return false;
     const mkt_params &p = c->p;
     if (2.0 * p.l_gsw * p.N * std::ldexp(1.0, p.logB_gsw - 1) * 32768.0 >= std::ldexp(1.0, 50)) return false;   // the rounding trick holds integers below 2^51
+    // automatic choice: the 64-bit ring at N >= 2048 stays on the integer NTT -- four limb transforms per key polynomial are 64 KiB there and a step of one rotation
+    // reads 0.8 MB of them; measured KMS2party 3.7 k gates/s against 7.3 k (profiles/r06_experiments.txt); exact_impl = 1 still runs it (the parity tests do)
+    if (c->tune.exact_impl < 0 && p.W == 64 && c->logM >= 10) return false;
     return fx_bound(c, c->ks->fx_kmax) < 0.45;
 }
 int fx_after_key_load(mkt_ctx *c) {   // the key's largest transform magnitude, for fx_bound
@@ -565,7 +568,7 @@ mktd::FxRotArgs fx_rot_args(mkt_ctx *c, const uint32_t *lwe, int stride, int pre
     q.om = c->fx_om(); q.twist = c->fx_tw(); q.nat = c->fx_nat(); q.brk = c->ks->d_fx_brk; q.brk_party_stride = c->ks->fx_brk_party_cplx;
     q.lwe = lwe; q.lwe_stride = stride; q.pre_switched = pre; q.n = p.n; q.logN = c->logN; q.l = p.l_gsw; q.logB = p.logB_gsw;
     q.rows_per_gate = c->ks->rtot; q.slot_party = c->ks->d_slot_party; q.slot_row = c->ks->d_slot_row; q.logB_lev = p.logB_lev;
-    q.stagger = c->tune.rot_stagger; q.map_mode = c->tune.rot_map;
+    q.stagger = c->tune.rot_stagger; q.map_mode = c->tune.rot_map; q.split = c->tune.rot_split;
     return q;
 }
 

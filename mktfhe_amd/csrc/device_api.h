@@ -201,6 +201,7 @@ struct FxRotArgs {
     int logB_lev;
     void *acc_io;             // [rot][2][N] ring words, in place
     int stagger; unsigned block0; int map_mode;
+    int split;                // workgroups per launch: 0 = one chip-fill, -1 = everything in one launch (fx_exact.hip launch_fx_blindrotate)
 };
 bool fx_supported(int logM, int W, int l);
 hipError_t launch_fx_key_fwd(int logM, int W, const cplx *om, const cplx *twist, const void *p, cplx *out, size_t npolys, unsigned long long *kmax, hipStream_t s);   // out [npolys][W/16][M]; kmax: largest |transform value|^2 (bit pattern, atomicMax) or NULL

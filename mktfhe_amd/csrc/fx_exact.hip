@@ -295,6 +295,15 @@ __global__ __launch_bounds__((Plan<LOGM, FLR>::NT)) void fx_polymul_kernel(const
 // the same words as the transform-domain monomial product, and the rounded integer is half as large).
 // brk: [party][n][2l][2][NL][M], device point order, scaled by 1 / M.
 // -------------------------------------------------------------------------------------------------------------------
+// development switch (speed only; tools/variant.sh fx_exact <sfx> "-D..."): digits whose key rows of a step's FIRST group are requested before the
+// digit transforms.  -1: two at gadget length 2 (headline 35.9 -> 33.8 ms), none at length 3 (the 32 registers they hold there are spilled:
+// CGGIparam 9.5 -> 20.2 ms).  Measured and not kept (profiles/r06_experiments.txt): the same ahead of every group's inverse transform (a spill reload
+// inside the inverse then waits for them -- scratch and buffer loads share one in-order counter: 33.8 -> 74.9 ms), the turn by X^at per output
+// polynomial (chaotic: 33.8 ... 97.7 ms with the register allocation), its LDS reads requested together (+-0), the inverse's twiddles read from
+// the LDS table (conj(fx_om[2^b + rev_b(j)]) = exp(+i pi j / 2^b): 28 registers less, 35.6 -> 41.8 ms), exchange routes 0 / 1 (100 / 39.7 ms).
+#ifndef MKT_FX_PF0
+#define MKT_FX_PF0 -1
+#endif
 template <int LOGM, typename WORD, int LT>
 __global__ __launch_bounds__((Plan<LOGM, FLR>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fx_blindrotate_kernel(const FxRotArgs a) {
@@ -302,6 +311,7 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
     using P = Plan<LOGM, FLR, NB>;
     constexpr int R = 4, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W, NL = W / 16, G2 = 2 * LT;
     constexpr int MO = -1;
+    constexpr int PF0 = MKT_FX_PF0 < 0 ? (LT == 2 ? 2 : 0) : (MKT_FX_PF0 < G2 ? MKT_FX_PF0 : G2);
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
     const LaneX lx = make_lanex();
@@ -353,6 +363,17 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
         at_raw = at_src[i + 1 < a.n ? i + 1 : i];
         if (at == 0) continue;                                          // :48 / :413
 
+        const unsigned so_bit = (unsigned)((size_t)i * G2 * 2 * NL * M * sizeof(cplx));
+        cplx kpf[PF0 > 0 ? PF0 : 1][R][NB];
+        if constexpr (PF0 > 0) {
+#pragma unroll
+            for (int g = 0; g < PF0; g++)
+#pragma unroll
+                for (int e = 0; e < R; e++)
+#pragma unroll
+                    for (int h2 = 0; h2 < NB; h2++) kpf[g][e][h2] = table_load(rs_brk, vo_dev[e], so_bit + (unsigned)((((size_t)g * 2) * NL) * M * sizeof(cplx)) + (unsigned)(h2 * M * sizeof(cplx)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // the 2l digit transforms (b digits, then a digits), two at a time, all kept
         cplx D[G2][R];
 #pragma unroll
@@ -378,7 +399,6 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
                 for (int e = 0; e < R; e++) D[g0 + h2][e] = z[h2][e];
         }
 
-        const unsigned so_bit = (unsigned)((size_t)i * G2 * 2 * NL * M * sizeof(cplx));
         WORD wsum[2][R][2];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -396,7 +416,7 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
                     for (int e = 0; e < R; e++) {
 #pragma unroll
                         for (int h2 = 0; h2 < NB; h2++) {
-                            const cplx k = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(h2 * M * sizeof(cplx)));
+                            const cplx k = (c == 0 && h0 == 0 && g < PF0) ? kpf[g < PF0 ? g : 0][e][h2] : table_load(rs_brk, vo_dev[e], so_row + (unsigned)(h2 * M * sizeof(cplx)));
                             const cplx d = D[g][e];
                             S[h2][e].re = fma_(-d.im, k.im, fma_(d.re, k.re, S[h2][e].re));
                             S[h2][e].im = fma_(d.im, k.re, fma_(d.re, k.im, S[h2][e].im));
@@ -510,10 +530,24 @@ hipError_t launch_fx_blindrotate(int logM, int W, const FxRotArgs &a, size_t nro
     if (!nrot) return hipSuccess;
     if (!fx_supported(logM, W, a.l)) return hipErrorInvalidValue;
     last_rot_kernel = "fx_blindrotate_kernel";
-    MKT_FX_DISPATCH(logM, {
-        if (W == 64) return a.l == 2 ? fx_rot_launch<LM, uint64_t, 2>(a, nrot, s) : fx_rot_launch<LM, uint64_t, 3>(a, nrot, s);
-        return a.l == 2 ? fx_rot_launch<LM, uint32_t, 2>(a, nrot, s) : fx_rot_launch<LM, uint32_t, 3>(a, nrot, s);
-    });
+    // One launch per chip-fill.  Every rotation of a party walks the same key rows, step by step, and the workgroups of ONE fill run in lock-step,
+    // so a fill reads each row from the fabric once per L2 and then hits; in a single launch of several fills the later workgroups start whenever a
+    // slot frees, the resident ones spread over all key bits and the 4 x larger key of this arithmetic no longer fits the L2s (hit rate 0.66,
+    // profiles/r06_experiments.txt).  a.split: 0 = one fill per launch (256 CUs x the workgroups LDS admits), -1 = one launch, > 0 = that many workgroups.
+    size_t chunk = nrot;
+    if (a.split == 0) chunk = (size_t)256 * (logM <= 9 ? 4 : logM == 10 ? 2 : 1);
+    else if (a.split > 0) chunk = (size_t)a.split;
+    for (size_t b0 = 0; b0 < nrot; b0 += chunk) {
+        FxRotArgs b = a;
+        b.block0 = a.block0 + (unsigned)b0;
+        const size_t n = nrot - b0 < chunk ? nrot - b0 : chunk;
+        hipError_t e = hipSuccess;
+        MKT_FX_DISPATCH(logM, {
+            if (W == 64) e = a.l == 2 ? fx_rot_launch<LM, uint64_t, 2>(b, n, s) : fx_rot_launch<LM, uint64_t, 3>(b, n, s);
+            else e = a.l == 2 ? fx_rot_launch<LM, uint32_t, 2>(b, n, s) : fx_rot_launch<LM, uint32_t, 3>(b, n, s);
+        });
+        if (e != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 

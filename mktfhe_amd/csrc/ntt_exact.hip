@@ -826,9 +826,6 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void ntt_fwd_split_kernel(cons
 }
 
 // the exact integers behind a (low, high) accumulator pair, combined mod 2^64: inverse transforms, N^-1, Garner lift
-#ifndef MKT_W3_WPE
-#define MKT_W3_WPE 3
-#endif
 #ifndef MKT_EXACT_WPE
 #define MKT_EXACT_WPE 2
 #endif
@@ -841,7 +838,7 @@ __device__ __forceinline__ void lift_pair(Pt (&x)[2][8], uint64_t (&w)[8], const
 
 // KMS phase 1 (bootstrapping.jl:389-443) with exact products: one workgroup per RLEV row rotation, accumulator (b, a) in
 // registers (slot e = coefficient e*NT + t); output: the row's two polynomials as split residue tables for phase 2
-template <int LOGN, bool BLK, bool WIDE = false>   // WIDE: l_gsw = 2, the digit products of an accumulator gathered in 64 bits (its own instantiation: its own register allocation)
+template <int LOGN, bool BLK>
 __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(MKT_EXACT_WPE, MKT_EXACT_WPE))) void exact_kms_phase1_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
                                                                               const uint64_t *__restrict__ mono, const uint32_t *__restrict__ lwe, int lwe_stride,
                                                                               int pre_switched, int n, int l, int logB, int blk_len, size_t ngates, int rows_per_gate,
@@ -892,54 +889,6 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
             const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
             if (at == 0) continue;
             Pt tacc[2][2][8];
-            // l = 2 (the headline gadget): the 2l = 4 digit transforms are all kept, and every accumulator gathers its four products
-            // WIDE (one multiply-add per term, one reduction per accumulator) right before its inverse transforms
-            if constexpr (WIDE) {
-                Pt zz[4][8];
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) zz[g][e] = res_small(gd.digit(gd.prep(g >= 2 ? acc[1][e] : acc[0][e]), g & 1));   // :415-425 decompto!
-                    ntt_forward<LOGN>(zz[g], tw[0], lds, t);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) zz[g][e] = wide_x(zz[g][e]);
-                }
-                const uint64_t *rowb = brk + ((size_t)i * 4 * 4) * N + 8 * t;     // [digit g][poly][half][N]
-                auto output_poly = [&](auto ppc) {                               // written out twice: a rolled loop would index acc[pp] at run time (-> scratch)
-                    constexpr int pp = decltype(ppc)::value;
-                    Pt th[2][8];
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        Wide wa[8];
-#pragma unroll
-                        for (int e = 0; e < 8; e++) { wa[e].a = 0; wa[e].b = 0; }
-                        __builtin_amdgcn_sched_barrier(0);                     // the key rows of this accumulator are requested here, not above the transforms before (registers)
-#pragma unroll
-                        for (int g = 0; g < 4; g++)
-#pragma unroll
-                            for (int e = 0; e < 8; e++) wide_mac(wa[e], zz[g][e], unpack(rowb[(size_t)(g * 4 + pp * 2 + h) * N + e]));   // :427-432: the same sum  (plain global loads: through a buffer descriptor 13 instead of 36 spilled registers, and 8 % SLOWER)
-#pragma unroll
-                        for (int e = 0; e < 8; e++) th[h][e] = wide_reduce(wa[e]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    uint64_t w[8];
-                    lift_pair<LOGN>(th, w, tw[0], k, lds, t);
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {                                  // :435-437: (X^at S)[i] = +-S[i - at mod N]
-                        const uint32_t src = (uint32_t)(e * NT + t - (int)at) & (2u * N - 1u);
-                        const uint64_t v = lds[src & (N - 1)];
-                        acc[pp][e] += (src >= (uint32_t)N ? (uint64_t)0 - v : v) - w[e];
-                    }
-                };
-                output_poly(std::integral_constant<int, 0>{});
-                output_poly(std::integral_constant<int, 1>{});
-                continue;
-            }
-            if constexpr (!WIDE) {
 #pragma unroll
             for (int pp = 0; pp < 2; pp++)
 #pragma unroll
@@ -981,7 +930,6 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
                             for (int e = 0; e < 8; e++)                                // :427-432 / :639-646, exactly
                                 tacc[pp][h][e] = pt_mac(tacc[pp][h][e], z[e], unpack(PF ? (pp == 0 ? kr[h][e] : ks[h][e]) : rowp[(size_t)(pp * 2 + h) * N + e]));
                 }
-            }
             if (BLK) {
                 const uint64_t *mrow = mono + (size_t)(at - 1) * N + 8 * t;
 #pragma unroll
@@ -1131,241 +1079,15 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
         }
 }
 
-// KMS phase 1 at l_gsw = 2, one key bit per step, laid out for THREE waves per SIMD (168 registers) on EVERY SIMD: ROTS = 2 rotations per
-// workgroup of four waves, side by side, sharing the staged twiddle table (2 x 8 + 16 KiB; three workgroups per CU).  Why four-wave
-// workgroups: the dispatcher deals two-wave workgroups unevenly -- six per CU land [2 4 3 3] waves per SIMD (tools/simd_place.hip) and the
-// SIMD with four sets the time -- while four-wave ones land one wave per SIMD; and why three: a gfx950 SIMD issues the multiply-class and
-// three-operand integer instructions these kernels are made of every 4.4 cycles with two waves resident and every 2.9-3.3 with three
-// (tools/int_probe.hip, profiles/r05_int_probe.txt).  The two rotations meet at every workgroup barrier, so neither may skip a step:
-// a zero mask word multiplies by X^0 - 1 = 0 and adds exactly zero (the reference skips it, :413 -- the same words).
-// The same sums as the WIDE form above, in an order that keeps fewer values alive --
-// the four digit transforms (64 registers) and the accumulator (32) stay; each (output polynomial, half) gathers its four products two
-// points at a time, is inverse-transformed and lifted at once, and X^at - 1 is applied to the low and to the high half SEPARATELY
-// ((X^at - 1)(S_lo + 2^32 S_hi) mod 2^64, the high half as 32-bit words): two more rotations through LDS per step, sixteen registers fewer.
-template <int LOGN, int ROTS>
-__global__ __launch_bounds__((ROTS << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(MKT_W3_WPE, MKT_W3_WPE))) void exact_kms_phase1_w3_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
-                                                                              const uint32_t *__restrict__ lwe, int lwe_stride, int pre_switched, int n, int logB, size_t ngates, int rows_per_gate,
-                                                                              const int *__restrict__ slot_party, const int *__restrict__ slot_row, int logB_lev,
-                                                                              uint64_t *__restrict__ lev_out) {
-    constexpr int N = 1 << LOGN, NT = N >> NLR;
-    const int sub = ROTS > 1 ? threadIdx.x / NT : 0, t = ROTS > 1 ? threadIdx.x % NT : threadIdx.x;
-    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)sub * NttLds<LOGN>::WORDS;
-    const uint4 *tw[1]; const int which[1] = {0};
-    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(reinterpret_cast<uint64_t *>(ntt_smem) + (size_t)ROTS * NttLds<LOGN>::WORDS), threadIdx.x, ROTS * NT, tw, which);
-    const NttConsts k = tab_consts<LOGN>(tab);
-    const size_t nrot = ngates * (size_t)rows_per_gate;
-    size_t r = (size_t)blockIdx.x * ROTS + sub;
-    const bool live = r < nrot;                                                    // a ragged last workgroup repeats the last rotation (it must keep the barriers) and stores nothing
-    if (!live) r = nrot - 1;
-    const size_t gate = r % ngates;
-    const int slot = (int)(r / ngates);
-    const size_t rot = gate * (size_t)rows_per_gate + slot;
-    const int party = slot_party[slot], row = slot_row[slot];
-    const uint32_t *at_src = lwe + gate * (size_t)lwe_stride + (size_t)party * n;
-    const uint64_t *brk = brk0 + (size_t)party * brk_party_stride;
-    const Gadget<uint64_t> gd(2, logB);
-    uint64_t acc[2][8];
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) acc[c][e] = 0;
-    if (t == 0) acc[0][0] = (uint64_t)1 << (64 - (row + 1) * logB_lev);           // :403-406 trivial RLEV row
-    const int msbit = 32 - LOGN - 1;
-    for (int i = 0; i < n; i++) {
-        const uint32_t v0 = at_src[i];
-        const uint32_t at_lane = pre_switched ? v0 : divbits<uint32_t>(v0, msbit);
-        const uint32_t at = (ROTS > 1 && NT < 64) ? at_lane : (uint32_t)__builtin_amdgcn_readfirstlane((int)at_lane);   // below N = 512 the two rotations of a workgroup share a wave: not wave-uniform
-        if (ROTS == 1 && at == 0) continue;                                        // :413 (ROTS > 1: no skip, the step adds zero)
-        Pt zz[4][8];
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) zz[g][e] = res_small(gd.digit(gd.prep(g >= 2 ? acc[1][e] : acc[0][e]), g & 1));   // :415-425 decompto!
-            ntt_forward<LOGN, 0, true>(zz[g], tw[0], lds, t);
-#pragma unroll
-            for (int e = 0; e < 8; e++) zz[g][e] = wide_x(zz[g][e]);
-        }
-        const uint4 *rowb = reinterpret_cast<const uint4 *>(brk + ((size_t)i * 4 * 4) * N + 8 * t);     // [digit g][poly][half][N], two points per 16 bytes
-        auto half_poly = [&](auto ppc, auto hc) {                                  // a rolled loop would index acc[pp] at run time (-> scratch)
-            constexpr int pp = decltype(ppc)::value, h = decltype(hc)::value;
-            Pt th[8];
-#pragma unroll
-            for (int ep = 0; ep < 4; ep++) {                                       // :427-432: the same sum, two points at a time
-                Wide w0, w1;
-                w0.a = w0.b = w1.a = w1.b = 0;
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const uint4 kv = (MKT_ABLATE & 2) ? make_uint4(zz[g][2 * ep].b >> 1, zz[g][2 * ep].a >> 1, zz[g][2 * ep + 1].b >> 1, zz[g][2 * ep + 1].a >> 1) : rowb[(size_t)(g * 4 + pp * 2 + h) * (N / 2) + ep];
-                    Pt y0, y1; y0.a = kv.x; y0.b = kv.y; y1.a = kv.z; y1.b = kv.w;
-                    wide_mac(w0, zz[g][2 * ep], y0); wide_mac(w1, zz[g][2 * ep + 1], y1);
-                }
-                th[2 * ep] = wide_reduce(w0); th[2 * ep + 1] = wide_reduce(w1);
-            }
-            ntt_inverse<LOGN, Plan<LOGN, NLR>::NPASS - 1, true>(th, tw[0], lds, t, k.ninv);
-            if (MKT_ABLATE & 8) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) acc[pp][e] += crt_signed(th[e]) << (32 * h);
-                return;
-            }
-            __syncthreads();
-            if constexpr (h == 0) {
-                uint64_t w[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) { w[e] = crt_signed(th[e]); lds[e * NT + t] = w[e]; }
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < 8; e++) {                                      // :435-437: (X^at S)[i] = +-S[i - at mod N]
-                    const uint32_t src = (uint32_t)(e * NT + t - (int)at) & (2u * N - 1u);
-                    const uint64_t v = lds[src & (N - 1)];
-                    acc[pp][e] += (src >= (uint32_t)N ? (uint64_t)0 - v : v) - w[e];
-                }
-            } else {
-                uint32_t *ldw = reinterpret_cast<uint32_t *>(lds);
-                uint32_t w[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) { w[e] = (uint32_t)crt_signed(th[e]); ldw[e * NT + t] = w[e]; }
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < 8; e++) {                                      // the high half: the same rotation on 32-bit words, times 2^32
-                    const uint32_t src = (uint32_t)(e * NT + t - (int)at) & (2u * N - 1u);
-                    const uint32_t v = ldw[src & (N - 1)];
-                    acc[pp][e] += (uint64_t)((src >= (uint32_t)N ? 0u - v : v) - w[e]) << 32;
-                }
-            }
-        };
-        half_poly(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        half_poly(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-        half_poly(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-        half_poly(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-    }
-    // :441 fftto!(tacc, acc): the row as split residue tables, Montgomery form
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            Pt z[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) z[e] = fwd_in(piece_of(acc[c][e], h), e);
-            ntt_forward<LOGN>(z, tw[0], lds, t);
-            uint64_t *o = lev_out + ((rot * 2 + c) * 2 + h) * (size_t)N + 8 * t;
-            if (live)
-#pragma unroll
-            for (int e = 0; e < 8; e++) o[e] = pack(Pt{montmul<P1, PI1>(z[e].a, RR1), montmul<P2, PI2>(z[e].b, RR2)});
-            __syncthreads();
-        }
-}
-
-// KMS phase 1 at l_gsw = 2 with PAIRED transforms (two waves per SIMD, the whole register file): the digit polynomials of one accumulator
-// (j = 0, 1) go through the forward transform side by side, the low and the high half of an output polynomial's lifted sum through the
-// inverse -- half the twiddle reads, slot addresses, barriers and exposed waits of the one-at-a-time form, and the two halves of a sum
-// arrive together, so X^at - 1 is applied once per output polynomial on the 64-bit words.  The same sums (WIDE form), the same words.
-template <int LOGN>
-__global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(2, 2))) void exact_kms_phase1_p2_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
-                                                                              const uint32_t *__restrict__ lwe, int lwe_stride, int pre_switched, int n, int logB, size_t ngates, int rows_per_gate,
-                                                                              const int *__restrict__ slot_party, const int *__restrict__ slot_row, int logB_lev,
-                                                                              uint64_t *__restrict__ lev_out) {
-    constexpr int N = 1 << LOGN, NT = N >> NLR;
-    uint64_t *lds = reinterpret_cast<uint64_t *>(ntt_smem);                        // two staging buffers, then the table
-    const int t = threadIdx.x;
-    const uint4 *tw[1]; const int which[1] = {0};
-    stage_tables<LOGN, 1>(tab, reinterpret_cast<uint4 *>(lds + 2 * NttLds<LOGN>::WORDS), t, NT, tw, which);
-    const NttConsts k = tab_consts<LOGN>(tab);
-    const size_t gate = blockIdx.x % ngates;
-    const int slot = (int)(blockIdx.x / ngates);
-    const size_t rot = gate * (size_t)rows_per_gate + slot;
-    const int party = slot_party[slot], row = slot_row[slot];
-    const uint32_t *at_src = lwe + gate * (size_t)lwe_stride + (size_t)party * n;
-    const uint64_t *brk = brk0 + (size_t)party * brk_party_stride;
-    const Gadget<uint64_t> gd(2, logB);
-    uint64_t acc[2][8];
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) acc[c][e] = 0;
-    if (t == 0) acc[0][0] = (uint64_t)1 << (64 - (row + 1) * logB_lev);           // :403-406 trivial RLEV row
-    const int msbit = 32 - LOGN - 1;
-    for (int i = 0; i < n; i++) {
-        const uint32_t v0 = at_src[i];
-        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pre_switched ? v0 : divbits<uint32_t>(v0, msbit)));
-        if (at == 0) continue;                                                     // :413
-        Pt zz[4][8];
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            Pt (&zp)[2][8] = *reinterpret_cast<Pt(*)[2][8]>(&zz[2 * c]);
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int e = 0; e < 8; e++) zp[j][e] = res_small(gd.digit(gd.prep(c ? acc[1][e] : acc[0][e]), j));   // :415-425 decompto!
-            ntt_forward_n<LOGN, 0, false, 2>(zp, tw[0], lds, t);
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int e = 0; e < 8; e++) zp[j][e] = wide_x(zp[j][e]);
-        }
-        const uint64_t *rowb = brk + ((size_t)i * 4 * 4) * N + 8 * t;             // [digit g][poly][half][N]
-        auto output_poly = [&](auto ppc) {                                       // written out twice: a rolled loop would index acc[pp] at run time (-> scratch)
-            constexpr int pp = decltype(ppc)::value;
-            Pt th[2][8];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                Wide wa[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) { wa[e].a = 0; wa[e].b = 0; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-#pragma unroll
-                    for (int e = 0; e < 8; e++) wide_mac(wa[e], zz[g][e], (MKT_ABLATE & 2) ? Pt{zz[g][e].b >> 1, zz[g][e].a >> 1} : unpack(rowb[(size_t)(g * 4 + pp * 2 + h) * N + e]));   // :427-432: the same sum
-#pragma unroll
-                for (int e = 0; e < 8; e++) th[h][e] = wide_reduce(wa[e]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            ntt_inverse_n<LOGN, Plan<LOGN, NLR>::NPASS - 1, false, 2>(th, tw[0], lds, t, k.ninv);
-            uint64_t w[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) w[e] = crt_signed(th[0][e]) + (crt_signed(th[1][e]) << 32);
-            if (MKT_ABLATE & 8) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) acc[pp][e] += w[e];
-                return;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 8; e++) lds[e * NT + t] = w[e];
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 8; e++) {                                          // :435-437: (X^at S)[i] = +-S[i - at mod N]
-                const uint32_t src = (uint32_t)(e * NT + t - (int)at) & (2u * N - 1u);
-                const uint64_t v = lds[src & (N - 1)];
-                acc[pp][e] += (src >= (uint32_t)N ? (uint64_t)0 - v : v) - w[e];
-            }
-        };
-        output_poly(std::integral_constant<int, 0>{});
-        output_poly(std::integral_constant<int, 1>{});
-    }
-    // :441 fftto!(tacc, acc): the row as split residue tables, Montgomery form; the two halves of a polynomial side by side
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        Pt z[2][8];
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) z[h][e] = fwd_in(piece_of(acc[c][e], h), e);
-        ntt_forward_n<LOGN, 0, false, 2>(z, tw[0], lds, t);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            uint64_t *o = lev_out + ((rot * 2 + c) * 2 + h) * (size_t)N + 8 * t;
-#pragma unroll
-            for (int e = 0; e < 8; e++) o[e] = pack(Pt{montmul<P1, PI1>(z[h][e].a, RR1), montmul<P2, PI2>(z[h][e].b, RR2)});
-        }
-        __syncthreads();
-    }
-}
-
-// The same kernel with the key rows of the FIRST (polynomial, half) requested ahead (exact_wide = 4): its 16 row pieces per thread are asked
-// for before the second forward pair instead of at use, where the wait was an exposed L2 / fabric round trip (key rows: 13 % of the step,
-// profiles/r05_experiments.txt item 4).  The other three sums load at use: asked ahead too (under the previous sum's multiply-adds, around
-// the inverse pair) the kernel spills 60-100 registers and runs 7-22 % SLOWER.
+// KMS phase 1 at l_gsw = 2 with PAIRED transforms (two waves per SIMD, the whole register file; exact_wide != 0, the default): the digit polynomials of one
+// accumulator (j = 0, 1) go through the forward transform side by side, the low and the high half of an output polynomial's lifted sum through the
+// inverse -- half the twiddle reads, slot addresses, barriers and exposed waits of the one-at-a-time form (exact_kms_phase1_kernel, exact_wide = 0) --
+// every sum gathers its four digit products in 64 bits (one v_mad_u64_u32 per term and residue, one reduction), and the two halves of a sum arrive
+// together, so X^at - 1 is applied once per output polynomial on the 64-bit words.  The key rows of the FIRST (polynomial, half) are requested ahead:
+// its 16 row pieces per thread are asked for before the second forward pair instead of at use, where the wait was an exposed L2 / fabric round trip
+// (key rows: 13 % of the step, profiles/r05_experiments.txt item 4).  The other three sums load at use: asked ahead too the kernel spills 60-100
+// registers and runs 7-22 % SLOWER.  (Rounds 3-5 also carried this kernel without the early request, a three-waves-per-SIMD form and a 64-bit-gathering
+// form of the one-at-a-time kernel -- all superseded by this one in the round-5 A/B and removed in round 6: docs/history.md.)
 template <int LOGN>
 __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_per_eu(2, 2))) void exact_kms_phase1_p2pf_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ brk0, size_t brk_party_stride,
                                                                               const uint32_t *__restrict__ lwe, int lwe_stride, int pre_switched, int n, int logB, size_t ngates, int rows_per_gate,
@@ -1904,26 +1626,11 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
             hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, true>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
                                a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, a.blk_len, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
         } else {
-            if (a.wide >= 4 && a.l_gsw == 2) {
+            if (a.wide != 0 && a.l_gsw == 2) {                                     // the paired-transform kernel (default); exact_wide = 0: the one-at-a-time kernel below (tests force both)
                 const size_t lds2 = lds_bytes<LN>(1, 2);
                 e = ntt_set_lds(exact_kms_phase1_p2pf_kernel<LN>, lds2); if (e != hipSuccess) return e;
                 hipLaunchKernelGGL((exact_kms_phase1_p2pf_kernel<LN>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds2, s, tb, a.brk, a.brk_party_stride,
                                    a.lwe, a.lwe_stride, a.pre_switched, a.n, a.logB_gsw, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
-            } else if (a.wide >= 3 && a.l_gsw == 2) {
-                const size_t lds2 = lds_bytes<LN>(1, 2);
-                e = ntt_set_lds(exact_kms_phase1_p2_kernel<LN>, lds2); if (e != hipSuccess) return e;
-                hipLaunchKernelGGL((exact_kms_phase1_p2_kernel<LN>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds2, s, tb, a.brk, a.brk_party_stride,
-                                   a.lwe, a.lwe_stride, a.pre_switched, a.n, a.logB_gsw, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
-            } else if (a.wide >= 2 && a.l_gsw == 2) {
-                constexpr int ROTS = 2;
-                const size_t lds2 = lds_bytes<LN>(1, ROTS), nrot = B * (size_t)a.rtot;
-                e = ntt_set_lds(exact_kms_phase1_w3_kernel<LN, ROTS>, lds2); if (e != hipSuccess) return e;
-                hipLaunchKernelGGL((exact_kms_phase1_w3_kernel<LN, ROTS>), dim3((unsigned)((nrot + ROTS - 1) / ROTS)), dim3(ROTS << (LN - NLR)), lds2, s, tb, a.brk, a.brk_party_stride,
-                                   a.lwe, a.lwe_stride, a.pre_switched, a.n, a.logB_gsw, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
-            } else if (a.wide && a.l_gsw == 2) {
-                e = ntt_set_lds(exact_kms_phase1_kernel<LN, false, true>, lds); if (e != hipSuccess) return e;
-                hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, false, true>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,
-                                   a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, 1, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
             } else {
                 e = ntt_set_lds(exact_kms_phase1_kernel<LN, false>, lds); if (e != hipSuccess) return e;
                 hipLaunchKernelGGL((exact_kms_phase1_kernel<LN, false>), dim3((unsigned)(B * (size_t)a.rtot)), dim3(1 << (LN - NLR)), lds, s, tb, a.brk, a.brk_party_stride, a.mono,

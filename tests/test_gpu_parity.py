@@ -1048,6 +1048,7 @@ def test_exact_mode_kms_gates(require_gpu, p):
     crs, keys = keygen(p, 73)
     so = oracle_scheme(p, crs, keys)
     sx = mk.Scheme(p, arith=mk.ARITH_EXACT)
+    sx.set_option("exact_impl", 0)                                    # this test is the integer-NTT path's; tests/test_gpu_fx.py runs the same shapes on the Float64 pipe
     sx.load_crs(crs)
     for i, kk in enumerate(keys):
         sx.load_party(i, kk)
@@ -1076,7 +1077,7 @@ def test_exact_mode_kms_gates(require_gpu, p):
         assert sx.last_kernel_name() == "exact_kms_block_phase1_kernel"
         sx.set_option("exact_wide", 0)
         assert np.array_equal(sx.blindrotate_(at, acc0.astype(np.uint64).copy()), acc_x) and sx.last_kernel_name() == "exact_kms_phase1_kernel"
-        sx.set_option("exact_wide", 4)
+        sx.set_option("exact_wide", 1)
     for op in (0, 3):
         out = sx.gate(op, x, y)
         assert np.array_equal(out, np.stack([RX.kms_gate(p, so, keys, crs, op, x[j], y[j]) for j in range(B)])), f"exact KMS gate {op}"
@@ -1087,11 +1088,10 @@ def test_exact_mode_kms_gates(require_gpu, p):
     sx.close()
 
 
-# The EXACT KMS phase 1 at l_gsw = 2 has five kernels (exact_wide 0: one product chain per term; 1: products gathered in 64 bits; 2: the same
-# on three waves per SIMD, two rotations per four-wave workgroup -- an odd rotation count leaves half a workgroup idle; 3: paired
-# transforms; 4: paired transforms with the first sum's key rows requested ahead, the default): every one must give the big-integer
-# restatement's words, at three ring sizes and ragged batches.
-@pytest.mark.parametrize("wide", [0, 1, 2, 3, 4])
+# The integer-NTT KMS phase 1 at l_gsw = 2 has two kernels (exact_wide 0: one transform at a time, one product chain per term -- the reference's
+# loop order; 1, the default: paired transforms, products gathered in 64 bits, the first sum's key rows requested ahead): both must give the
+# big-integer restatement's words, at three ring sizes and ragged batches.
+@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("p", [mk.KMS2party_N1024_l2.scaled(n=10), mk.KMS2party_N1024_l2.scaled(n=8, N=256), mk.KMS2party_N1024_l2.scaled(n=12, N=512)], ids=lambda p: f"N{p.N}-n{p.n}")     # (N = 2048 with this gadget exceeds the two-prime modulus: refused)
 def test_exact_kms_phase1_kernels_are_word_identical(require_gpu, p, wide):
     import ref_exact as RX
@@ -1101,6 +1101,7 @@ def test_exact_kms_phase1_kernels_are_word_identical(require_gpu, p, wide):
     sx.load_crs(crs)
     for i, kk in enumerate(keys):
         sx.load_party(i, kk)
+    sx.set_option("exact_impl", 0)                                    # the integer-NTT kernels (the Float64-pipe phase 1 has tests/test_gpu_fx.py)
     sx.set_option("exact_wide", wide)
     rng = np.random.default_rng(84)
     for B in (3, 2):                                                  # 3 gates x 3 RLEV rows = 9 rotations: odd
@@ -1176,6 +1177,7 @@ def test_exact_mode_cggi_gates(require_gpu, p):
     crs, keys = keygen(p, 71)
     so = oracle_scheme(p, crs, keys)
     sx = mk.Scheme(p, arith=mk.ARITH_EXACT)
+    sx.set_option("exact_impl", 0)                                    # the integer-NTT kernels (tests/test_gpu_fx.py: the Float64 pipe on the k = 1 shapes)
     sx.load_party(0, keys[0])
     B = 4
     bits = np.array([1, 0, 1, 1, 0, 1, 0, 0], dtype=bool)

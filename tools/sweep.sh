@@ -3,7 +3,7 @@
 # ONE parametrised sweep for what used to be a dozen one-off scripts: every combination of the given environment settings (kernel
 # switches read at mkt_ctx_create: MKT_ROT_STAGGER, MKT_ROT_WIDE, MKT_ROT_VARIANT, MKT_ROT_BLKG, MKT_KS_G, MKT_KS_BLOCKS, MKT_KS_PAIR,
 # MKT_CCS_STAGGER, MKT_EXACT_WIDE, MKT_FFT_GRID ...) x alternative builds mktfhe_amd/lib/libmktfhe_hip_<sfx>.so ("base" = the default;
-# build them with tools/tu_variant.sh / tools/ntt_variant.sh / make SFX=) x workloads x batch sizes, one bench.py line each, printed as
+# build them with tools/tu_variant.sh / tools/variant.sh / make SFX=) x workloads x batch sizes, one bench.py line each, printed as
 # gates/s, rotation / key-switch / phase-2 ms, decrypt_ok.  Same device, same call: the only way to compare on a pool whose devices differ.
 # examples:  bash tools/sweep.sh MKT_ROT_STAGGER=0,16,64 --workloads "kms2_n1024 kms2party cggi"
 #            bash tools/sweep.sh MKT_ROT_WIDE=1,2 --workloads cggi --batches "96 128 256 512"
@@ -15,9 +15,9 @@ while [ $# -gt 0 ]; do case "$1" in
   --) shift; EXTRA=("$@"); break;; *=*) VARS+=("$1"); shift;; *) echo "unknown argument $1"; exit 2;; esac; done
 combos=("")
 for v in "${VARS[@]}"; do name=${v%%=*}; next=(); for c in "${combos[@]}"; do for val in $(echo "${v#*=}" | tr ',' ' '); do next+=("$c $name=$val"); done; done; combos=("${next[@]}"); done
-cp mktfhe_amd/lib/libmktfhe_hip.so /tmp/sweep_orig.so
 for sfx in $LIBS; do
-  if [ "$sfx" != base ]; then cp mktfhe_amd/lib/libmktfhe_hip_$sfx.so mktfhe_amd/lib/libmktfhe_hip.so; else cp /tmp/sweep_orig.so mktfhe_amd/lib/libmktfhe_hip.so; fi
+  # the alternative build is SELECTED (MKT_LIB_PATH, mktfhe_amd/_lib.py), never copied over the default library: an interrupted sweep leaves nothing behind
+  if [ "$sfx" != base ]; then export MKT_LIB_PATH=$PWD/mktfhe_amd/lib/libmktfhe_hip_$sfx.so; else unset MKT_LIB_PATH; fi
   for c in "${combos[@]}"; do for w in $WORKLOADS; do for b in $BATCHES; do
     env $c python3 bench.py --steps 3 --warmup 1 --workload $w --batch $b --no-cpu-baseline --no-roofline --no-secondary "${EXTRA[@]}" 2>/dev/null | grep -a '"metric"' | python3 -c "
 import sys, json
@@ -26,4 +26,4 @@ for l in sys.stdin:
     print('$sfx |$c |', d['config']['params'], 'batch $b | %.0f gates/s | rot %.3f ks %.3f p2 %.3f ms | %.3f ms/step | ok' % (d['value'], k['blindrotate'], k['keyswitch'], k['kms_phase2'], d['ms_per_step']), d['decrypt_ok'], flush=True)"
   done; done; done
 done
-cp /tmp/sweep_orig.so mktfhe_amd/lib/libmktfhe_hip.so
+unset MKT_LIB_PATH

@@ -11,4 +11,8 @@ for TU in $TUS; do
   OBJ=$(echo "$OBJ" | grep -v kernels_tu$TU.o); NEW="$NEW /tmp/mkt_tuv/kernels_tu${TU}_$SFX.o"
 done; wait
 [ -e /tmp/mkt_tuv/failed_$SFX ] && { rm -f /tmp/mkt_tuv/failed_$SFX; echo "compile failed"; exit 1; }
+# the variant names itself: context.o rebuilt with a build id over the sources AND the extra flags (bench.py quotes committed PMC traffic only for the build it was taken from)
+BID=$( (cat *.hip *.h *.cpp Makefile ../../include/mktfhe.h; echo "variant tu $2 $EXTRA"; /opt/rocm/bin/hipcc --version) | sha256sum | cut -c1-16)
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-cuda-compat -Wno-pass-failed -Wno-unused-function -DMKT_BUILD_ID="\"$BID\"" -x hip -c context.cpp -o /tmp/mkt_tuv/context_$SFX.o || exit 1
+OBJ=$(echo "$OBJ" | grep -v "/context.o"); NEW="$NEW /tmp/mkt_tuv/context_$SFX.o"
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/libmktfhe_hip_$SFX.so $OBJ $NEW -lpthread && echo built libmktfhe_hip_$SFX.so
