@@ -550,9 +550,10 @@ bool fx_usable(const mkt_ctx *c) {
     if (!c->ks->d_fx_brk || c->tune.exact_impl == 0 || c->ks->fx_kmax <= 0.0) return false;
     const mkt_params &p = c->p;
     if (2.0 * p.l_gsw * p.N * std::ldexp(1.0, p.logB_gsw - 1) * 32768.0 >= std::ldexp(1.0, 50)) return false;   // the rounding trick holds integers below 2^51
-    // automatic choice: the 64-bit ring at N >= 2048 stays on the integer NTT -- four limb transforms per key polynomial are 64 KiB there and a step of one rotation
-    // reads 0.8 MB of them; measured KMS2party 3.7 k gates/s against 7.3 k (profiles/r06_experiments.txt); exact_impl = 1 still runs it (the parity tests do)
-    if (c->tune.exact_impl < 0 && p.W == 64 && c->logM >= 10) return false;
+    // automatic choice: KMS at N >= 2048 with gadget length 3 stays on the integer NTT -- four limb transforms per key polynomial are 64 KiB there and a step of one
+    // rotation reads 0.8 MB of them; measured KMS2party 6.3 k gates/s against 7.3 k (N = 2048 at length 2: 12.2 k against 9.5 k; N = 1024 at length 3: 16.1 k against 14.3 k:
+    // profiles/r06_experiments.txt); exact_impl = 1 still runs it (the parity tests do)
+    if (c->tune.exact_impl < 0 && p.W == 64 && c->logM >= 10 && p.l_gsw >= 3) return false;
     return fx_bound(c, c->ks->fx_kmax) < 0.45;
 }
 int fx_after_key_load(mkt_ctx *c) {   // the key's largest transform magnitude, for fx_bound

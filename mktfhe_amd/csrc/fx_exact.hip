@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "kernel_common.h"
+#include <cstdio>
 
 namespace mktd {
 
@@ -304,14 +305,26 @@ __global__ __launch_bounds__((Plan<LOGM, FLR>::NT)) void fx_polymul_kernel(const
 #ifndef MKT_FX_PF0
 #define MKT_FX_PF0 -1
 #endif
+#ifndef MKT_FX_KBATCH      // a digit's key rows requested together, one digit ahead (-1: on the 64-bit ring at gadget length 3 or N >= 2048 -- where the compiler's own
+                           // schedule collapses to one load in flight; elsewhere its schedule is ahead: headline 31.5 vs 36.9 ms, CGGIparam 9.9 vs 12.2)
+#define MKT_FX_KBATCH -1
+#endif
+#ifndef MKT_FX_WPE_L3W64   // waves per SIMD the register allocator is told to hit at gadget length 3 on the 64-bit ring
+#define MKT_FX_WPE_L3W64 2
+#endif
+#ifndef MKT_FX_RTREG_L3W64 // twist factors in registers (1) or re-read through a buffer descriptor (0) there
+#define MKT_FX_RTREG_L3W64 1
+#endif
+template <typename WORD, int LT> struct FxOcc { static constexpr int W = (LT == 3 && sizeof(WORD) == 8) ? MKT_FX_WPE_L3W64 : 2; };
 template <int LOGM, typename WORD, int LT>
-__global__ __launch_bounds__((Plan<LOGM, FLR>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__((Plan<LOGM, FLR>::NT)) __attribute__((amdgpu_waves_per_eu(FxOcc<WORD, LT>::W, FxOcc<WORD, LT>::W)))
 void fx_blindrotate_kernel(const FxRotArgs a) {
     constexpr int NB = 2;
     using P = Plan<LOGM, FLR, NB>;
     constexpr int R = 4, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W, NL = W / 16, G2 = 2 * LT;
     constexpr int MO = -1;
-    constexpr int PF0 = MKT_FX_PF0 < 0 ? (LT == 2 ? 2 : 0) : (MKT_FX_PF0 < G2 ? MKT_FX_PF0 : G2);
+    constexpr bool KBATCH = MKT_FX_KBATCH < 0 ? (sizeof(WORD) == 8 && (LT == 3 || LOGM >= 10)) : MKT_FX_KBATCH != 0;
+    constexpr int PF0 = KBATCH ? 0 : MKT_FX_PF0 < 0 ? (LT == 2 ? 2 : 0) : (MKT_FX_PF0 < G2 ? MKT_FX_PF0 : G2);
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
     const LaneX lx = make_lanex();
@@ -336,9 +349,12 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
 #pragma unroll
     for (int e = 0; e < R; e++) vo_dev[e] = (unsigned)dev_pos(1, t * R + e, NT) * 16u;
     const Gadget<WORD> gd(LT, a.logB);
-    cplx rt[R];                                   // rho^j of this thread's points j = e*NT + t (twist; the untwist conjugates it)
+    constexpr bool RTREG = !(LT == 3 && sizeof(WORD) == 8) || MKT_FX_RTREG_L3W64;
+    const __amdgpu_buffer_rsrc_t rs_tw = table_rsrc(a.twist, (size_t)M * sizeof(cplx));
+    cplx rt_reg[R];                               // rho^j of this thread's points j = e*NT + t (twist; the untwist conjugates it)
 #pragma unroll
-    for (int e = 0; e < R; e++) rt[e] = a.twist[e * NT + t];
+    for (int e = 0; e < R; e++) rt_reg[e] = a.twist[e * NT + t];
+    auto rtw = [&](int e) { return RTREG ? rt_reg[e] : table_load(rs_tw, (unsigned)(e * NT + t) * 16u, 0); };
     FxItw<LOGM> itw; itw.load(a.nat, t);
 
     WORD acc[2][R][2];
@@ -388,8 +404,9 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
                 for (int e = 0; e < R; e++) {
                     const WORD w0 = isa ? acc[1][e][0] : acc[0][e][0], w1 = isa ? acc[1][e][1] : acc[0][e][1];
                     const double d0 = (double)gd.digit(gd.prep(w0), j), d1 = (double)gd.digit(gd.prep(w1), j);
-                    z[h2][e].re = fma_(d0, rt[e].re, d1 * rt[e].im);
-                    z[h2][e].im = fma_(d0, rt[e].im, -(d1 * rt[e].re));
+                    const cplx r = rtw(e);
+                    z[h2][e].re = fma_(d0, r.re, d1 * r.im);
+                    z[h2][e].im = fma_(d0, r.im, -(d1 * r.re));
                 }
             }
             fx_forward<LOGM, NB, MO>(z, om_l, lds, t, lx);
@@ -409,6 +426,34 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
                 for (int h2 = 0; h2 < NB; h2++)
 #pragma unroll
                     for (int e = 0; e < R; e++) { S[h2][e].re = 0.0; S[h2][e].im = 0.0; }
+                if constexpr (KBATCH) {
+                    // the key rows of one digit are requested TOGETHER (distinct registers) and the next digit's while this one's multiply-adds run: left
+                    // to itself the compiler reuses ONE register quad for all 48 loads of a group at gadget length 3 on the 64-bit ring -- load, wait,
+                    // four multiply-adds, load ... -- and a step exposes 192 round trips (KMS2party 3.6 k gates/s; profiles/r06_experiments.txt)
+                    cplx kb[2][R][NB];
+                    auto req = [&](int g) {
+                        const unsigned so_row = so_bit + (unsigned)((((size_t)g * 2 + c) * NL + h0) * M * sizeof(cplx));
+#pragma unroll
+                        for (int e = 0; e < R; e++)
+#pragma unroll
+                            for (int h2 = 0; h2 < NB; h2++) kb[g & 1][e][h2] = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(h2 * M * sizeof(cplx)));
+                    };
+                    req(0);
+#pragma unroll
+                    for (int g = 0; g < G2; g++) {
+                        if (g + 1 < G2) req(g + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < R; e++)
+#pragma unroll
+                            for (int h2 = 0; h2 < NB; h2++) {
+                                const cplx k = kb[g & 1][e][h2], d = D[g][e];
+                                S[h2][e].re = fma_(-d.im, k.im, fma_(d.re, k.re, S[h2][e].re));
+                                S[h2][e].im = fma_(d.im, k.re, fma_(d.re, k.im, S[h2][e].im));
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
 #pragma unroll
                 for (int g = 0; g < G2; g++) {
                     const unsigned so_row = so_bit + (unsigned)((((size_t)g * 2 + c) * NL + h0) * M * sizeof(cplx));
@@ -423,15 +468,17 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
                         }
                     }
                 }
+                }
                 fx_inverse<LOGM, NB, MO>(S, itw, lds, t, lx);
 #pragma unroll
                 for (int e = 0; e < R; e++) {
                     uint64_t b0[NB], b1[NB];
+                    const cplx r = rtw(e);
 #pragma unroll
                     for (int h2 = 0; h2 < NB; h2++) {                   // untwist by conj(rho^j), nearest integer
                         const cplx v = S[h2][e];
-                        b0[h2] = round_bits(fma_(v.re, rt[e].re, v.im * rt[e].im));
-                        b1[h2] = round_bits(fma_(v.re, rt[e].im, -(v.im * rt[e].re)));     // -(Im)
+                        b0[h2] = round_bits(fma_(v.re, r.re, v.im * r.im));
+                        b1[h2] = round_bits(fma_(v.re, r.im, -(v.im * r.re)));     // -(Im)
                     }
                     // sum_h (bits_h - MAGIC) 2^(16 h): MAGIC's pattern has 48 zero low bits, so only limb 0 carries it
                     if constexpr (W == 32) {
@@ -480,6 +527,11 @@ hipError_t fx_rot_launch(const FxRotArgs &a, size_t nrot, hipStream_t s) {
     static_assert(P::LDS_BYTES >= (size_t)4 * P::M * sizeof(WORD), "the staging buffers hold the turned sums of both polynomials");
     hipError_t e = set_lds(fx_blindrotate_kernel<LM, WORD, LT>, LB);
     if (e != hipSuccess) return e;
+    if (getenv("MKT_FX_DEBUG")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fx_blindrotate_kernel<LM, WORD, LT>, P::NT, LB);
+        fprintf(stderr, "fx_blindrotate_kernel<%d, %d, %d>: %d threads, %zu B LDS, %d workgroups per CU, %zu rotations\n", LM, (int)sizeof(WORD) * 8, LT, P::NT, LB, nb, nrot);
+    }
     hipLaunchKernelGGL((fx_blindrotate_kernel<LM, WORD, LT>), dim3((unsigned)nrot), dim3(P::NT), LB, s, a);
     return hipGetLastError();
 }
