@@ -1036,6 +1036,7 @@ int mkt_gate_batch_ops(mkt_ctx *c, const uint8_t *ops, const uint32_t *x, const 
 int mkt_gate_batch_gather(mkt_ctx *c, const uint8_t *ops, const uint32_t *pool, size_t pool_rows, const uint32_t *ix, const uint32_t *iy,
                           uint32_t *out, size_t B, int mem) {
     if (!c || !ops || !pool || !ix || !iy || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (B && !pool_rows) return fail(c, MKT_ERR_ARG, "mkt_gate_batch_gather: gates over an empty pool");     // (the kernel clamps indices into [0, pool_rows): there must be a row to clamp to, in either memory kind)
     if (mem == MKT_MEM_HOST) {
         if (!ops_valid_host(ops, B)) return fail(c, MKT_ERR_ARG, "mkt_gate_batch_gather: unknown gate code");
         for (size_t j = 0; j < B; j++) if (ix[j] >= pool_rows || iy[j] >= pool_rows) return fail(c, MKT_ERR_ARG, "mkt_gate_batch_gather: operand index outside the pool");
@@ -1079,6 +1080,7 @@ int mkt_mux_batch(mkt_ctx *c, const uint32_t *sel, const uint32_t *a, const uint
 int mkt_mux_batch_gather(mkt_ctx *c, const uint32_t *pool, size_t pool_rows, const uint32_t *is, const uint32_t *ia, const uint32_t *ib, const uint8_t *not_ab,
                          uint32_t *out, size_t B, int mem) {
     if (!c || !pool || !is || !ia || !ib || !out || !mem_ok(mem)) return fail(c, MKT_ERR_ARG, "bad argument");
+    if (B && !pool_rows) return fail(c, MKT_ERR_ARG, "mkt_mux_batch_gather: gates over an empty pool");
     if (mem == MKT_MEM_HOST)
         for (size_t j = 0; j < B; j++) if (is[j] >= pool_rows || ia[j] >= pool_rows || ib[j] >= pool_rows || (not_ab && (not_ab[j] & ~3u))) return fail(c, MKT_ERR_ARG, "mkt_mux_batch_gather: operand index outside the pool, or unknown flag");
     MKT_EXACT_GATE(c);

@@ -35,20 +35,33 @@ def _agree(store, rank, world, stage, ok, wait_s):
     """every rank publishes whether `stage` worked for it and reads every other rank's verdict: the ranks switch backend together or
     not at all (a rank that fell back alone would leave the others waiting in RCCL until their collective timeout)"""
     import datetime
-    store.set(f"mkt/{stage}/{rank}", "1" if ok else "0")
-    keys = [f"mkt/{stage}/{r}" for r in range(world)]
+    store.set(f"{stage}/{rank}", "1" if ok else "0")
+    keys = [f"{stage}/{r}" for r in range(world)]
     store.wait(keys, datetime.timedelta(seconds=wait_s))          # raises after wait_s: a loud error instead of a 900 s hang
     return all(store.get(k) == b"1" for k in keys)
 
 
-def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900, agree_s=180):
+def _verdict_store(rank, world, port, wait_s):
+    """The agreement store: a TCPStore of its own on MASTER_ADDR : MASTER_PORT + 2, hosted by rank 0 and created for THIS launch -- it works across
+    nodes (the file store of round 5 did not) and cannot hold a previous launch's verdicts; the keys additionally carry the elastic launcher's run id and
+    restart count where there is one.  A rank that cannot reach it raises: acting alone is exactly what the store exists to prevent."""
+    import datetime
+    import torch.distributed as dist
+    store = dist.TCPStore(os.environ["MASTER_ADDR"], port + 2, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=wait_s), wait_for_workers=False)
+    nonce = os.environ.get("TORCHELASTIC_RUN_ID", "run") + "." + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    return dist.PrefixStore(f"mkt/{nonce}", store)
+
+
+def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900, agree_s=180, _test_fail_ranks=()):
     """Rendezvous of the ranks (nothing on the data path: gates shard with no collective).  backend "nccl" is RCCL; it is
     PROVED with one tiny all-reduce right away, and if creating or proving it fails on ANY rank -- no peer access between the
     visible devices, an IPC mode the host driver refuses -- ALL ranks fall back to `fallback` (gloo over TCP, CPU tensors)
     instead of losing the run: the barrier, the max-over-ranks and the census are all it carries.  The outcome of each stage
-    (communicator created; probe all-reduce correct) is agreed through a small file store of its own (/tmp, named after the launcher's pid)
-    before any rank acts on it, and nobody enters the probe collective unless every rank holds a communicator.  What this cannot shorten is a
-    rank that never ARRIVES at a collective (creation and the probe are collectives themselves): the others then wait out `timeout_s`."""
+    (communicator created; probe all-reduce correct) is agreed through a small store of its own (_verdict_store) before any rank acts on
+    it, and nobody enters the probe collective unless every rank holds a communicator.  What this cannot shorten is a rank that never
+    ARRIVES at a collective (creation and the probe are collectives themselves): the others then wait out `timeout_s`.
+    Ports: MASTER_PORT (the group), + 1 (the fallback group), + 2 (the verdicts).  `_test_fail_ranks`: tests only -- these ranks report a local
+    failure of the probe after its collective."""
     import datetime
     import sys
     import torch
@@ -63,14 +76,7 @@ def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900
         port = int(os.environ["MASTER_PORT"])
         verdicts = None
         if fallback:                                       # (fallback == backend: one retry of the same backend on a fresh store)
-            # the agreement store is a FILE in /tmp (one node: the contract of this launcher), named after the launcher's pid -- the same for
-            # every rank, new for every launch -- so the rendezvous needs no port beyond MASTER_PORT (and MASTER_PORT + 1 for a fallback group)
-            import tempfile
-            path = os.path.join(tempfile.gettempdir(), f"mkt_verdicts_{os.getppid()}_{port}")
-            try:
-                verdicts = _VERDICTS = dist.FileStore(path, world)
-            except Exception as e:      # noqa: BLE001  (no agreement store: the ranks act on their own outcome, as before round 5)
-                sys.stderr.write(f"mktfhe_amd.distributed: rank {rank}: no agreement store ({type(e).__name__}: {str(e)[:120]})\n")
+            verdicts = _VERDICTS = _verdict_store(rank, world, port, agree_s)     # raises if unreachable: fatal on that rank, and the others time out on its verdict
         why = None
         try:
             kw = {}
@@ -82,15 +88,14 @@ def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900
                 raise
             why = e
         ok = why is None if verdicts is None else _agree(verdicts, rank, world, "created", why is None, agree_s)
-        lone = os.environ.get("MKT_DIST_TEST_FAIL_RANKS", "")     # test hook: the probe of these ranks fails AFTER its collective (a local fault)
-        if ok and (backend == "nccl" or lone):
+        if ok and (backend == "nccl" or _test_fail_ranks):
             try:
                 probe = torch.ones(1, device=(device if device is not None else "cuda") if backend == "nccl" else "cpu")
                 dist.all_reduce(probe)
                 if backend == "nccl":
                     torch.cuda.synchronize()
                 assert int(probe.item()) == world
-                if str(rank) in lone.split(","):
+                if rank in _test_fail_ranks:
                     raise RuntimeError("simulated local failure on this rank only")
             except Exception as e:  # noqa: BLE001
                 if verdicts is None:
@@ -111,12 +116,7 @@ def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=to)
         ACTIVE_BACKEND = backend
         if verdicts is not None:
-            dist.barrier()                                 # every rank has read every verdict
-            if rank == 0:
-                try:
-                    os.remove(path)                        # a later launch that recycles this pid and port must not find old verdicts
-                except OSError:
-                    pass
+            dist.barrier()                                 # every rank has read every verdict; the store lives as long as rank 0's process
     return rank, world, local
 
 

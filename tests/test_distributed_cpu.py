@@ -80,11 +80,10 @@ def test_rendezvous_falls_back_to_gloo_when_rccl_cannot_start():
 
 
 def _lone_failure_worker(rank, world, port, ret):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      MKT_DIST_TEST_FAIL_RANKS="1")
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     from mktfhe_amd import distributed as D
-    D.init_process_group("gloo", device=None, fallback="gloo", agree_s=60)     # rank 1's probe fails locally, rank 0's succeeds
+    D.init_process_group("gloo", device=None, fallback="gloo", agree_s=60, _test_fail_ranks=(1,))     # rank 1's probe fails locally, rank 0's succeeds
     t = torch.ones(1)
     torch.distributed.all_reduce(t)
     ret[rank] = (D.ACTIVE_BACKEND, float(t.item()), os.environ["MASTER_PORT"])

@@ -110,6 +110,11 @@ def test_gather_level_matches_the_oracle(require_gpu, p):
     assert np.array_equal(big[:P].cpu().numpy().view(np.uint32), pool)          # the operand rows are untouched
     with pytest.raises(mk.MktError):
         sg.gate_gather(ops, pool, ix + P, iy, out_h)                              # index outside the pool
+    # gates over an EMPTY pool are refused in both memory kinds (device-side index arrays are clamped into the pool: there must be a row to clamp to)
+    with pytest.raises(mk.MktError, match="empty pool"):
+        sg.gate_gather(ops, pool[:0], ix, iy, out_h)
+    with pytest.raises(mk.MktError):                                              # (an empty device view has no address: refused as a null argument)
+        sg.gate_gather(torch.from_numpy(ops).cuda(), big[:0], torch.from_numpy(ix.view(np.int32)).cuda(), torch.from_numpy(iy.view(np.int32)).cuda(), big[P:])
     sg.close()
 
 

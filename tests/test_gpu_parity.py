@@ -117,6 +117,12 @@ SMALL = [
     mk.CGGIparam.scaled(n=8, N=128, k=6, l_gsw=2, logB_gsw=10),
     mk.Blockparam.scaled(n=24, N=256, blk_d=8, k=4),
     mk.Blockparam.scaled(n=20, N=128, blk_d=10, k=5, blk_len=2),
+    # N = 4096 (M = 2048: the largest transform the header admits; the reference leaves N free, scheme.jl:6-20): every stage and gate, all five schemes
+    mk.CGGIparam.scaled(n=6, N=4096),
+    mk.KMS2party.scaled(n=4, N=4096),
+    mk.Blockparam.scaled(n=12, N=4096, blk_d=4),
+    mk.CCS2party.scaled(n=4, N=4096),
+    mk.KMS2partyblock.scaled(n=6, N=4096, blk_d=2),
 ]
 
 
@@ -223,6 +229,9 @@ BLOCK_SETS = [
     mk.CGGIparam.scaled(n=16, N=256, k=2),                             # the plain CMux with RLWE length 2 / 3 on the same kernel (one key bit per block)
     mk.CGGIparam.scaled(n=8, N=1024, k=2),
     mk.CGGIparam.scaled(n=12, N=512, k=3, l_gsw=2, logB_gsw=10),
+    mk.Blockparam.scaled(n=12, N=4096, blk_d=4),                       # M = 2048 under every forced grouping (the grouped kernels fall back where LDS does not admit them)
+    mk.KMS2partyblock.scaled(n=6, N=4096, blk_d=2),
+    mk.Blockparam_k2.scaled(n=6, N=4096, blk_d=2),
 ]
 
 
@@ -237,7 +246,7 @@ def test_block_rotation_groupings_are_bit_identical(require_gpu, p, G, monkeypat
 # thread groups per ciphertext as a two-stage pipeline over a step's input polynomials (ccs_pipe.hip: the ordered Float64 sums
 # into tacc.b / tacc.a[idx] stay one chain in one group).  MKT_CCS_PIPE forces either; every stage and gate must give the oracle's words.
 CCS_SETS = [mk.CCS2party.scaled(n=12, N=256), mk.CCS2party.scaled(n=8, N=1024), mk.CCS4party.scaled(n=6, N=512), mk.CCS8party.scaled(n=4, N=512),
-            mk.CCS8party.scaled(n=3, N=2048, k=3), mk.CCS16party.scaled(n=2, N=128, k=5)]
+            mk.CCS8party.scaled(n=3, N=2048, k=3), mk.CCS16party.scaled(n=2, N=128, k=5), mk.CCS2party.scaled(n=4, N=4096), mk.CCS4party.scaled(n=2, N=4096, k=3)]
 
 
 @pytest.mark.parametrize("pipe", ["0", "1"])
@@ -1034,7 +1043,7 @@ def test_exact_products_at_the_modulus_edge(require_gpu):
     ex.close()
 
 
-@pytest.mark.parametrize("p", [mk.KMS2party.scaled(n=8, N=256), mk.KMS2party_N1024_l2.scaled(n=8), mk.KMS2party.scaled(n=6), mk.KMS4party.scaled(n=4, N=512),
+@pytest.mark.parametrize("p", [mk.KMS2party.scaled(n=8, N=256), mk.KMS2party_N1024_l2.scaled(n=8), mk.KMS2party.scaled(n=6), mk.KMS4party.scaled(n=4, N=512), mk.KMS2party.scaled(n=3, N=4096),
                                mk.KMS8party.scaled(n=3, N=256, k=3), mk.KMS2partyblock.scaled(n=12, N=256, blk_d=4), mk.KMS2partyblock.scaled(n=6, blk_d=2)],
                          ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
 def test_exact_mode_kms_gates(require_gpu, p):
@@ -1121,7 +1130,7 @@ def test_exact_kms_phase1_kernels_are_word_identical(require_gpu, p, wide):
     sx.close()
 
 
-@pytest.mark.parametrize("p", [mk.CCS2party.scaled(n=8, N=256), mk.CCS2party.scaled(n=6), mk.CCS4party.scaled(n=4, N=512), mk.CCS8party.scaled(n=3, N=256, k=3),
+@pytest.mark.parametrize("p", [mk.CCS2party.scaled(n=8, N=256), mk.CCS2party.scaled(n=6), mk.CCS4party.scaled(n=4, N=512), mk.CCS8party.scaled(n=3, N=256, k=3), mk.CCS2party.scaled(n=3, N=4096),
                                mk.CCS16party.scaled(n=2, N=256, k=4)], ids=lambda p: f"{p.name}-n{p.n}-N{p.N}-k{p.k}")
 def test_exact_mode_ccs_gates(require_gpu, p):
     """MKT_ARITH_EXACT for CCS (bootstrapping.jl:234-364, 32-bit ring): the hybrid products over Z_P.  Accumulators after the
@@ -1159,7 +1168,7 @@ def test_exact_mode_ccs_gates(require_gpu, p):
 
 
 @pytest.mark.parametrize("p", [mk.CGGIparam.scaled(n=12, N=256), mk.CGGIparam.scaled(n=10, N=1024), mk.CGGI_N1024_l2.scaled(n=10),
-                               mk.CGGIparam.scaled(n=6, N=2048, l_gsw=4, logB_gsw=7),
+                               mk.CGGIparam.scaled(n=6, N=2048, l_gsw=4, logB_gsw=7), mk.CGGIparam.scaled(n=4, N=4096), mk.Blockparam.scaled(n=6, N=4096, blk_d=2),
                                mk.Blockparam.scaled(n=12, N=256, blk_d=4), mk.Blockparam.scaled(n=9, N=1024, blk_d=3),
                                # RLWE length 2 / 3 and other block lengths: exact_blindrotate_kr_kernel (BASELINE configs[4] = LMSS, k = 2, in the integer arithmetic)
                                mk.Blockparam_k2.scaled(n=9, blk_d=3), mk.Blockparam_k2.scaled(n=12, N=256, blk_d=4), mk.CGGIparam.scaled(n=8, N=256, k=2),

@@ -16,7 +16,7 @@ def run(rounds=6, seed=77, log=print):
     bad = 0
     saved = os.environ.get("MKT_ROT_BLKG")
     for it in range(rounds):
-        logN = int(rng.integers(6, 11))
+        logN = int(rng.integers(6, 13))       # N = 64 .. 4096
         N = 1 << logN
         kind = int(rng.integers(0, 4))
         if kind == 0:      # block-binary, RLWE length 1
