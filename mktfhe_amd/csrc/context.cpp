@@ -41,7 +41,7 @@ struct Tune {
                             // L2 misses -27 %), time -0.3 ... -2.5 % (profiles/r04j_bench_kms2_n1024_map{0,1}_pmc.txt)
     int exact_wide = 1;     // EXACT (integer NTT) KMS phase 1 at l_gsw = 2 and KMS_block phase 1: 1 = the paired-transform kernel / one set of digit transforms per block (default), 0 = the one-at-a-time kernel (reference loop order; tests force both)
     int exact_kany = 0;     // EXACT CGGI / LMSS: 1 = the run-time-RLWE-length kernel (sums in memory) also where the register kernels serve (k <= 3); tests
-    int exact_impl = -1;    // EXACT blind rotation of CGGI (RLWE length 1) and KMS phase 1: 0 = integer NTT over two 30-bit primes (ntt_exact.hip), 1 / -1 = the Float64 pipe
+    int exact_impl = -1;    // EXACT blind rotation of CGGI (RLWE length 1) and KMS phase 1: 0 = integer NTT over two 30-bit primes (ntt_exact.hip), 1 / -1 = the Float64 pipe (ahead at every measured shape: profiles/r06_fx_shapes.txt)
                             // (fx_exact.hip: FMA transforms over 16-bit key limbs) wherever its error bound certifies the loaded keys (fx_usable), the integer NTT elsewhere
     void from_env() {
         exact_impl = env_int("MKT_EXACT_IMPL", exact_impl);
@@ -538,11 +538,11 @@ bool fx_shape(const mkt_ctx *c) {
 //   the inverse's own roundings are relative to the 2-norm of what it transforms:  gamma_i sum_g |d_g|_2 max_r |K_g[r]|
 // with |d_g|_2 <= sqrt(N) 2^(logB-1), |limb_g|_2 <= sqrt(N) 2^15, max_r |K[r]| MEASURED over the loaded key (kmax; a random key sits near
 // 4 sqrt(N) 2^15 / sqrt(3), an adversarial one at N 2^15 fails the bound and the integer NTT serves), per-stage constants 5.5 u (6-operation
-// butterfly incl. the rounded twiddle), 1.5 u (product-free stages), 3 u (twist / untwist), (2 + 4 l) u for the multiply-add chain.
+// butterfly incl. the rounded twiddle), 1.5 u (product-free stages), 3 u (twist / untwist), (2 + 6 l) u for the multiply-add chain.
 double fx_bound(const mkt_ctx *c, double kmax) {
     const mkt_params &p = c->p;
     const double u = std::ldexp(1.0, -53), g2 = 2.0 * p.l_gsw;
-    const double gt = (3.0 + 5.5 * (c->logM - 2) + 1.5 * 2) * u, gm = (2.0 + 2.0 * g2) * u;
+    const double gt = (3.0 + 5.5 * (c->logM - 2) + 1.5 * 2) * u, gm = (2.0 + 3.0 * g2) * u;     // (chain of 2 g2 fused operations per component, sqrt(2) for the complex value: 2.83 g2 u)
     const double dn = std::sqrt((double)p.N) * std::ldexp(1.0, p.logB_gsw - 1), kn = std::sqrt((double)p.N) * 32768.0;
     return (gt + (gt + u) + gm) * g2 * dn * kn + gt * g2 * dn * kmax * (1.0 + 1e-6);
 }
@@ -550,10 +550,6 @@ bool fx_usable(const mkt_ctx *c) {
     if (!c->ks->d_fx_brk || c->tune.exact_impl == 0 || c->ks->fx_kmax <= 0.0) return false;
     const mkt_params &p = c->p;
     if (2.0 * p.l_gsw * p.N * std::ldexp(1.0, p.logB_gsw - 1) * 32768.0 >= std::ldexp(1.0, 50)) return false;   // the rounding trick holds integers below 2^51
-    // automatic choice: KMS at N >= 2048 with gadget length 3 stays on the integer NTT -- four limb transforms per key polynomial are 64 KiB there and a step of one
-    // rotation reads 0.8 MB of them; measured KMS2party 6.3 k gates/s against 7.3 k (N = 2048 at length 2: 12.2 k against 9.5 k; N = 1024 at length 3: 16.1 k against 14.3 k:
-    // profiles/r06_experiments.txt); exact_impl = 1 still runs it (the parity tests do)
-    if (c->tune.exact_impl < 0 && p.W == 64 && c->logM >= 10 && p.l_gsw >= 3) return false;
     return fx_bound(c, c->ks->fx_kmax) < 0.45;
 }
 int fx_after_key_load(mkt_ctx *c) {   // the key's largest transform magnitude, for fx_bound

@@ -305,9 +305,23 @@ __global__ __launch_bounds__((Plan<LOGM, FLR>::NT)) void fx_polymul_kernel(const
 #ifndef MKT_FX_PF0
 #define MKT_FX_PF0 -1
 #endif
-#ifndef MKT_FX_KBATCH      // a digit's key rows requested together, one digit ahead (-1: on the 64-bit ring at gadget length 3 or N >= 2048 -- where the compiler's own
-                           // schedule collapses to one load in flight; elsewhere its schedule is ahead: headline 31.5 vs 36.9 ms, CGGIparam 9.9 vs 12.2)
-#define MKT_FX_KBATCH -1
+#ifndef MKT_FX_KBATCH      // 1 (default): the key rows of a group are requested in explicit units, a fixed number of units ahead of the multiply-adds that use them
+#define MKT_FX_KBATCH 1    // (below); 0: left to the compiler -- which keeps ~10 loads in flight at some instantiations (headline 31.2 ms either way, CGGIparam 9.85
+#endif                     // vs 9.36 ms) and collapses to ONE load in flight on the 64-bit ring at gadget length 3 or N >= 2048 (KMS2party 284 vs 102 ms)
+#ifndef MKT_FX_KBPRE
+#define MKT_FX_KBPRE 0
+#endif
+#ifndef MKT_FX_KBU3
+#define MKT_FX_KBU3 1
+#endif
+#ifndef MKT_FX_KBLA3
+#define MKT_FX_KBLA3 3
+#endif
+#ifndef MKT_FX_KBU2
+#define MKT_FX_KBU2 1
+#endif
+#ifndef MKT_FX_KBLA2
+#define MKT_FX_KBLA2 4
 #endif
 #ifndef MKT_FX_WPE_L3W64   // waves per SIMD the register allocator is told to hit at gadget length 3 on the 64-bit ring
 #define MKT_FX_WPE_L3W64 2
@@ -323,7 +337,7 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
     using P = Plan<LOGM, FLR, NB>;
     constexpr int R = 4, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W, NL = W / 16, G2 = 2 * LT;
     constexpr int MO = -1;
-    constexpr bool KBATCH = MKT_FX_KBATCH < 0 ? (sizeof(WORD) == 8 && (LT == 3 || LOGM >= 10)) : MKT_FX_KBATCH != 0;
+    constexpr bool KBATCH = MKT_FX_KBATCH != 0;
     constexpr int PF0 = KBATCH ? 0 : MKT_FX_PF0 < 0 ? (LT == 2 ? 2 : 0) : (MKT_FX_PF0 < G2 ? MKT_FX_PF0 : G2);
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
@@ -390,6 +404,23 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
                     for (int h2 = 0; h2 < NB; h2++) kpf[g][e][h2] = table_load(rs_brk, vo_dev[e], so_bit + (unsigned)((((size_t)g * 2) * NL) * M * sizeof(cplx)) + (unsigned)(h2 * M * sizeof(cplx)));
             __builtin_amdgcn_sched_barrier(0);
         }
+        // KBATCH: request units = KBU points of one digit, both limbs (2 KBU loads), LA units in flight ahead of the one in use
+        constexpr int KBU = LT >= 3 ? MKT_FX_KBU3 : MKT_FX_KBU2, UPG = R / KBU, NU = G2 * UPG, LA = LT >= 3 ? MKT_FX_KBLA3 : MKT_FX_KBLA2;
+        constexpr bool KBPRE = KBATCH && MKT_FX_KBPRE;      // the first group's first LA units are requested before the digit transforms
+        cplx kb[KBATCH ? LA + 1 : 1][KBU][NB];
+        auto req = [&](int c, int h0, int u) {
+            const int g = u / UPG, e0 = (u % UPG) * KBU;
+            const unsigned so_row = so_bit + (unsigned)((((size_t)g * 2 + c) * NL + h0) * M * sizeof(cplx));
+#pragma unroll
+            for (int e = 0; e < KBU; e++)
+#pragma unroll
+                for (int h2 = 0; h2 < NB; h2++) kb[u % (LA + 1)][e][h2] = table_load(rs_brk, vo_dev[e0 + e], so_row + (unsigned)(h2 * M * sizeof(cplx)));
+        };
+        if constexpr (KBPRE) {
+#pragma unroll
+            for (int u = 0; u < LA && u < NU; u++) req(0, 0, u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // the 2l digit transforms (b digits, then a digits), two at a time, all kept
         cplx D[G2][R];
 #pragma unroll
@@ -430,26 +461,24 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
                     // the key rows of one digit are requested TOGETHER (distinct registers) and the next digit's while this one's multiply-adds run: left
                     // to itself the compiler reuses ONE register quad for all 48 loads of a group at gadget length 3 on the 64-bit ring -- load, wait,
                     // four multiply-adds, load ... -- and a step exposes 192 round trips (KMS2party 3.6 k gates/s; profiles/r06_experiments.txt)
-                    cplx kb[2][R][NB];
-                    auto req = [&](int g) {
-                        const unsigned so_row = so_bit + (unsigned)((((size_t)g * 2 + c) * NL + h0) * M * sizeof(cplx));
+                    // (unit = KBU points of one digit, both limbs: 2 KBU loads; at gadget length 3 the 64 registers of two 4-point units next to the 96 of
+                    // the digit transforms were spilled -- 192 scratch accesses per step -- so the unit is 2 points there)
+                    if (!(KBPRE && c == 0 && h0 == 0)) {
 #pragma unroll
-                        for (int e = 0; e < R; e++)
+                        for (int u = 0; u < LA && u < NU; u++) req(c, h0, u);
+                    }
 #pragma unroll
-                            for (int h2 = 0; h2 < NB; h2++) kb[g & 1][e][h2] = table_load(rs_brk, vo_dev[e], so_row + (unsigned)(h2 * M * sizeof(cplx)));
-                    };
-                    req(0);
-#pragma unroll
-                    for (int g = 0; g < G2; g++) {
-                        if (g + 1 < G2) req(g + 1);
+                    for (int u = 0; u < NU; u++) {
+                        if (u + LA < NU) req(c, h0, u + LA);
                         __builtin_amdgcn_sched_barrier(0);
+                        const int g = u / UPG, e0 = (u % UPG) * KBU;
 #pragma unroll
-                        for (int e = 0; e < R; e++)
+                        for (int e = 0; e < KBU; e++)
 #pragma unroll
                             for (int h2 = 0; h2 < NB; h2++) {
-                                const cplx k = kb[g & 1][e][h2], d = D[g][e];
-                                S[h2][e].re = fma_(-d.im, k.im, fma_(d.re, k.re, S[h2][e].re));
-                                S[h2][e].im = fma_(d.im, k.re, fma_(d.re, k.im, S[h2][e].im));
+                                const cplx k = kb[u % (LA + 1)][e][h2], d = D[g][e0 + e];
+                                S[h2][e0 + e].re = fma_(-d.im, k.im, fma_(d.re, k.re, S[h2][e0 + e].re));
+                                S[h2][e0 + e].im = fma_(d.im, k.re, fma_(d.re, k.im, S[h2][e0 + e].im));
                             }
                         __builtin_amdgcn_sched_barrier(0);
                     }

@@ -23,6 +23,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MKT_BLK_ABLATE_SAMEAT
+#define MKT_BLK_ABLATE_SAMEAT 0
+#endif
 namespace mktd {
 
 // NP = 3 (RLWE length 2, round 3): the one-rotation kernel of that shape (blindrotate_kr_kernel) waits on memory 73 % of the time --
@@ -77,7 +80,9 @@ void blindrotate_blk_kernel(const RotArgs a, int wg_per_slot) {
 #pragma unroll
     for (int r = 0; r < G; r++) {
         const size_t gr = gate0 + r < a.ngates ? gate0 + r : a.ngates - 1;
-        at_src[r] = a.lwe + gr * (size_t)a.lwe_stride + (size_t)party * a.n;
+        // development only (-DMKT_BLK_ABLATE_SAMEAT=1, WRONG results): every rotation of the workgroup reads rotation 0's mask words, so their monomial rows and
+        // mask loads coincide -- the ceiling of what pairing the RLEV rows of one (ciphertext, party) in a workgroup could save (profiles/r06_experiments.txt)
+        at_src[r] = a.lwe + (MKT_BLK_ABLATE_SAMEAT ? (gate0 < a.ngates ? gate0 : a.ngates - 1) : gr) * (size_t)a.lwe_stride + (size_t)party * a.n;
     }
     const bool mine_valid = gate0 + grp < a.ngates;
     const size_t my_gate = mine_valid ? gate0 + grp : a.ngates - 1;

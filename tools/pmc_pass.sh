@@ -22,6 +22,6 @@ run clk "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_WAVE_CYCLES SQ_ACTIVE_INST_
 if [ $FULL = 1 ]; then
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$NAME -- python3 $R/bench.py --steps 20 --warmup 5 $ARGS > $O/trace_$NAME.log 2>&1     # the driver's step counts: the average launch duration here is the one the bench line's avg_launch_ms must agree with
   run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"
-  run sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES"
+  run sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_WAIT_INST_LDS"
 fi
 ls $O | grep "_${NAME}_" | tr '\n' ' '; echo

@@ -17,7 +17,7 @@ if [ $PART = 1 ]; then
   line --op mux --no-roofline --no-secondary > $O/bench_kms2_n1024_mux.json
 fi
 if [ $PART = 4 ]; then      # PMC passes of the other EXACT workloads (the headline's are in part 1)
-  for w in kms2party kms2partyblock cggi lmss ccs2party; do bash tools/pmc_pass.sh $TAG $w ${w}_exact -- --arith exact > /dev/null; done
+  for w in kms2party kms2partyblock cggi lmss ccs2party; do bash tools/pmc_pass.sh $TAG $w ${w}_exact full -- --arith exact > /dev/null; done
   bash tools/pmc_pass.sh $TAG lmss lmss_16384 -- --batch 16384 > /dev/null
   bash tools/pmc_pass.sh $TAG kms2_n1024 kms2_n1024_mux -- --op mux > /dev/null
 fi
@@ -39,17 +39,17 @@ fi
 if [ $PART = 2 ]; then
   for w in kms2party cggi cggi_l2 lmss kms2partyblock kms4party; do
     line --steps 8 --warmup 4 --workload $w --no-roofline > $O/bench_$w.json
-    bash tools/pmc_pass.sh $TAG $w $w > /dev/null
+    bash tools/pmc_pass.sh $TAG $w $w full > /dev/null          # full: the SQ groups too (issue_roofline needs SQ_INSTS_VALU)
   done
 fi
 if [ $PART = 3 ]; then
   for w in ccs2party ccs8party ccs8_n2048; do
     line --steps 2 --warmup 1 --workload $w --no-roofline > $O/bench_$w.json
-    bash tools/pmc_pass.sh $TAG $w $w > /dev/null
+    bash tools/pmc_pass.sh $TAG $w $w full > /dev/null
   done
   line --steps 2 --warmup 1 --workload lmss --batch 16384 --no-roofline --no-cpu-baseline > $O/bench_lmss_16384.json
   line --steps 2 --warmup 1 --workload lmss_k2 --batch 16384 --no-roofline --no-cpu-baseline > $O/bench_lmss_k2_16384.json
-  bash tools/pmc_pass.sh $TAG lmss_k2 lmss_k2_16384 -- --batch 16384 > /dev/null
+  bash tools/pmc_pass.sh $TAG lmss_k2 lmss_k2_16384 full -- --batch 16384 > /dev/null
   for w in kms2party kms2partyblock cggi lmss lmss_k2 ccs2party; do line --steps 6 --warmup 3 --workload $w --arith exact --no-roofline --no-cpu-baseline --no-secondary > $O/bench_${w}_exact.json; done
 fi
 ls $O | tr '\n' ' '
