@@ -29,6 +29,14 @@
 
 #include "fft_device.h"
 
+// The file is compiled once per translation unit MKT_NTT_TU (Makefile) so that its kernel families build in parallel (one unit took 175 s, the
+// critical path of the whole build): 0 batched transforms + exact products, 1 CGGI / LMSS rotations, 2 KMS phase 1, 3 KMS phase 2 + CCS.  Undefined = everything.
+#ifdef MKT_NTT_TU
+#define MKT_NTT_IN(n) (MKT_NTT_TU == (n))
+#else
+#define MKT_NTT_IN(n) 1
+#endif
+
 namespace mktd {
 
 namespace {
@@ -344,6 +352,7 @@ template <int LOGN> constexpr size_t lds_bytes(int ntab, int ppw = 1) { return (
 #define MKT_NTT_PPW 2
 #endif
 template <int LOGN> struct Ppw { static constexpr int v = (LOGN <= 10 && LOGN >= 6) ? MKT_NTT_PPW : 1; };
+#if MKT_NTT_IN(0)
 template <int LOGN, typename WORD, bool MONT>
 __global__ __launch_bounds__((Ppw<LOGN>::v << (LOGN - NLR))) void ntt_fwd_kernel(const uint4 *__restrict__ tab, const WORD *__restrict__ p,
                                                                                  uint64_t *__restrict__ out, size_t B) {
@@ -464,6 +473,9 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_polymul_kernel(cons
 }
 
 
+#endif  // unit 0
+
+#if MKT_NTT_IN(1)
 // ------------------------------------------------------------------------------------------------
 // Blind rotation with EXACT products (CGGI and LMSS, RLWE length 1, 32-bit ring): bootstrapping.jl:32-76 / :114-165 with
 // every transform-domain product replaced by the exact negacyclic product mod 2^32 -- digit transforms, row MACs
@@ -790,6 +802,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kany_ke
     }
 }
 
+#endif  // unit 1
+
 // ------------------------------------------------------------------------------------------------
 // The 64-bit ring (KMS) with exact products.  A product  digit polynomial x 64-bit polynomial  exceeds P, so every resident
 // 64-bit table is kept as TWO residue polynomials -- the transforms of its low and of its high 32-bit halves (centered
@@ -800,6 +814,7 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void exact_blindrotate_kany_ke
 // Layout of a split table: logical polynomial i -> residue polynomials 2i (low half) and 2i + 1 (high half), natural
 // transform order, Montgomery form.  The monomial table (coefficients -2 .. 1) is not split.
 // ------------------------------------------------------------------------------------------------
+#if MKT_NTT_IN(0)
 template <int LOGN>
 __global__ __launch_bounds__((1 << (LOGN - NLR))) void ntt_fwd_split_kernel(const uint4 *__restrict__ tab, const uint64_t *__restrict__ p,
                                                                            uint64_t *__restrict__ out, size_t B) {
@@ -825,6 +840,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) void ntt_fwd_split_kernel(cons
     }
 }
 
+#endif  // unit 0
+
 // the exact integers behind a (low, high) accumulator pair, combined mod 2^64: inverse transforms, N^-1, Garner lift
 #ifndef MKT_EXACT_WPE
 #define MKT_EXACT_WPE 2
@@ -836,6 +853,7 @@ __device__ __forceinline__ void lift_pair(Pt (&x)[2][8], uint64_t (&w)[8], const
     for (int e = 0; e < 8; e++) w[e] = crt_signed(x[0][e]) + (crt_signed(x[1][e]) << 32);
 }
 
+#if MKT_NTT_IN(2)
 // KMS phase 1 (bootstrapping.jl:389-443) with exact products: one workgroup per RLEV row rotation, accumulator (b, a) in
 // registers (slot e = coefficient e*NT + t); output: the row's two polynomials as split residue tables for phase 2
 template <int LOGN, bool BLK>
@@ -1210,6 +1228,9 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
     }
 }
 
+#endif  // unit 2
+
+#if MKT_NTT_IN(3)
 // KMS phase 2 (bootstrapping.jl:448-558) with exact products; one workgroup per ciphertext, every thread only touches its
 // own coefficients (e*NT + t) and transform points (8t + e)
 struct ExactPhase2Args {
@@ -1466,6 +1487,8 @@ __global__ __launch_bounds__((1 << (LOGN - NLR))) __attribute__((amdgpu_waves_pe
     }
 }
 
+#endif  // unit 3
+
 template <typename K>
 static hipError_t ntt_set_lds(K kern, size_t bytes) {
     if (bytes > 48 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1495,6 +1518,7 @@ static hipError_t ntt_set_lds(K kern, size_t bytes) {
     }
 #endif
 
+#if MKT_NTT_IN(0)
 template <int LN, typename WORD, bool MONT>
 static hipError_t ntt_fwd_launch(const uint4 *tb, const void *p, uint64_t *t, size_t B, int grid, size_t lds, hipStream_t s) {
     hipError_t e = ntt_set_lds(ntt_fwd_kernel<LN, WORD, MONT>, lds);
@@ -1547,6 +1571,8 @@ hipError_t launch_exact_polymul(int logN, int W, const uint64_t *tab, const void
     return hipGetLastError();
 }
 
+#endif  // unit 0
+#if MKT_NTT_IN(1)
 hipError_t launch_exact_blindrotate(int logN, const uint64_t *tab, const uint64_t *brk, const uint64_t *mono, const uint32_t *lwe, int lwe_stride,
                                     int pre_switched, int n, int l, int logB, int blk_len, uint32_t *acc, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
@@ -1596,6 +1622,8 @@ hipError_t launch_exact_blindrotate_kany(int logN, const uint64_t *tab, const ui
     return hipGetLastError();
 }
 
+#endif  // unit 1
+#if MKT_NTT_IN(0)
 hipError_t launch_ntt_fwd_split(int logN, const uint64_t *tab, const void *p, uint64_t *out, size_t B, hipStream_t s) {
     if (!B) return hipSuccess;
     const int grid = (int)(B < 32768 ? B : 32768);
@@ -1608,8 +1636,10 @@ hipError_t launch_ntt_fwd_split(int logN, const uint64_t *tab, const void *p, ui
     return hipGetLastError();
 }
 
-hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a, size_t B, hipStream_t s) {
-    if (!B) return hipSuccess;
+#endif  // unit 0
+#if MKT_NTT_IN(2)
+hipError_t launch_exact_kms_phase1(int logN, const uint64_t *tab, const ExactKmsArgs &a, size_t B, hipStream_t s) {      // internal: phase 1 of launch_exact_kms (unit 2)
+    if (!B || a.phase2_only) return hipSuccess;
     last_rot_kernel = "exact_kms_phase1_kernel";
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
     MKT_NTT_DISPATCH(logN, {
@@ -1637,7 +1667,20 @@ hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a
                                    a.lwe, a.lwe_stride, a.pre_switched, a.n, a.l_gsw, a.logB_gsw, 1, B, a.rtot, a.slot_party, a.slot_row, a.logB_lev, a.levkey);
             }
         }
-        if (a.phase1_only) return hipGetLastError();
+    });
+    return hipGetLastError();
+}
+#endif  // unit 2
+#if MKT_NTT_IN(3)
+hipError_t launch_exact_kms_phase1(int logN, const uint64_t *tab, const ExactKmsArgs &a, size_t B, hipStream_t s);
+hipError_t launch_exact_kms(int logN, const uint64_t *tab, const ExactKmsArgs &a, size_t B, hipStream_t s) {
+    if (!B) return hipSuccess;
+    hipError_t e1 = launch_exact_kms_phase1(logN, tab, a, B, s);
+    if (e1 != hipSuccess || a.phase1_only) return e1;
+    const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
+    MKT_NTT_DISPATCH(logN, {
+        const size_t lds = lds_bytes<LN>(1, 2);
+        hipError_t e = hipSuccess;
         ExactPhase2Args q;
         q.lin = a.lin_for_tv; q.lwe_stride = a.lwe_len; q.k = a.k; q.l_lev = a.l_lev; q.logB_lev = a.logB_lev; q.l_uni = a.l_uni; q.logB_uni = a.logB_uni; q.rtot = a.rtot;
         q.levkey = a.levkey; q.rlk_d = a.rlk_d; q.rlk_f = a.rlk_f; q.pub_b = a.pub_b; q.crs = a.crs; q.acc = a.acc; q.scratch = a.scratch;
@@ -1661,5 +1704,7 @@ hipError_t launch_exact_ccs(int logN, const uint64_t *tab, const ExactCcsHostArg
     });
     return hipGetLastError();
 }
+
+#endif  // unit 3
 
 }  // namespace mktd

@@ -1,4 +1,4 @@
-# usage: bash tools/variant.sh <source: fx_exact | ntt_exact | rot_block_32 | ...> <sfx> "<-D flags>"
+# usage: bash tools/variant.sh <source: fx_exact | ntt_exact_0..3 | rot_block_32 | rot_block_64 | ccs_pipe | keygen> <sfx> "<-D flags>"
 # libmktfhe_hip_<sfx>.so = the default build with ONE translation unit recompiled with extra flags and context.o rebuilt with a build id
 # that names the variant (so that bench.py never quotes the default build's committed PMC traffic for it).  Development A/B builds; run
 # them with tools/sweep.sh --libs "base <sfx>" (selected through MKT_LIB_PATH).  The default build must be current.
@@ -8,6 +8,7 @@ mkdir -p /tmp/mkt_tuv
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-cuda-compat -Wno-pass-failed -Wno-unused-function"
 case $SRC in
   rot_block_32|rot_block_64) FILE=rot_block.hip; EXTRA="$EXTRA -DMKT_BLK_WORD=${SRC#rot_block_}";;
+  ntt_exact_[0-3]) FILE=ntt_exact.hip; EXTRA="$EXTRA -DMKT_NTT_TU=${SRC#ntt_exact_}";;      # one kernel family of ntt_exact.hip (see its header)
   *) FILE=$SRC.hip;;
 esac
 /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $FILE -o /tmp/mkt_tuv/${SRC}_$SFX.o || { echo "compile failed"; exit 1; }
