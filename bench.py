@@ -539,7 +539,7 @@ def fx_rot_roofline(mk, p, B, t, kern, workload):
     avg_ms = t["rot_ms"] / max(t["rot_n"], 1)
     peak = 256 * 4 * 16 * 2.4e9 / 1e12
     ach = instr / (avg_ms * 1e-3) / 1e12
-    fill = 256 * (4 if lg <= 9 else 2 if lg == 10 else 1)
+    fill = 256 * 4 if (p.W == 64 and lg <= 9) else 1 << 62             # launch_fx_blindrotate: one launch per chip-fill on the 64-bit ring up to N = 1024, one launch elsewhere
     r = {"bound": "f64-valu-issue (FMA)", "kernel": kern, "achieved": ach, "peak": peak, "unit": "T f64 lane-instr/s", "frac": ach / peak, "traffic": None,
          "algorithmic_f64_instr_per_launch": instr, "f64_instr_per_point_and_cmux": per_point, "avg_launch_ms": avg_ms, "launches_timed": t["rot_n"],
          "kernel_launches_per_batch": -(-int(rows * B / launches_per_step) // fill),

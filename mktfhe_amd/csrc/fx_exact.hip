@@ -26,7 +26,6 @@
 #include <stdint.h>
 
 #include "kernel_common.h"
-#include <cstdio>
 
 namespace mktd {
 
@@ -296,21 +295,12 @@ __global__ __launch_bounds__((Plan<LOGM, FLR>::NT)) void fx_polymul_kernel(const
 // the same words as the transform-domain monomial product, and the rounded integer is half as large).
 // brk: [party][n][2l][2][NL][M], device point order, scaled by 1 / M.
 // -------------------------------------------------------------------------------------------------------------------
-// development switch (speed only; tools/variant.sh fx_exact <sfx> "-D..."): digits whose key rows of a step's FIRST group are requested before the
-// digit transforms.  -1: two at gadget length 2 (headline 35.9 -> 33.8 ms), none at length 3 (the 32 registers they hold there are spilled:
-// CGGIparam 9.5 -> 20.2 ms).  Measured and not kept (profiles/r06_experiments.txt): the same ahead of every group's inverse transform (a spill reload
-// inside the inverse then waits for them -- scratch and buffer loads share one in-order counter: 33.8 -> 74.9 ms), the turn by X^at per output
-// polynomial (chaotic: 33.8 ... 97.7 ms with the register allocation), its LDS reads requested together (+-0), the inverse's twiddles read from
-// the LDS table (conj(fx_om[2^b + rev_b(j)]) = exp(+i pi j / 2^b): 28 registers less, 35.6 -> 41.8 ms), exchange routes 0 / 1 (100 / 39.7 ms).
-#ifndef MKT_FX_PF0
-#define MKT_FX_PF0 -1
-#endif
-#ifndef MKT_FX_KBATCH      // 1 (default): the key rows of a group are requested in explicit units, a fixed number of units ahead of the multiply-adds that use them
-#define MKT_FX_KBATCH 1    // (below); 0: left to the compiler -- which keeps ~10 loads in flight at some instantiations (headline 31.2 ms either way, CGGIparam 9.85
-#endif                     // vs 9.36 ms) and collapses to ONE load in flight on the 64-bit ring at gadget length 3 or N >= 2048 (KMS2party 284 vs 102 ms)
-#ifndef MKT_FX_KBPRE
-#define MKT_FX_KBPRE 0
-#endif
+// Key rows are requested in explicit UNITS -- the KBU points of one digit, both limbs of the group (2 KBU loads into their own registers) -- a fixed number of units
+// (KBLA) ahead of the multiply-adds that use them, fenced with sched_barrier.  Left to itself the compiler keeps ~10 loads in flight at some instantiations and collapses
+// to ONE register quad for all loads of a group at others (64-bit ring at gadget length 3 or N >= 2048: load, wait, four multiply-adds, load ... KMS2party 284 ms against
+// 102 ms).  Units and depth by gadget length (the 2l digit transforms hold 64 / 96 registers): measured in profiles/r06_experiments.txt items 3, 4, where also what was
+// tried around it and not kept (rows requested ahead of the digit transforms or of every inverse, the turn per output polynomial, inverse twiddles from the LDS table,
+// other exchange routes and LLVM schedulers).  Speed only: tools/variant.sh fx_exact <sfx> "-DMKT_FX_KBU3=2 ...".
 #ifndef MKT_FX_KBU3
 #define MKT_FX_KBU3 1
 #endif
@@ -323,22 +313,14 @@ __global__ __launch_bounds__((Plan<LOGM, FLR>::NT)) void fx_polymul_kernel(const
 #ifndef MKT_FX_KBLA2
 #define MKT_FX_KBLA2 4
 #endif
-#ifndef MKT_FX_WPE_L3W64   // waves per SIMD the register allocator is told to hit at gadget length 3 on the 64-bit ring
-#define MKT_FX_WPE_L3W64 2
-#endif
-#ifndef MKT_FX_RTREG_L3W64 // twist factors in registers (1) or re-read through a buffer descriptor (0) there
-#define MKT_FX_RTREG_L3W64 1
-#endif
-template <typename WORD, int LT> struct FxOcc { static constexpr int W = (LT == 3 && sizeof(WORD) == 8) ? MKT_FX_WPE_L3W64 : 2; };
 template <int LOGM, typename WORD, int LT>
-__global__ __launch_bounds__((Plan<LOGM, FLR>::NT)) __attribute__((amdgpu_waves_per_eu(FxOcc<WORD, LT>::W, FxOcc<WORD, LT>::W)))
+__global__ __launch_bounds__((Plan<LOGM, FLR>::NT)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fx_blindrotate_kernel(const FxRotArgs a) {
     constexpr int NB = 2;
     using P = Plan<LOGM, FLR, NB>;
     constexpr int R = 4, NT = P::NT, M = P::M, N = 2 * M, W = WordTraits<WORD>::W, NL = W / 16, G2 = 2 * LT;
     constexpr int MO = -1;
-    constexpr bool KBATCH = MKT_FX_KBATCH != 0;
-    constexpr int PF0 = KBATCH ? 0 : MKT_FX_PF0 < 0 ? (LT == 2 ? 2 : 0) : (MKT_FX_PF0 < G2 ? MKT_FX_PF0 : G2);
+    constexpr int KBU = LT >= 3 ? MKT_FX_KBU3 : MKT_FX_KBU2, UPG = R / KBU, NU = G2 * UPG, LA = LT >= 3 ? MKT_FX_KBLA3 : MKT_FX_KBLA2;
     cplx *lds = reinterpret_cast<cplx *>(mkt_smem);
     const int t = threadIdx.x;
     const LaneX lx = make_lanex();
@@ -363,12 +345,9 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
 #pragma unroll
     for (int e = 0; e < R; e++) vo_dev[e] = (unsigned)dev_pos(1, t * R + e, NT) * 16u;
     const Gadget<WORD> gd(LT, a.logB);
-    constexpr bool RTREG = !(LT == 3 && sizeof(WORD) == 8) || MKT_FX_RTREG_L3W64;
-    const __amdgpu_buffer_rsrc_t rs_tw = table_rsrc(a.twist, (size_t)M * sizeof(cplx));
-    cplx rt_reg[R];                               // rho^j of this thread's points j = e*NT + t (twist; the untwist conjugates it)
+    cplx rt[R];                                   // rho^j of this thread's points j = e*NT + t (twist; the untwist conjugates it)
 #pragma unroll
-    for (int e = 0; e < R; e++) rt_reg[e] = a.twist[e * NT + t];
-    auto rtw = [&](int e) { return RTREG ? rt_reg[e] : table_load(rs_tw, (unsigned)(e * NT + t) * 16u, 0); };
+    for (int e = 0; e < R; e++) rt[e] = a.twist[e * NT + t];
     FxItw<LOGM> itw; itw.load(a.nat, t);
 
     WORD acc[2][R][2];
@@ -393,34 +372,6 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
         at_raw = at_src[i + 1 < a.n ? i + 1 : i];
         if (at == 0) continue;                                          // :48 / :413
 
-        const unsigned so_bit = (unsigned)((size_t)i * G2 * 2 * NL * M * sizeof(cplx));
-        cplx kpf[PF0 > 0 ? PF0 : 1][R][NB];
-        if constexpr (PF0 > 0) {
-#pragma unroll
-            for (int g = 0; g < PF0; g++)
-#pragma unroll
-                for (int e = 0; e < R; e++)
-#pragma unroll
-                    for (int h2 = 0; h2 < NB; h2++) kpf[g][e][h2] = table_load(rs_brk, vo_dev[e], so_bit + (unsigned)((((size_t)g * 2) * NL) * M * sizeof(cplx)) + (unsigned)(h2 * M * sizeof(cplx)));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // KBATCH: request units = KBU points of one digit, both limbs (2 KBU loads), LA units in flight ahead of the one in use
-        constexpr int KBU = LT >= 3 ? MKT_FX_KBU3 : MKT_FX_KBU2, UPG = R / KBU, NU = G2 * UPG, LA = LT >= 3 ? MKT_FX_KBLA3 : MKT_FX_KBLA2;
-        constexpr bool KBPRE = KBATCH && MKT_FX_KBPRE;      // the first group's first LA units are requested before the digit transforms
-        cplx kb[KBATCH ? LA + 1 : 1][KBU][NB];
-        auto req = [&](int c, int h0, int u) {
-            const int g = u / UPG, e0 = (u % UPG) * KBU;
-            const unsigned so_row = so_bit + (unsigned)((((size_t)g * 2 + c) * NL + h0) * M * sizeof(cplx));
-#pragma unroll
-            for (int e = 0; e < KBU; e++)
-#pragma unroll
-                for (int h2 = 0; h2 < NB; h2++) kb[u % (LA + 1)][e][h2] = table_load(rs_brk, vo_dev[e0 + e], so_row + (unsigned)(h2 * M * sizeof(cplx)));
-        };
-        if constexpr (KBPRE) {
-#pragma unroll
-            for (int u = 0; u < LA && u < NU; u++) req(0, 0, u);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         // the 2l digit transforms (b digits, then a digits), two at a time, all kept
         cplx D[G2][R];
 #pragma unroll
@@ -435,9 +386,8 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
                 for (int e = 0; e < R; e++) {
                     const WORD w0 = isa ? acc[1][e][0] : acc[0][e][0], w1 = isa ? acc[1][e][1] : acc[0][e][1];
                     const double d0 = (double)gd.digit(gd.prep(w0), j), d1 = (double)gd.digit(gd.prep(w1), j);
-                    const cplx r = rtw(e);
-                    z[h2][e].re = fma_(d0, r.re, d1 * r.im);
-                    z[h2][e].im = fma_(d0, r.im, -(d1 * r.re));
+                    z[h2][e].re = fma_(d0, rt[e].re, d1 * rt[e].im);
+                    z[h2][e].im = fma_(d0, rt[e].im, -(d1 * rt[e].re));
                 }
             }
             fx_forward<LOGM, NB, MO>(z, om_l, lds, t, lx);
@@ -447,6 +397,7 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
                 for (int e = 0; e < R; e++) D[g0 + h2][e] = z[h2][e];
         }
 
+        const unsigned so_bit = (unsigned)((size_t)i * G2 * 2 * NL * M * sizeof(cplx));
         WORD wsum[2][R][2];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -457,57 +408,41 @@ void fx_blindrotate_kernel(const FxRotArgs a) {
                 for (int h2 = 0; h2 < NB; h2++)
 #pragma unroll
                     for (int e = 0; e < R; e++) { S[h2][e].re = 0.0; S[h2][e].im = 0.0; }
-                if constexpr (KBATCH) {
-                    // the key rows of one digit are requested TOGETHER (distinct registers) and the next digit's while this one's multiply-adds run: left
-                    // to itself the compiler reuses ONE register quad for all 48 loads of a group at gadget length 3 on the 64-bit ring -- load, wait,
-                    // four multiply-adds, load ... -- and a step exposes 192 round trips (KMS2party 3.6 k gates/s; profiles/r06_experiments.txt)
-                    // (unit = KBU points of one digit, both limbs: 2 KBU loads; at gadget length 3 the 64 registers of two 4-point units next to the 96 of
-                    // the digit transforms were spilled -- 192 scratch accesses per step -- so the unit is 2 points there)
-                    if (!(KBPRE && c == 0 && h0 == 0)) {
-#pragma unroll
-                        for (int u = 0; u < LA && u < NU; u++) req(c, h0, u);
-                    }
-#pragma unroll
-                    for (int u = 0; u < NU; u++) {
-                        if (u + LA < NU) req(c, h0, u + LA);
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int g = u / UPG, e0 = (u % UPG) * KBU;
-#pragma unroll
-                        for (int e = 0; e < KBU; e++)
-#pragma unroll
-                            for (int h2 = 0; h2 < NB; h2++) {
-                                const cplx k = kb[u % (LA + 1)][e][h2], d = D[g][e0 + e];
-                                S[h2][e0 + e].re = fma_(-d.im, k.im, fma_(d.re, k.re, S[h2][e0 + e].re));
-                                S[h2][e0 + e].im = fma_(d.im, k.re, fma_(d.re, k.im, S[h2][e0 + e].im));
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else {
-#pragma unroll
-                for (int g = 0; g < G2; g++) {
+                cplx kb[LA + 1][KBU][NB];
+                auto req = [&](int u) {
+                    const int g = u / UPG, e0 = (u % UPG) * KBU;
                     const unsigned so_row = so_bit + (unsigned)((((size_t)g * 2 + c) * NL + h0) * M * sizeof(cplx));
 #pragma unroll
-                    for (int e = 0; e < R; e++) {
+                    for (int e = 0; e < KBU; e++)
+#pragma unroll
+                        for (int h2 = 0; h2 < NB; h2++) kb[u % (LA + 1)][e][h2] = table_load(rs_brk, vo_dev[e0 + e], so_row + (unsigned)(h2 * M * sizeof(cplx)));
+                };
+#pragma unroll
+                for (int u = 0; u < LA && u < NU; u++) req(u);
+#pragma unroll
+                for (int u = 0; u < NU; u++) {                          // :427-432 S += D_g (.) K[i][g][c][limb]
+                    if (u + LA < NU) req(u + LA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int g = u / UPG, e0 = (u % UPG) * KBU;
+#pragma unroll
+                    for (int e = 0; e < KBU; e++)
 #pragma unroll
                         for (int h2 = 0; h2 < NB; h2++) {
-                            const cplx k = (c == 0 && h0 == 0 && g < PF0) ? kpf[g < PF0 ? g : 0][e][h2] : table_load(rs_brk, vo_dev[e], so_row + (unsigned)(h2 * M * sizeof(cplx)));
-                            const cplx d = D[g][e];
-                            S[h2][e].re = fma_(-d.im, k.im, fma_(d.re, k.re, S[h2][e].re));
-                            S[h2][e].im = fma_(d.im, k.re, fma_(d.re, k.im, S[h2][e].im));
+                            const cplx k = kb[u % (LA + 1)][e][h2], d = D[g][e0 + e];
+                            S[h2][e0 + e].re = fma_(-d.im, k.im, fma_(d.re, k.re, S[h2][e0 + e].re));
+                            S[h2][e0 + e].im = fma_(d.im, k.re, fma_(d.re, k.im, S[h2][e0 + e].im));
                         }
-                    }
-                }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 fx_inverse<LOGM, NB, MO>(S, itw, lds, t, lx);
 #pragma unroll
                 for (int e = 0; e < R; e++) {
                     uint64_t b0[NB], b1[NB];
-                    const cplx r = rtw(e);
 #pragma unroll
                     for (int h2 = 0; h2 < NB; h2++) {                   // untwist by conj(rho^j), nearest integer
                         const cplx v = S[h2][e];
-                        b0[h2] = round_bits(fma_(v.re, r.re, v.im * r.im));
-                        b1[h2] = round_bits(fma_(v.re, r.im, -(v.im * r.re)));     // -(Im)
+                        b0[h2] = round_bits(fma_(v.re, rt[e].re, v.im * rt[e].im));
+                        b1[h2] = round_bits(fma_(v.re, rt[e].im, -(v.im * rt[e].re)));     // -(Im)
                     }
                     // sum_h (bits_h - MAGIC) 2^(16 h): MAGIC's pattern has 48 zero low bits, so only limb 0 carries it
                     if constexpr (W == 32) {
@@ -556,11 +491,6 @@ hipError_t fx_rot_launch(const FxRotArgs &a, size_t nrot, hipStream_t s) {
     static_assert(P::LDS_BYTES >= (size_t)4 * P::M * sizeof(WORD), "the staging buffers hold the turned sums of both polynomials");
     hipError_t e = set_lds(fx_blindrotate_kernel<LM, WORD, LT>, LB);
     if (e != hipSuccess) return e;
-    if (getenv("MKT_FX_DEBUG")) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fx_blindrotate_kernel<LM, WORD, LT>, P::NT, LB);
-        fprintf(stderr, "fx_blindrotate_kernel<%d, %d, %d>: %d threads, %zu B LDS, %d workgroups per CU, %zu rotations\n", LM, (int)sizeof(WORD) * 8, LT, P::NT, LB, nb, nrot);
-    }
     hipLaunchKernelGGL((fx_blindrotate_kernel<LM, WORD, LT>), dim3((unsigned)nrot), dim3(P::NT), LB, s, a);
     return hipGetLastError();
 }
@@ -611,12 +541,13 @@ hipError_t launch_fx_blindrotate(int logM, int W, const FxRotArgs &a, size_t nro
     if (!nrot) return hipSuccess;
     if (!fx_supported(logM, W, a.l)) return hipErrorInvalidValue;
     last_rot_kernel = "fx_blindrotate_kernel";
-    // One launch per chip-fill.  Every rotation of a party walks the same key rows, step by step, and the workgroups of ONE fill run in lock-step,
-    // so a fill reads each row from the fabric once per L2 and then hits; in a single launch of several fills the later workgroups start whenever a
-    // slot frees, the resident ones spread over all key bits and the 4 x larger key of this arithmetic no longer fits the L2s (hit rate 0.66,
-    // profiles/r06_experiments.txt).  a.split: 0 = one fill per launch (256 CUs x the workgroups LDS admits), -1 = one launch, > 0 = that many workgroups.
+    // One launch per chip-fill on the 64-bit ring up to N = 1024.  Every rotation of a party walks the same key rows, step by step, and the workgroups of ONE fill run in
+    // lock-step, so a fill reads each row from the fabric once per L2 and then hits; in a single launch of several fills the later workgroups start whenever a slot frees,
+    // the resident ones spread over all key bits and the 4 x larger key of this arithmetic no longer fits the L2s (headline: hit rate 0.66 -> 0.96, 34.3 -> 31.6 ms).  At
+    // N = 2048 (512 workgroups per fill, hit rate 0.98 either way) the six launch tails cost more than the locality gives (KMS2party 105.2 vs 101.7 ms in one launch), on the
+    // 32-bit ring it makes no difference (profiles/r06_experiments.txt).  a.split: 0 = this rule, -1 = one launch, > 0 = that many workgroups per launch.
     size_t chunk = nrot;
-    if (a.split == 0) chunk = (size_t)256 * (logM <= 9 ? 4 : logM == 10 ? 2 : 1);
+    if (a.split == 0 && W == 64 && logM <= 9) chunk = (size_t)256 * 4;
     else if (a.split > 0) chunk = (size_t)a.split;
     for (size_t b0 = 0; b0 < nrot; b0 += chunk) {
         FxRotArgs b = a;
