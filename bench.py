@@ -31,11 +31,14 @@ the flat NAND rate of the same parameter set measured in the same run.
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline           -- the kernel that costs the time, blindrotate_k1_kernel (93 % of a step): bound = f64 VALU issue
                         WITHOUT FMA (the reference's arithmetic rounds after every multiply and every add), achieved =
-                        algorithmic flop per launch / average launch time from HIP events on the engine's stream.
+                        algorithmic flop per launch / average launch time from HIP events on the engine's stream;
+                        issue_roofline inside it = the kernel's MEASURED VALU instruction count (committed PMC pass of this
+                        build) priced at the class costs of its own instruction mix (profiles/isa_<build_id>.json).
   roofline_transform -- the batched negacyclic transforms HBM -> HBM (BASELINE.json's second metric), forward and
                         inverse at N = 1024 and N = 2048, working set >= 4 GiB, against 8 TB/s.
   secondary          -- the same measurement on the reference's own two-party set KMS2party (params.jl:47-53).
-  exact_mode         -- the headline workload in MKT_ARITH_EXACT (the integer NTT the north star names), N = 1 only.
+  exact_mode         -- the headline workload in MKT_ARITH_EXACT under both implementations (Float64 FMA transforms over 16-bit key
+                        limbs; the integer NTT the north star names), the same words, N = 1 only.
   cpu_baseline       -- the C oracle (restatement of the reference CPU path, F64REF) timed on this box's host cores
                         on a bounded sample of the same workload; kind "port".
 """
@@ -721,7 +724,7 @@ def main():
     ap.add_argument("--launcher", default="ranks", choices=["ranks", "inproc"], help="ranks: one process per GPU under torch.distributed (default); inproc: one process, all GPUs through mkt_multi_*")
     ap.add_argument("--instances", type=int, default=1024, help="--workload adder8: independent circuit instances")
     ap.add_argument("--op", default="nand", choices=["nand", "mux"], help="nand (default: the metric); mux: the native MUX gate, two blind rotations + one key switch per gate (ranks launcher)")
-    ap.add_argument("--arith", default="f64ref", choices=["f64ref", "exact"], help="f64ref: the reference's Float64 transforms, bit-identical to it (default); exact: integer NTT over two 30-bit primes (MKT_ARITH_EXACT: all five schemes)")
+    ap.add_argument("--arith", default="f64ref", choices=["f64ref", "exact"], help="f64ref: the reference's Float64 transforms, bit-identical to it (default); exact: MKT_ARITH_EXACT, exact products -- Float64 FMA transforms over 16-bit key limbs where the engine has that kernel (CGGI, KMS phase 1), the integer NTT over two 30-bit primes elsewhere (all five schemes); MKT_EXACT_IMPL=0 forces the NTT")
     ap.add_argument("--inputs", default="mixed", choices=["mixed", "fresh"], help="mixed: every ciphertext involves all k parties (default); fresh: single-party first-level encryptions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the transform legs (roofline_transform)")

@@ -61,7 +61,10 @@ enum { MKT_OP_NOT_X = 8, MKT_OP_NOT_Y = 16 };
 /* arithmetic modes of the negacyclic transform */
 enum {
     MKT_ARITH_F64REF = 0, /* the reference's Float64 twisted FFT, operation for operation (fft.jl) */
-    MKT_ARITH_EXACT = 1   /* exact integer arithmetic: the negacyclic NTT over Z_P[X]/(X^N+1) in residue form, P = p1 p2 =
+    MKT_ARITH_EXACT = 1   /* EXACT products (what the reference's transform approximates, polynomial.jl:99-113; its MultiFloat option, README.md:9), two
+                             implementations with the same words (option "exact_impl"): Float64 FMA transforms over centered 16-bit key limbs whose rounding
+                             is proven exact for the loaded keys (fx_exact.hip: CGGI with RLWE length 1, KMS phase 1; mkt_get_metric "fx_bound"), and
+                             exact integer arithmetic: the negacyclic NTT over Z_P[X]/(X^N+1) in residue form, P = p1 p2 =
                              (131063 * 2^13 + 1)(131066 * 2^13 + 1) = 2^59.9998, the two largest NTT primes below 2^30
                              (4 p < 2^32: lazy butterflies).
                              Transform-level entry points (mkt_transform_*_batch, mkt_exact_polymul_batch,
