@@ -1,4 +1,4 @@
-"""Fixed-seed slices of the builder-side soak / fuzz tools (tools/fuzz_shapes.py, tools/fuzz_exact.py, tools/soak.py), run under
+"""Fixed-seed slices of the builder-side soak / fuzz tools (tools/fuzz_shapes.py, tools/fuzz_exact.py, tools/fuzz_fx.py, tools/soak.py), run under
 the driver's `-m gpu` pass, and the MKT_ARITH_EXACT gate paths at FULL key length.
 
 * fuzz_shapes: random small shapes of every rotation kernel that has more than one implementation, each forced grouping,
@@ -36,6 +36,16 @@ def test_fuzz_exact_slice(require_gpu):
     bad, refused = fuzz_exact.run(rounds=10, seed=102, log=log.append)      # seed 102: all five scheme kinds (LMSS with block lengths 2, 3, 4 and RLWE length 1, 2) and two gadgets beyond the modulus
     assert bad == 0, "\n".join(log)
     assert refused >= 1, "the slice must include a gadget beyond the modulus\n" + "\n".join(log)
+
+
+def test_fuzz_fx_slice(require_gpu):
+    """tools/fuzz_fx.py: the two EXACT implementations of the RLWE-length-1 blind rotation (Float64 pipe / integer NTT) on random accumulators, random
+    shapes N = 128 .. 4096 and gadgets, ragged batches: the same words (and the big-integer restatement's at N <= 256)"""
+    import fuzz_fx
+    log = []
+    bad, on_fx, _ = fuzz_fx.run(rounds=10, seed=61, log=log.append)
+    assert bad == 0, "\n".join(log)
+    assert on_fx >= 6, "\n".join(log)
 
 
 @pytest.mark.parametrize("p,arith", [(mk.CGGIparam, 0), (mk.KMS2party_N1024_l2, 0), (mk.Blockparam, 0), (mk.CCS2party, 0), (mk.KMS2party_N1024_l2, 1), (mk.CGGIparam, 1)],
