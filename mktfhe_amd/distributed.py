@@ -49,7 +49,7 @@ def _verdict_store(rank, world, port, wait_s):
     import torch.distributed as dist
     store = dist.TCPStore(os.environ["MASTER_ADDR"], port + 2, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=wait_s), wait_for_workers=False)
     nonce = os.environ.get("TORCHELASTIC_RUN_ID", "run") + "." + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
-    return dist.PrefixStore(f"mkt/{nonce}", store)
+    return dist.PrefixStore(f"mkt/{nonce}", store), dist.PrefixStore(f"mkt/{nonce}/fallback_group", store)
 
 
 def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900, agree_s=180, _test_fail_ranks=()):
@@ -60,8 +60,9 @@ def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900
     (communicator created; probe all-reduce correct) is agreed through a small store of its own (_verdict_store) before any rank acts on
     it, and nobody enters the probe collective unless every rank holds a communicator.  What this cannot shorten is a rank that never
     ARRIVES at a collective (creation and the probe are collectives themselves): the others then wait out `timeout_s`.
-    Ports: MASTER_PORT (the group), + 1 (the fallback group), + 2 (the verdicts).  `_test_fail_ranks`: tests only -- these ranks report a local
-    failure of the probe after its collective."""
+    Ports: MASTER_PORT (the group), + 2 (the verdicts AND the fallback group's rendezvous: under torch.distributed.run the ranks are clients of the
+    launcher's store on MASTER_PORT, so a second env:// rendezvous on another port would find no server -- the fallback group is built on the
+    verdict store, which rank 0 hosts itself).  `_test_fail_ranks`: tests only -- these ranks report a local failure of the probe after its collective."""
     import datetime
     import sys
     import torch
@@ -74,9 +75,9 @@ def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900
         backend = backend or "nccl"
         to = datetime.timedelta(seconds=timeout_s)
         port = int(os.environ["MASTER_PORT"])
-        verdicts = None
+        verdicts = fb_store = None
         if fallback:                                       # (fallback == backend: one retry of the same backend on a fresh store)
-            verdicts = _VERDICTS = _verdict_store(rank, world, port, agree_s)     # raises if unreachable: fatal on that rank, and the others time out on its verdict
+            verdicts, fb_store = _VERDICTS = _verdict_store(rank, world, port, agree_s)     # raises if unreachable: fatal on that rank, and the others time out on its verdict
         why = None
         try:
             kw = {}
@@ -111,9 +112,8 @@ def init_process_group(backend=None, device=None, fallback="gloo", timeout_s=900
                     dist.destroy_process_group()
             except Exception:       # noqa: BLE001
                 pass
-            os.environ["MASTER_PORT"] = str(port + 1)      # a fresh store: every rank takes the same step
             backend = fallback
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=to)
+            dist.init_process_group(backend, store=fb_store, rank=rank, world_size=world, timeout=to)     # a fresh key space: every rank takes the same step
         ACTIVE_BACKEND = backend
         if verdicts is not None:
             dist.barrier()                                 # every rank has read every verdict; the store lives as long as rank 0's process

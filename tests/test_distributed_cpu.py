@@ -86,14 +86,14 @@ def _lone_failure_worker(rank, world, port, ret):
     D.init_process_group("gloo", device=None, fallback="gloo", agree_s=60, _test_fail_ranks=(1,))     # rank 1's probe fails locally, rank 0's succeeds
     t = torch.ones(1)
     torch.distributed.all_reduce(t)
-    ret[rank] = (D.ACTIVE_BACKEND, float(t.item()), os.environ["MASTER_PORT"])
+    ret[rank] = (D.ACTIVE_BACKEND, float(t.item()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
 def test_ranks_agree_before_switching_backend_when_only_one_of_them_failed():
     """one rank's probe of the first process group fails locally, the other's succeeds: the verdicts are exchanged first, so BOTH move to
-    the fallback group on the fresh store (a rank that switched alone would leave the other waiting in a collective until its timeout)"""
+    the fallback group on the verdict store's fresh key space (a rank that switched alone would leave the other waiting in a collective until its timeout)"""
     world, port = 2, 29700 + (os.getpid() % 90)
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
@@ -103,7 +103,28 @@ def test_ranks_agree_before_switching_backend_when_only_one_of_them_failed():
     for pr in procs:
         pr.join(180)
         assert pr.exitcode == 0
-    assert ret[0] == ret[1] == ("gloo", 2.0, str(port + 1))
+    assert ret[0] == ret[1] == ("gloo", 2.0)
+
+
+def test_fallback_under_the_drivers_launcher(tmp_path):
+    """the driver's launch line (python -m torch.distributed.run --master-addr 127.0.0.1 --master-port P): the ranks are CLIENTS of the launcher's
+    store, so the fallback group cannot rendezvous on a port of its own -- it is built on the verdict store rank 0 hosts (no GPU here: RCCL
+    fails on every rank, both fall back to gloo and reduce)"""
+    import subprocess
+    w = tmp_path / "w.py"
+    w.write_text(f"""import os, sys, torch
+sys.path.insert(0, {ROOT!r})
+from mktfhe_amd import distributed as D
+r, w, l = D.init_process_group("nccl", device=None, agree_s=60, timeout_s=120)
+t = torch.ones(1); torch.distributed.all_reduce(t)
+print("RANK", r, D.ACTIVE_BACKEND, float(t.item()), flush=True)
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+""")
+    port = 29800 + (os.getpid() % 90)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(w)], capture_output=True, text=True, timeout=240, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RANK 0 gloo 2.0" in out.stdout and "RANK 1 gloo 2.0" in out.stdout, out.stdout
 
 
 def test_shard_slices():
