@@ -39,7 +39,7 @@ for title, name, big in rows:
     else:
         exs = "—"
     cb = d.get("cpu_baseline")
-    print(f"| {title} | {('**' + v + '**') if name == 'kms2_n1024' else v} | {d['kernels_ms_per_step']['blindrotate']:.1f} ms | {r['frac']:.3f} / {ir.get('frac_at_sustained_clock', float('nan')):.2f} | {exs} | {(str(round(cb['value'])) + ' (' + str(cb['cores']) + ')') if cb else '—'} |")
+    print(f"| {title} | {('**' + v + '**') if name == 'kms2_n1024' else v} | {d['kernels_ms_per_step']['blindrotate']:.1f} ms | {r['frac']:.3f} / {('%.2f' % ir['frac_at_sustained_clock']) if 'frac_at_sustained_clock' in ir else '—'} | {exs} | {(str(round(cb['value'])) + ' (' + str(cb['cores']) + ')') if cb else '—'} |")
 a = line("adder8")
 if a:
     print(f"| 1024 eight-bit adder circuits, one call per level | {k(a['circuit']['gates_per_s'] if 'circuit' in a and 'gates_per_s' in a['circuit'] else a['value'])} gates/s | — | — | — | — |")
